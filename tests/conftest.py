@@ -1,0 +1,58 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def tparams(cfg, seed, dtype=torch.float32, device="cpu"):
+    return {k: torch.from_numpy(v).to(device=device, dtype=dtype) for k, v in cfg.make_params(seed).items()}
+
+
+def replay_list(gold):
+    out, i = [], 0
+    while f"rand{i}" in gold:
+        out.append(torch.from_numpy(gold[f"rand{i}"]))
+        i += 1
+    return out
+
+
+def assert_close(a, b, rtol=1e-4, atol=1e-6, msg=""):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, f"{msg}: shape {a.shape} vs {b.shape}"
+    both_nan = np.isnan(a) & np.isnan(b)          # the reference itself yields NaN there (e.g. grazing angles)
+    a = np.where(both_nan, 0.0, a)
+    b = np.where(both_nan, 0.0, b)
+    with np.errstate(invalid="ignore"):
+        err = np.abs(a - b)
+        err = np.where(np.isnan(err), np.inf, err)
+        tol = atol + rtol * np.abs(b)
+    if not np.all(err <= tol):
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(f"{msg}: max violation at {i}: got {a[i]!r} want {b[i]!r} (|err|={err[i]:.3e}, "
+                             f"tol={tol[i]:.3e}); max|err|={err.max():.3e}")

@@ -1,0 +1,222 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself
+(tests/golden/make_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, tparams, replay_list, assert_close
+from oracle.config import FieldConfig
+from oracle import field as F, render as RD, brdf as B, losses as L
+
+CONFIGS = {
+    "lambert": dict(),
+    "rpv111_nan": dict(funcM=1, funcF=1, funcH=1, normal="analystic"),
+    "rpv111_nlr": dict(funcM=1, funcF=1, funcH=1, normal="learned"),
+    "hapke_bc": dict(b=1, c=1, normal="analystic"),
+    "hapke_bct": dict(b=1, c=1, theta=1, normal="learned"),
+    "microfacet": dict(roughness=True, normal="learned"),
+}
+
+
+def mini(**kw):
+    base = dict(feat=64, n_samples=16, guided_samples=16)
+    base.update(kw)
+    return FieldConfig(**base)
+
+
+def checksum(cfg, seed):
+    return float(sum(v.astype(np.float64).sum() for v in cfg.make_params(seed).values()))
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_field_forward_matches_reference(name):
+    g = load_golden(f"field_{name}_F64")
+    cfg = mini(**CONFIGS[name])
+    assert abs(checksum(cfg, 11) - float(g["param_checksum"])) < 1e-9
+    p = tparams(cfg, 11)
+    xyz = torch.from_numpy(g["xyz"])
+    an = cfg.normal in ("analystic", "analystic_learned")
+    lr = cfg.normal in ("learned", "analystic_learned")
+    out = F.field_forward(p, cfg, xyz, apply_brdf=True, apply_theta=True, nr_an_on=an, nr_lr_on=lr)
+    assert out.shape[1] == cfg.out_channels(True, True)
+    assert_close(out, g["out_brdf"], 1e-5, 1e-6, "out_brdf")
+    out0 = F.field_forward(p, cfg, xyz, apply_brdf=False, nr_an_on=an, nr_lr_on=lr)
+    assert_close(out0, g["out_nobrdf"], 1e-5, 1e-6, "out_nobrdf")
+    assert_close(F.field_forward(p, cfg, xyz, sigma_only=True), g["sigma"], 1e-5, 1e-6, "sigma")
+
+
+def test_field_forward_F512():
+    g = load_golden("field_rpv111_nan_F512")
+    cfg = FieldConfig(**CONFIGS["rpv111_nan"])
+    assert cfg.n_params() == 2690567          # SURVEY.md section 8 row a4 [probed]
+    assert FieldConfig().n_params() == 2295812
+    p = tparams(cfg, 12)
+    out = F.field_forward(p, cfg, torch.from_numpy(g["xyz"]), apply_brdf=True, nr_an_on=True)
+    assert out.shape[1] == 16
+    assert_close(out, g["out_brdf"], 2e-4, 2e-5, "F512 out")
+
+
+def test_sigma_grad_closed_form_fp64():
+    g = load_golden("field_sigma_grad_F64_fp64")
+    cfg = mini(**CONFIGS["rpv111_nan"])
+    p = tparams(cfg, 11, torch.float64)
+    x = torch.from_numpy(g["xyz"])
+    assert_close(F.sigma_grad(p, cfg, x, create_graph=False), g["grad"], 1e-10, 1e-12, "autograd")
+    assert_close(F.sigma_grad_closed_form(p, cfg, x), g["grad"], 1e-10, 1e-12, "closed form")
+
+
+@pytest.mark.parametrize("S", [16, 128])
+def test_composite(S):
+    g = load_golden(f"composite_S{S}")
+    z = torch.from_numpy(g["z"])
+    sigma = torch.from_numpy(g["sigma"]).requires_grad_(True)
+    a, T, w, d = RD.composite(z, sigma)
+    for got, key in ((a, "alphas"), (T, "transparency"), (w, "weights"), (d, "depth")):
+        assert np.array_equal(got.detach().numpy(), g[key]), key        # identical op sequence -> bit-exact
+    ((w * torch.from_numpy(g["cw"])).sum() + (d * torch.from_numpy(g["cd"])).sum()).backward()
+    assert_close(sigma.grad, g["dsigma"], 1e-6, 1e-9, "dsigma")
+
+
+@pytest.mark.parametrize("mode", ["test", "train"])
+def test_guided_samples(mode):
+    g = load_golden(f"guided_{mode}")
+    t = {k: torch.from_numpy(v) for k, v in g.items()}
+    rnd = RD.Randoms(replay=replay_list(g))
+    kw = {}
+    if mode == "train":
+        kw = dict(valid_depth=t["valid_depth"], target_depths=t["target_depths"], target_std=t["target_std"])
+    near0, far0 = torch.tensor(0.0), torch.tensor(2.0)
+    z2, inds, inds_gt = RD.guided_samples(t["depth"], t["weights"], t["z"], 64, near0, far0, rnd, 3.0, mode, **kw)
+    assert np.array_equal(z2.numpy(), g["z2"])
+    z2s = torch.sort(z2, -1)[0]
+    z_all, idx = torch.sort(torch.cat([t["z"], z2s], -1), -1)
+    assert np.array_equal(z_all.numpy(), g["z_all"])
+    assert np.array_equal(idx.numpy(), g["sort_idx"])
+    assert inds.dtype == torch.int64 and int(inds.min()) >= 1 and int(inds.max()) <= 63
+
+
+def test_brdf_rpv():
+    g = load_golden("brdf_rpv")
+    t = {k: torch.from_numpy(v) for k, v in g.items()}
+    n, w, k, th, rc = [t[x].clone().requires_grad_(True) for x in ("n", "w", "k", "theta", "rhoc")]
+    brdf, M1, G, H, ci, cv = B.rpv(t["l"], t["v"], n, w, k, th, rc)
+    for got, key in ((brdf, "brdf"), (M1, "M1"), (G, "G"), (H, "H"), (ci, "ci"), (cv, "cv")):
+        assert_close(got, g[key], 1e-6, 1e-7, key)
+    (brdf * t["coef"]).sum().backward()
+    for got, key in ((n, "dn"), (w, "dw"), (k, "dk"), (th, "dtheta"), (rc, "drhoc")):
+        assert_close(got.grad, g[key], 1e-5, 1e-6, key)
+
+
+@pytest.mark.parametrize("tag,use_c,use_t,shell", [("hapke_b", 0, 0, 0), ("hapke_bc", 1, 0, 0), ("hapke_bct", 1, 1, 0),
+                                                   ("hapke_shell1", 0, 0, 1), ("hapke_shell2", 0, 0, 2),
+                                                   ("hapke_shell3", 0, 0, 3)])
+def test_brdf_hapke(tag, use_c, use_t, shell):
+    g = load_golden(f"brdf_{tag}")
+    t = {k: torch.from_numpy(v) for k, v in g.items()}
+    n, w, b, c, th = [t[x].clone().requires_grad_(True) for x in ("n", "w", "b", "c", "theta")]
+    o = B.hapke(t["l"], t["v"], n, w, None if shell else b, c if use_c else None, th if use_t else None, 4.0, shell)
+    brdf, P, Bf, Hi, Hv, S, ci, cv = o
+    for got, key in ((brdf, "brdf"), (P, "P"), (Hi, "Hi"), (Hv, "Hv"), (S, "S"), (ci, "ci"), (cv, "cv")):
+        assert_close(got, g[key], 1e-5, 1e-6, key)
+    (brdf * t["coef"]).sum().backward()
+    assert_close(w.grad, g["dw"], 1e-4, 1e-6, "dw")
+    if "dn" in g:        # shell_hapke==1 does not depend on the normal (reference grad is None)
+        assert_close(n.grad, g["dn"], 1e-4, 1e-5, "dn")
+    if not shell:
+        assert_close(b.grad, g["db"], 1e-4, 1e-6, "db")
+    if use_c:
+        assert_close(c.grad, g["dc"], 1e-4, 1e-6, "dc")
+    if use_t:
+        assert_close(th.grad, g["dtheta"], 1e-4, 1e-5, "dtheta")
+
+
+def test_brdf_microfacet():
+    g = load_golden("brdf_microfacet")
+    t = {k: torch.from_numpy(v) for k, v in g.items()}
+    n, w, r = [t[x].clone().requires_grad_(True) for x in ("n", "w", "rough")]
+    gl, brdf, f, gg, d, ldn, vdn, h, n_h = B.microfacet(t["l"], t["v"], n, w, r, 0.04)
+    for got, key in ((gl, "glossy"), (brdf, "brdf"), (f, "f"), (gg, "g"), (d, "d"), (ldn, "l_dot_n"),
+                     (vdn, "v_dot_n"), (h, "h"), (n_h, "n_h")):
+        assert_close(got, g[key], 1e-5, 1e-6, key)
+    (brdf * t["coef"]).sum().backward()
+    assert_close(w.grad, g["dw"], 1e-5, 1e-6, "dw")
+    assert_close(n.grad, g["dn"], 1e-4, 1e-5, "dn")
+    assert_close(r.grad, g["drough"], 1e-4, 1e-5, "drough")
+
+
+def _render(name, mode, cfg=None, seed=11):
+    g = load_golden(f"render_{name}_{mode}")
+    cfg = cfg or mini(**CONFIGS[name])
+    p = tparams(cfg, seed)
+    for v in p.values():
+        v.requires_grad_(True)
+    rnd = RD.Randoms(replay=replay_list(g))
+    kw = {}
+    if mode == "train":
+        kw = dict(valid_depth=torch.from_numpy(g["tgt/valid_depth"]), target_depths=torch.from_numpy(g["tgt/depths"]),
+                  target_std=torch.from_numpy(g["tgt/depth_std"]))
+    res, brdf_type = RD.render_rays(p, cfg, torch.from_numpy(g["rays"]), rnd, mode=mode,
+                                    apply_brdf=name != "lambert", apply_theta=True, cos_irra_on=name != "lambert", **kw)
+    assert rnd.replay == [], "oracle consumed a different number of random draws than the reference"
+    return g, p, res, brdf_type
+
+
+@pytest.mark.parametrize("mode", ["train", "test"])
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_render_rays_matches_reference(name, mode):
+    g, p, res, brdf_type = _render(name, mode)
+    assert brdf_type == str(g["brdf_type"])
+    ref_keys = {k[4:] for k in g if k.startswith("out/")}
+    got_keys = {k for k in res if not k.startswith("_")}
+    assert ref_keys == got_keys, (sorted(ref_keys ^ got_keys))
+    for k in sorted(ref_keys):
+        if k == "sort_idx_coarse":
+            assert np.array_equal(res[k].numpy(), g["out/" + k]), k
+        else:
+            assert_close(res[k], g["out/" + k], 2e-4, 2e-5, k)
+    if mode == "train":
+        tgt = torch.from_numpy(g["tgt/rgbs"])
+        loss = torch.mean((res["rgb_coarse"] - tgt) ** 2) + 0.01 * torch.mean(res["depth_coarse"])
+        assert_close(loss, g["loss"], 1e-5, 1e-7, "loss")
+        loss.backward()
+        for k, v in p.items():
+            ref = g[f"grad/{k}"]
+            got = v.grad if v.grad is not None else torch.zeros_like(v)
+            scale = max(float(np.abs(ref).max()), 1e-12)
+            assert float((got - torch.from_numpy(ref)).abs().max()) <= 2e-3 * scale + 1e-9, k
+
+
+def test_render_F512_and_blender():
+    g = load_golden("render_rpv111_nan_F512")
+    cfg = FieldConfig(**CONFIGS["rpv111_nan"])
+    p = tparams(cfg, 12)
+    res, bt = RD.render_rays(p, cfg, torch.from_numpy(g["rays"]), RD.Randoms(replay=replay_list(g)), mode="test",
+                             apply_brdf=True, apply_theta=True, cos_irra_on=True)
+    assert bt == "RPV"
+    for k in [k[4:] for k in g if k.startswith("out/")]:
+        if k == "sort_idx_coarse":
+            assert np.array_equal(res[k].numpy(), g["out/" + k])
+        else:
+            assert_close(res[k], g["out/" + k], 1e-3, 1e-4, k)
+    g = load_golden("render_lambert_blender")
+    cfg = mini(data="blender")
+    res, bt = RD.render_rays(tparams(cfg, 11), cfg, torch.from_numpy(g["rays"]), RD.Randoms(replay=replay_list(g)))
+    for k in [k[4:] for k in g if k.startswith("out/")]:
+        if k == "sort_idx_coarse":
+            assert np.array_equal(res[k].numpy(), g["out/" + k])
+        else:
+            assert_close(res[k], g["out/" + k], 2e-4, 2e-5, k)
+
+
+def test_losses():
+    g = load_golden("loss_snerf_depth")
+    t = {k: torch.from_numpy(v) for k, v in g.items()}
+    rgb, depth, w = [t[k].clone().requires_grad_(True) for k in ("rgb", "depth", "weights")]
+    res = {"rgb_coarse": rgb, "depth_coarse": depth, "weights_coarse": w, "z_vals_coarse": t["z"]}
+    l_rgb = L.snerf_loss(res, t["tgt"])
+    l_ds = L.depth_loss(res, t["target_depths"][:, 0], t["target_depths"][:, 1], t["valid_depth"], t["target_std"], 10.0)
+    assert_close(l_rgb, g["loss_rgb"], 1e-6, 1e-8, "loss_rgb")
+    assert_close(l_ds, g["loss_ds"], 1e-6, 1e-8, "loss_ds")
+    (l_rgb + l_ds).backward()
+    assert_close(rgb.grad, g["drgb"], 1e-6, 1e-9, "drgb")
+    assert_close(depth.grad, g["ddepth"], 1e-6, 1e-9, "ddepth")
