@@ -1,0 +1,103 @@
+"""ctypes binding of the C ABI declared in include/brdfnerf_hip.h.
+
+There is NO fallback: if libbrdfnerf_hip.so is missing or fails to load, importing the product
+path raises.  (Build it with `python -m brdf_nerf_amd.build` or `__graft_entry__.build()`.)
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbrdfnerf_hip.so")
+
+BN_MAX_LAYERS = 12
+BN_MAX_HEADS = 4
+BN_F32, BN_BF16 = 0, 1
+BN_ACT_SIN, BN_ACT_RELU = 0, 1
+BN_HEAD_PLAIN, BN_HEAD_RPV_K, BN_HEAD_RPV_THETA, BN_HEAD_HAPKE_THETA, BN_HEAD_TILE3 = 0, 1, 2, 3, 4
+BN_BRDF_AUX = 16
+
+fptr = C.c_void_p
+
+
+class FieldDesc(C.Structure):
+    _fields_ = [("feat", C.c_int32), ("layers", C.c_int32), ("skip", C.c_int32), ("pe_freqs", C.c_int32),
+                ("act", C.c_int32), ("dtype", C.c_int32), ("n_heads", C.c_int32),
+                ("head_out", C.c_int32 * BN_MAX_HEADS), ("head_kind", C.c_int32 * BN_MAX_HEADS),
+                ("normal_lr", C.c_int32), ("normal_an", C.c_int32), ("out_channels", C.c_int32)]
+
+
+class FieldParams(C.Structure):
+    _fields_ = [("trunk_w", fptr * BN_MAX_LAYERS), ("trunk_b", fptr * BN_MAX_LAYERS),
+                ("sigma_w", fptr), ("sigma_b", fptr), ("feats_w", fptr), ("feats_b", fptr),
+                ("head_w1", fptr * BN_MAX_HEADS), ("head_b1", fptr * BN_MAX_HEADS),
+                ("head_w2", fptr * BN_MAX_HEADS), ("head_b2", fptr * BN_MAX_HEADS),
+                ("normal_w", fptr), ("normal_b", fptr)]
+
+
+FieldGrads = FieldParams  # identical shape (writable pointers)
+
+
+class Points(C.Structure):
+    _fields_ = [("xyz", fptr), ("rays", fptr), ("z", fptr), ("ray_stride", C.c_int32), ("n_samples", C.c_int32),
+                ("n_points", C.c_int64)]
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGS = {
+    "bn_abi_version": (C.c_int, []),
+    "bn_last_error": (C.c_char_p, []),
+    "bn_field_packed_bytes": (C.c_size_t, [C.POINTER(FieldDesc)]),
+    "bn_pack_field": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), fptr, fptr]),
+    "bn_field_stash_bytes": (C.c_size_t, [C.POINTER(FieldDesc), C.c_int64]),
+    "bn_field_sigma": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), fptr, C.POINTER(Points), fptr, fptr]),
+    "bn_field_forward": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), fptr, C.POINTER(Points), fptr, fptr,
+                                   fptr]),
+    "bn_field_backward": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), fptr, C.POINTER(Points), fptr, fptr,
+                                    fptr, C.POINTER(FieldGrads), fptr]),
+    "bn_composite_forward": (C.c_int, [fptr, fptr, C.c_int64, fptr, C.c_float, fptr, C.c_int64, C.c_int32, C.c_int64,
+                                       C.c_int32, fptr, fptr, fptr, fptr, fptr, fptr]),
+    "bn_composite_backward": (C.c_int, [fptr, fptr, C.c_int64, fptr, C.c_float, fptr, C.c_int64, C.c_int32, C.c_int64,
+                                        C.c_int32, fptr, fptr, fptr, fptr, C.c_int64, fptr, C.c_int64, fptr]),
+    "bn_stratified_z": (C.c_int, [fptr, fptr, C.c_int64, fptr, C.c_int64, C.c_int32, fptr, fptr]),
+    "bn_guided_samples": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                    C.c_float, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr]),
+    "bn_brdf_rpv_forward": (C.c_int, [fptr] * 7 + [C.c_int64, fptr, fptr, fptr]),
+    "bn_brdf_rpv_backward": (C.c_int, [fptr] * 8 + [C.c_int64] + [fptr] * 6),
+    "bn_brdf_hapke_forward": (C.c_int, [fptr] * 7 + [C.c_float, C.c_int32, C.c_int64, fptr, fptr, fptr]),
+    "bn_brdf_hapke_backward": (C.c_int, [fptr] * 7 + [C.c_float, C.c_int32, fptr, C.c_int64] + [fptr] * 6),
+    "bn_brdf_microfacet_forward": (C.c_int, [fptr] * 5 + [C.c_float, C.c_int64, fptr, fptr, fptr]),
+    "bn_brdf_microfacet_backward": (C.c_int, [fptr] * 5 + [C.c_float, fptr, C.c_int64] + [fptr] * 4),
+    "bn_adam_step": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                               C.c_float, C.c_int32, C.c_float, fptr]),
+}
+
+
+def exported_symbols():
+    """Every symbol include/brdfnerf_hip.h declares (checked by the CPU test-suite)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LibraryMissing(f"{LIB_PATH} not found: build the HIP extension first "
+                                 f"(python -m brdf_nerf_amd.build). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if L.bn_abi_version() != 1:
+            raise LibraryMissing("libbrdfnerf_hip.so ABI version mismatch; rebuild")
+        _lib = L
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        raise RuntimeError(f"{what} failed ({status}): {lib().bn_last_error().decode()}")

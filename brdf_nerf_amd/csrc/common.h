@@ -1,0 +1,111 @@
+// Shared device/host helpers for the gfx950 kernels.  CDNA4 only (wave64, MFMA 32x32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "brdfnerf_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+void bn_set_error(const char *fmt, ...);
+
+#define BN_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      bn_set_error(__VA_ARGS__);         \
+      return BN_EINVAL;                  \
+    }                                    \
+  } while (0)
+
+#define BN_LAUNCH_CHECK(what)                                             \
+  do {                                                                    \
+    hipError_t e_ = hipGetLastError();                                    \
+    if (e_ != hipSuccess) {                                               \
+      bn_set_error("%s: launch failed: %s", what, hipGetErrorString(e_)); \
+      return BN_ELAUNCH;                                                  \
+    }                                                                     \
+  } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- MFMA element traits
+// A "fragment" is 8 consecutive k-elements of one row (A) / column (B) held by lane (r = lane&31,
+// h = lane>>5) for k = 8h + j.  bf16: one v_mfma_f32_32x32x16_bf16.  f32: eight
+// v_mfma_f32_32x32x2_f32, MFMA j consuming element j of both fragments (k-permutation is
+// consistent between A and B, so the sum over k is the same).
+template <typename T> struct Elem;
+template <> struct Elem<bf16> {
+  typedef bf16x8 frag;
+  typedef bf16x4 vec4;
+  static constexpr int kBM = 128;   // points per workgroup tile
+  static constexpr int kPad = 8;    // LDS row pad (elements) = 16 B
+  static constexpr int kU = 2;      // k-steps per prefetch block
+  static constexpr bool kFastMath = true;
+};
+template <> struct Elem<float> {
+  typedef f32x8 frag;
+  typedef f32x4 vec4;
+  static constexpr int kBM = 64;
+  static constexpr int kPad = 4;
+  static constexpr int kU = 2;
+  static constexpr bool kFastMath = false;
+};
+
+__device__ __forceinline__ void mma32(f32x16 &acc, const bf16x8 &a, const bf16x8 &b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16 &acc, const f32x8 &a, const f32x8 &b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x4 to_vec4(bf16, float a, float b, float c, float d) {
+  bf16x4 v;
+  v[0] = (bf16)a; v[1] = (bf16)b; v[2] = (bf16)c; v[3] = (bf16)d;
+  return v;
+}
+__device__ __forceinline__ f32x4 to_vec4(float, float a, float b, float c, float d) {
+  f32x4 v = {a, b, c, d};
+  return v;
+}
+
+// sin/cos of the Siren / PE arguments.  Parity mode (fp32) uses the accurate libm forms; the bf16
+// throughput mode uses the hardware v_sin/v_cos (abs. error ~1e-6 for |x| < 100, far below bf16).
+// Compact accurate sincos for |x| < ~1e4 (PE arguments reach 2^9 * |xyz|): 3-term Cody-Waite reduction by pi/2
+// with FMA (exact products), then the Cephes single-precision minimax polynomials on [-pi/4, pi/4]
+// (max abs error 9.3e-8 over |x| < 1220, checked on the host).
+__device__ __forceinline__ void sincos_cw(float x, float &s, float &c) {
+  const float k = rintf(x * 0.63661977236758134f);
+  float r = fmaf(-k, 1.57079637050628662109375f, x);
+  r = fmaf(-k, -4.37113900018624283e-8f, r);
+  r = fmaf(-k, -1.71512449591634e-15f, r);
+  const float z = r * r;
+  const float S = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+  const float C = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                       fmaf(-0.5f, z, 1.0f));
+  const int q = ((int)k) & 3;
+  const float ss = (q & 1) ? C : S, cc = (q & 1) ? S : C;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
+
+template <bool FAST> __device__ __forceinline__ void sincos_t(float x, float &s, float &c) {
+  if (FAST) {
+    s = __sinf(x);
+    c = __cosf(x);
+  } else {
+    sincos_cw(x, s, c);
+  }
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// Register index i (0..15) of a 32x32 MFMA accumulator -> row offset inside the tile for lane half h:
+// row = (i & 3) + 8 * (i >> 2) + 4 * h ;  column = lane & 31.

@@ -1,0 +1,136 @@
+// Geometry, packed-weight layout and activation-stash layout of the fused field MLP.
+// Shared by the pack, forward, backward and weight-gradient kernels (host + device).
+#pragma once
+#include "common.h"
+
+#define BN_MAX_PASS 2
+
+struct FieldGeom {
+  int F, L, skip, pe_freqs, act;
+  int P;        // valid trunk input width: 6*pe_freqs, or 3 without mapping
+  int KP;       // P rounded up to 64 (60 -> 64, 3 -> 64): k-extent of the PE operand (4 MFMA k-steps)
+  int NT;       // 32-column tiles per wave in the F-wide phases (F=512: 2, else 1)
+  int H2;       // head hidden width F/2
+  int n_heads, n_pass;
+  int pass_heads[BN_MAX_PASS];  // heads evaluated in pass p (2 or 1)
+  int pass_N[BN_MAX_PASS];      // columns of pass p = pass_heads * H2
+  int pass_NTW[BN_MAX_PASS];    // tiles per wave in pass p
+  int head_col[BN_MAX_HEADS];   // first output channel of head i in `out`
+  int C;                        // out channels
+  int ch_normal_an, ch_normal_lr;  // channel index or -1
+};
+
+static inline int bn_make_geom(const bn_field_desc *d, FieldGeom *g) {
+  BN_REQUIRE(d->feat >= 64 && d->feat <= 512 && d->feat % 64 == 0 && (d->feat == 512 || d->feat <= 256),
+             "field: feat=%d unsupported (64,128,192,256,512)", d->feat);
+  BN_REQUIRE(d->layers >= 2 && d->layers <= BN_MAX_LAYERS, "field: layers=%d unsupported", d->layers);
+  BN_REQUIRE(d->skip < d->layers && d->skip != 0, "field: skip=%d invalid", d->skip);
+  BN_REQUIRE(d->n_heads >= 1 && d->n_heads <= BN_MAX_HEADS, "field: n_heads=%d", d->n_heads);
+  BN_REQUIRE(d->pe_freqs >= 0 && d->pe_freqs <= 10, "field: pe_freqs=%d", d->pe_freqs);
+  g->F = d->feat; g->L = d->layers; g->skip = d->skip; g->pe_freqs = d->pe_freqs; g->act = d->act;
+  g->P = d->pe_freqs > 0 ? 6 * d->pe_freqs : 3;
+  g->KP = (g->P + 63) / 64 * 64;
+  g->NT = d->feat == 512 ? 2 : 1;
+  g->H2 = d->feat / 2;
+  g->n_heads = d->n_heads;
+  g->n_pass = (d->n_heads + 1) / 2;
+  int c = 4;
+  g->ch_normal_an = g->ch_normal_lr = -1;
+  if (d->normal_an) { g->ch_normal_an = c; c += 3; }
+  if (d->normal_lr) { g->ch_normal_lr = c; c += 3; }
+  g->head_col[0] = 0;
+  for (int i = 1; i < d->n_heads; ++i) {
+    BN_REQUIRE(d->head_out[i] == 1 || d->head_out[i] == 3, "field: head_out[%d]=%d", i, d->head_out[i]);
+    g->head_col[i] = c;
+    // 1-wide heads are tiled x3 in the output except roughness / Hapke theta (spsbrdfnerf.py:726,731,755)
+    c += (d->head_kind[i] == BN_HEAD_PLAIN || d->head_kind[i] == BN_HEAD_HAPKE_THETA) ? d->head_out[i] : 3;
+  }
+  BN_REQUIRE(d->head_out[0] == 3, "field: head 0 must be rgb (3 outputs)");
+  g->C = c;
+  BN_REQUIRE(d->out_channels == c, "field: out_channels=%d but layout needs %d", d->out_channels, c);
+  for (int p = 0; p < g->n_pass; ++p) {
+    g->pass_heads[p] = (d->n_heads - 2 * p) >= 2 ? 2 : 1;
+    g->pass_N[p] = g->pass_heads[p] * g->H2;
+    g->pass_NTW[p] = g->pass_heads[p] == 2 ? g->NT : (g->NT == 2 ? 1 : 1);
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ packed weights (elements of T)
+// A matrix with R rows and K contraction columns is stored as [R/32][K/16][64 lanes][8]: element j of
+// lane (r = lane&31, h = lane>>5) of block (rt, ks) is M[rt*32 + r][ks*16 + 8h + j]  (one MFMA A operand
+// = one fully coalesced 64-lane x 16 B (bf16) load).
+struct PackedLayout {
+  size_t fwd_trunk[BN_MAX_LAYERS][2];  // [l][0]: PE part (l==0, l==skip) or h part; [l][1]: h part of the skip layer
+  size_t fwd_feats, fwd_head[BN_MAX_PASS];
+  size_t bwd_trunk[BN_MAX_LAYERS];     // W_l^T restricted to the h inputs, l >= 1
+  size_t bwd_feats, bwd_head[BN_MAX_PASS];
+  size_t total;
+};
+
+static inline size_t bn_pad(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static inline void bn_make_packed_layout(const FieldGeom &g, PackedLayout *pl) {
+  size_t off = 0;
+  auto take = [&](size_t rows, size_t k) { size_t o = off; off += bn_pad(rows, 32) * bn_pad(k, 16); return o; };
+  for (int l = 0; l < g.L; ++l) {
+    pl->fwd_trunk[l][0] = pl->fwd_trunk[l][1] = 0;
+    if (l == 0) pl->fwd_trunk[l][0] = take(g.F, g.KP);
+    else if (l == g.skip) { pl->fwd_trunk[l][0] = take(g.F, g.KP); pl->fwd_trunk[l][1] = take(g.F, g.F); }
+    else pl->fwd_trunk[l][0] = take(g.F, g.F);
+  }
+  pl->fwd_feats = take(g.F, g.F);
+  for (int p = 0; p < g.n_pass; ++p) pl->fwd_head[p] = take(g.pass_N[p], g.F);
+  for (int l = 0; l < g.L; ++l) pl->bwd_trunk[l] = l >= 1 ? take(g.F, g.F) : 0;
+  pl->bwd_feats = take(g.F, g.F);
+  for (int p = 0; p < g.n_pass; ++p) pl->bwd_head[p] = take(g.F, g.pass_N[p]);
+  pl->total = off;
+}
+
+// ------------------------------------------------------------------ activation stash (byte offsets)
+// Row-major arrays [Mpad][width] of T feed the weight-gradient GEMMs; "native" arrays hold one
+// accumulator-register image per tile ([tile][wave][nt][mt][g][lane][4]) and are only re-read by
+// the backward chain, which uses the same tiling.
+struct StashLayout {
+  size_t sraw;                    // fp32 [Mpad]  pre-softplus sigma
+  size_t nraw;                    // fp32 [Mpad][4] learned-normal pre-normalisation vector
+  size_t dpre_trunk;              // fp32 [Mpad][4]  (d sigma_raw, d normal_raw xyz)      (bwd-produced)
+  size_t dpre_head;               // fp32 [Mpad][12] (per head, 3 each)                   (bwd-produced)
+  size_t pe;                      // T [Mpad][KP]
+  size_t Y[BN_MAX_LAYERS];        // T [Mpad][F]  output of trunk layer l
+  size_t D[BN_MAX_LAYERS];        // T native     d act / d z of trunk layer l
+  size_t feats;                   // T [Mpad][F]
+  size_t G[BN_MAX_PASS];          // T [Mpad][pass_N]  head hidden activations
+  size_t DG[BN_MAX_PASS];         // T native
+  size_t dZ[BN_MAX_LAYERS];       // T [Mpad][F]                                          (bwd-produced)
+  size_t dfeats;                  // T [Mpad][F]                                          (bwd-produced)
+  size_t dG[BN_MAX_PASS];         // T [Mpad][pass_N]                                     (bwd-produced)
+  size_t total;
+  int64_t Mpad;
+};
+
+static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, int BM, size_t esz, StashLayout *s) {
+  int64_t Mpad = ceil_div64(n_points, BM) * BM;
+  s->Mpad = Mpad;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += bn_pad(bytes, 256); return o; };
+  s->sraw = take((size_t)Mpad * 4);
+  s->nraw = take((size_t)Mpad * 16);
+  s->dpre_trunk = take((size_t)Mpad * 16);
+  s->dpre_head = take((size_t)Mpad * 48);
+  s->pe = take((size_t)Mpad * g.KP * esz);
+  for (int l = 0; l < g.L; ++l) s->Y[l] = take((size_t)Mpad * g.F * esz);
+  for (int l = 0; l < g.L; ++l) s->D[l] = take((size_t)Mpad * g.F * esz);
+  s->feats = take((size_t)Mpad * g.F * esz);
+  for (int p = 0; p < BN_MAX_PASS; ++p) {
+    s->G[p] = s->DG[p] = s->dG[p] = 0;
+    if (p < g.n_pass) {
+      s->G[p] = take((size_t)Mpad * g.pass_N[p] * esz);
+      s->DG[p] = take((size_t)Mpad * g.F * esz);  // native image sized for a full-width phase
+    }
+  }
+  for (int l = 0; l < g.L; ++l) s->dZ[l] = take((size_t)Mpad * g.F * esz);
+  s->dfeats = take((size_t)Mpad * g.F * esz);
+  for (int p = 0; p < g.n_pass; ++p) s->dG[p] = take((size_t)Mpad * g.pass_N[p] * esz);
+  s->total = off;
+}

@@ -1,0 +1,502 @@
+// Fused field-MLP backward for gfx950 (parameter gradients).
+//   1. field_bwd_kernel: the dX chain - one workgroup per tile of BM points walks the network in reverse with
+//      the gradient tile resident in LDS (same tiling as the forward; weights = pre-packed W^T fragments),
+//      writing each layer's pre-activation gradient dZ_l row-major for step 2.
+//   2. wgrad_kernel: dW_l[n][k] += sum_m dZ_l[m][n] X_l[m][k] as MFMA GEMMs over the stashed activations
+//      (bf16: LDS tiles + ds_read_b64_tr_b16 transposing reads; fp32: plain ds_read_b32), split over point
+//      chunks with fp32 atomics; bias gradients as column sums in the same kernel.
+//   3. skinny_wgrad_kernel: the <= 4-row matrices (sigma head, learned normal, second head layers).
+// Autograd counterpart in the reference: loss.backward() through SpSBRDFNeRF.forward (models/spsbrdfnerf.py:662-757).
+#include "field_kernels.h"
+
+struct BwdArgs {
+  FieldGeom g;
+  bn_field_desc d;
+  bn_field_params p;
+  PackedLayout pl;
+  StashLayout sl;
+  const void *packed;
+  int64_t M;
+  const float *out, *d_out;
+  char *stash;
+};
+
+// sigmoid output y and dL/dy of head `hd`, channel c, recovered from the forward's rescaled output.
+__device__ __forceinline__ void head_y_dy(int kind, int nout, const float *o, const float *dgo, int c, float &y, float &dy) {
+  if (kind == BN_HEAD_PLAIN) { y = o[c]; dy = dgo[c]; }
+  else if (kind == BN_HEAD_HAPKE_THETA) { y = o[0] * (1.f / 0.52359877559829887f); dy = dgo[0] * 0.52359877559829887f; }
+  else {
+    const float ov = nout == 1 ? o[0] : o[c];
+    const float dv = nout == 1 ? dgo[0] + dgo[1] + dgo[2] : dgo[c];
+    if (kind == BN_HEAD_RPV_K) { y = (ov - 1.f) * 0.5f + 0.5f; dy = 2.f * dv; }
+    else if (kind == BN_HEAD_RPV_THETA) { y = ov * 0.5f + 0.5f; dy = 2.f * dv; }
+    else { y = ov; dy = dv; }
+  }
+}
+
+template <typename T, int MT, int NTW>
+__device__ __forceinline__ void bwd_head_dG(const BwdArgs &A, int p, T *ACT, const float *DPH, int64_t m0, int64_t tile) {
+  typedef typename Elem<T>::vec4 vec4;
+  constexpr int BM = MT * 32;
+  const FieldGeom &g = A.g;
+  const int F = g.F, LDA = F + Elem<T>::kPad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int N = g.pass_N[p];
+  const int pc0 = wave * 32 * NTW;
+  if (pc0 >= N) return;
+  const int hl = pc0 / g.H2, hd = 2 * p + hl;
+  const int nout = A.d.head_out[hd];
+  const float *w2 = A.p.head_w2[hd];
+  const T *DGs = (const T *)(A.stash + A.sl.DG[p]) + (size_t)tile * BM * F;
+  T *dGs = (T *)(A.stash + A.sl.dG[p]) + (size_t)m0 * N;
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int n = pc0 + nt * 32 + 8 * gq + 4 * h;
+      const int nl = n - hl * g.H2;
+      f32x4 w2v[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) w2v[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl) : f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 32 + r;
+        const float d0 = DPH[m * 12 + hd * 3 + 0], d1 = DPH[m * 12 + hd * 3 + 1], d2 = DPH[m * 12 + hd * 3 + 2];
+        const vec4 dg = *(const vec4 *)(DGs + native_off<MT, NTW>(wave, nt, mt, gq, lane));
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (d0 * w2v[0][e] + d1 * w2v[1][e] + d2 * w2v[2][e]) * (float)dg[e];
+        const vec4 o = to_vec4(T(), v[0], v[1], v[2], v[3]);
+        *(vec4 *)(ACT + (size_t)m * LDA + n) = o;
+        *(vec4 *)(dGs + (size_t)m * N + n) = o;
+      }
+    }
+}
+
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(BN_THREADS, 2) void field_bwd_kernel(const BwdArgs A) {
+  typedef typename Elem<T>::vec4 vec4;
+  constexpr int BM = MT * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const FieldGeom &g = A.g;
+  const int F = g.F, LDA = F + Elem<T>::kPad, KSF = F / 16;
+  T *ACT = (T *)smem;
+  float *DPH = (float *)(ACT + (size_t)BM * LDA);  // [BM][12] head pre-sigmoid gradients
+  float *DPT = DPH + BM * 12;                        // [BM][4]  (d sigma_raw, d normal_raw)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.M;
+  const T *packed = (const T *)A.packed;
+
+  // ---------------------------------------------------------------- pre-activation gradients of the small outputs
+  if (tid < BM) {
+    const int m = tid;
+    const int64_t gm = m0 + m;
+    float dph[12], dpt[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dph[i] = 0.f;
+    if (gm < M) {
+      const float *o = A.out + gm * g.C, *dgo = A.d_out + gm * g.C;
+      for (int hd = 0; hd < g.n_heads; ++hd) {
+        const int nout = A.d.head_out[hd], kind = A.d.head_kind[hd];
+        for (int c = 0; c < nout; ++c) {
+          float y, dy;
+          head_y_dy(kind, nout, o + g.head_col[hd], dgo + g.head_col[hd], c, y, dy);
+          dph[hd * 3 + c] = dy * y * (1.f - y);
+        }
+      }
+      const float sraw = ((const float *)(A.stash + A.sl.sraw))[gm];
+      dpt[0] = dgo[3] * sigmoid_f(sraw);
+      if (g.ch_normal_lr >= 0) {
+        const float *v = (const float *)(A.stash + A.sl.nraw) + gm * 4;
+        const float *dn = dgo + g.ch_normal_lr;
+        const float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        const float eps = 1.1920928955078125e-07f;
+        const float inv = 1.f / sqrtf(fmaxf(n2, eps));
+        // out = -v * inv ; inv depends on v only when n2 > eps (torch.maximum passes the gradient to the larger)
+        const float vd = v[0] * dn[0] + v[1] * dn[1] + v[2] * dn[2];
+        const float k = n2 > eps ? vd * inv * inv * inv : 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dpt[1 + i] = -(dn[i] * inv - v[i] * k);
+      }
+    }
+    float *sh = (float *)(A.stash + A.sl.dpre_head) + gm * 12;
+    float *st = (float *)(A.stash + A.sl.dpre_trunk) + gm * 4;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { DPH[m * 12 + i] = dph[i]; sh[i] = dph[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { DPT[m * 4 + i] = dpt[i]; st[i] = dpt[i]; }
+  }
+  __syncthreads();
+
+  const int ncol0 = wave * 32 * NT;
+  const bool wave_on = ncol0 < F;
+  f32x16 acc[NT][MT];
+  zero_acc<MT, NT>(acc);
+
+  // ---------------------------------------------------------------- heads: dG -> LDS, dFeats += W1^T dG
+  for (int p = 0; p < g.n_pass; ++p) {
+    if (g.pass_heads[p] == 2) bwd_head_dG<T, MT, NT>(A, p, ACT, DPH, m0, tile);
+    else bwd_head_dG<T, MT, 1>(A, p, ACT, DPH, m0, tile);
+    __syncthreads();
+    const int KSp = g.pass_N[p] / 16;
+    if (wave_on) gemm_seg<T, MT, NT>(acc, packed + A.pl.bwd_head[p] + (size_t)(ncol0 / 32) * KSp * 512, KSp, ACT, LDA, lane);
+    __syncthreads();
+  }
+  // dFeats -> LDS + stash
+  if (wave_on) {
+    T *dFs = (T *)(A.stash + A.sl.dfeats) + (size_t)m0 * F;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = ncol0 + nt * 32 + 8 * gq + 4 * h;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int m = mt * 32 + r;
+          const vec4 o = to_vec4(T(), acc[nt][mt][4 * gq], acc[nt][mt][4 * gq + 1], acc[nt][mt][4 * gq + 2], acc[nt][mt][4 * gq + 3]);
+          *(vec4 *)(ACT + (size_t)m * LDA + n) = o;
+          *(vec4 *)(dFs + (size_t)m * F + n) = o;
+        }
+      }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- trunk, top layer first
+  for (int l = g.L; l >= 1; --l) {
+    // l == L: dY_{L-1} = Wf^T dFeats + sigma/normal rank-1 terms; else dY_{l-1} = W_l^T dZ_l
+    zero_acc<MT, NT>(acc);
+    if (wave_on) {
+      const size_t off = (l == g.L ? A.pl.bwd_feats : A.pl.bwd_trunk[l]) + (size_t)(ncol0 / 32) * KSF * 512;
+      gemm_seg<T, MT, NT>(acc, packed + off, KSF, ACT, LDA, lane);
+    }
+    __syncthreads();
+    if (wave_on) {
+      const int lo = l - 1;  // layer whose pre-activation gradient is produced
+      const T *Ds = (const T *)(A.stash + A.sl.D[lo]) + (size_t)tile * BM * F;
+      T *dZs = (T *)(A.stash + A.sl.dZ[lo]) + (size_t)m0 * F;
+      const bool top = l == g.L, nlr = g.ch_normal_lr >= 0;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int n = ncol0 + nt * 32 + 8 * gq + 4 * h;
+          f32x4 ws = {0, 0, 0, 0}, wn0 = ws, wn1 = ws, wn2 = ws;
+          if (top) {
+            ws = *(const f32x4 *)(A.p.sigma_w + n);
+            if (nlr) { wn0 = *(const f32x4 *)(A.p.normal_w + n); wn1 = *(const f32x4 *)(A.p.normal_w + F + n); wn2 = *(const f32x4 *)(A.p.normal_w + 2 * F + n); }
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const int m = mt * 32 + r;
+            const vec4 dv = *(const vec4 *)(Ds + native_off<MT, NT>(wave, nt, mt, gq, lane));
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * gq + e];
+            if (top) {
+              const float ds = DPT[m * 4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += ws[e] * ds;
+              if (nlr) {
+                const float a0 = DPT[m * 4 + 1], a1 = DPT[m * 4 + 2], a2 = DPT[m * 4 + 3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += wn0[e] * a0 + wn1[e] * a1 + wn2[e] * a2;
+              }
+            }
+            const vec4 o = to_vec4(T(), v[0] * (float)dv[0], v[1] * (float)dv[1], v[2] * (float)dv[2], v[3] * (float)dv[3]);
+            *(vec4 *)(ACT + (size_t)m * LDA + n) = o;
+            *(vec4 *)(dZs + (size_t)m * F + n) = o;
+          }
+        }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------ weight gradients
+struct WgradJob {
+  const void *A;   // [Mpad][lda] T : gradient rows (dZ / dFeats / dG)
+  const void *B;   // [Mpad][ldb] T : layer input rows (PE / Y / feats)
+  float *C;        // [N][ldc] fp32, +=
+  float *bias;     // [N] fp32, += column sums of A (nullable)
+  int lda, ldb, ldc;
+  int a_col0, b_col0;  // first column used in A / B
+  int N, K;            // valid output extents (rows of C, cols of C)
+};
+#define BN_MAX_WGRAD_JOBS 40
+struct WgradArgs {
+  WgradJob job[BN_MAX_WGRAD_JOBS];
+  int tile0[BN_MAX_WGRAD_JOBS + 1];  // prefix sum of 128x128 output tiles per job
+  int n_jobs;
+  int64_t Mpad;
+  int m_per_block;                   // points per split (multiple of 32)
+};
+
+#define WG_BK 32
+template <typename T> struct WgTile;
+template <> struct WgTile<bf16> { static constexpr int LD = 128 + 32; };   // 320 B rows: the 4 rows of a tr-read block hit disjoint banks
+template <> struct WgTile<float> { static constexpr int LD = 128 + 4; };
+
+// 8-element MFMA fragment of the TRANSPOSED tile: element j <-> contraction index (point) m, fixed column `col`.
+template <typename T> __device__ __forceinline__ typename Elem<T>::frag wg_frag(const T *tile, int mm, int col0, int lane);
+template <> __device__ __forceinline__ bf16x8 wg_frag<bf16>(const bf16 *tile, int mm, int col0, int lane) {
+  // two ds_read_b64_tr_b16: each 16-lane group reads a 4(m) x 16(col) block and gets it column-major:
+  // lane i of the group receives column i, rows 0..3.  Lane 4q+p supplies the address of row q, columns 4p..4p+3.
+  constexpr int LD = WgTile<bf16>::LD;
+  const int h = lane >> 5, grp = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
+  const bf16 *a = tile + (size_t)(mm + 8 * h + q) * LD + col0 + 16 * grp + 4 * p;
+  typedef __attribute__((address_space(3))) s16x4 lds_v4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)a);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a + 4 * LD));
+  union { s16x4 s[2]; bf16x8 b; } u;
+  u.s[0] = lo; u.s[1] = hi;
+  return u.b;
+}
+template <> __device__ __forceinline__ f32x8 wg_frag<float>(const float *tile, int mm, int col0, int lane) {
+  // fp32 MFMA j consumes element j of both operands with lane-half h as its k index: m = mm + 2j + h.
+  constexpr int LD = WgTile<float>::LD;
+  const int h = lane >> 5, r = lane & 31;
+  f32x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = tile[(size_t)(mm + 2 * j + h) * LD + col0 + r];
+  return f;
+}
+
+template <typename T> __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
+  constexpr int LD = WgTile<T>::LD;
+  constexpr int EPC = 16 / sizeof(T);          // elements per 16-byte chunk
+  constexpr int CPR = 128 / EPC;               // chunks per tile row
+  constexpr int NCH = WG_BK * CPR / 256;       // chunks per thread per operand
+  __shared__ __attribute__((aligned(16))) T sA[WG_BK * LD];
+  __shared__ __attribute__((aligned(16))) T sB[WG_BK * LD];
+  // which job / output tile
+  int jb = 0;
+  while (jb + 1 < A.n_jobs && (int)blockIdx.x >= A.tile0[jb + 1]) ++jb;
+  const WgradJob &J = A.job[jb];
+  const int t = blockIdx.x - A.tile0[jb];
+  const int tiles_k = (J.K + 127) / 128;
+  const int n0 = (t / tiles_k) * 128, k0 = (t % tiles_k) * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int64_t mb = (int64_t)blockIdx.y * A.m_per_block;
+  const int64_t me = mb + A.m_per_block < A.Mpad ? mb + A.m_per_block : A.Mpad;
+  const T *gA = (const T *)J.A + J.a_col0 + n0;
+  const T *gB = (const T *)J.B + J.b_col0 + k0;
+  // columns beyond the valid extent are zero-filled (they lie inside the row for n, may not for k: PE has K=60<64)
+  uint4 ra[NCH], rb[NCH];
+  auto gload = [&](int64_t m) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = tid + c * 256, row = ch / CPR, cc = (ch % CPR) * EPC;
+      ra[c] = (n0 + cc < J.N) ? *(const uint4 *)(gA + (m + row) * J.lda + cc) : uint4{0, 0, 0, 0};
+      rb[c] = (k0 + cc < J.K) ? *(const uint4 *)(gB + (m + row) * J.ldb + cc) : uint4{0, 0, 0, 0};
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = tid + c * 256, row = ch / CPR, cc = (ch % CPR) * EPC;
+      *(uint4 *)(sA + row * LD + cc) = ra[c];
+      *(uint4 *)(sB + row * LD + cc) = rb[c];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = J.bias != nullptr && k0 == 0 && tid < 128;
+  gload(mb);
+  for (int64_t m = mb; m < me; m += WG_BK) {
+    __syncthreads();
+    sstore();
+    __syncthreads();
+    if (m + WG_BK < me) gload(m + WG_BK);
+#pragma unroll
+    for (int mm = 0; mm < WG_BK; mm += 16) {
+      typename Elem<T>::frag fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = wg_frag<T>(sA, mm, wr * 64 + a * 32, lane);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[b] = wg_frag<T>(sB, mm, wc * 64 + b * 32, lane);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) mma32(acc[a][b], fa[a], fb[b]);
+    }
+    if (do_bias) {
+#pragma unroll 8
+      for (int row = 0; row < WG_BK; ++row) bsum += (float)sA[row * LD + tid];
+    }
+  }
+  // C[n][k]: accumulator row index = n (A operand rows), column (lane&31) = k
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int k = k0 + wc * 64 + b * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = n0 + wr * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (n < J.N && k < J.K) atomicAdd(J.C + (size_t)n * J.ldc + k, acc[a][b][i]);
+      }
+    }
+  if (do_bias && n0 + tid < J.N) atomicAdd(J.bias + n0 + tid, bsum);
+}
+
+struct SkinnyJob {
+  const void *X;       // [Mpad][ldx] T
+  const float *dpre;   // [Mpad][ldp] fp32
+  int ldx, x_col0, K, ldp, p_col0, nc;
+  float *out[4];       // row c of the gradient: out[c][k], k < K
+  float *bias[4];      // scalar bias gradient of row c (nullable)
+};
+#define BN_MAX_SKINNY_JOBS 8
+struct SkinnyArgs {
+  SkinnyJob job[BN_MAX_SKINNY_JOBS];
+  int n_jobs;
+  int64_t Mpad;
+  int m_per_block;
+};
+
+template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const SkinnyArgs A) {
+  const SkinnyJob &J = A.job[blockIdx.y];
+  const int64_t mb = (int64_t)blockIdx.x * A.m_per_block;
+  const int64_t me = mb + A.m_per_block < A.Mpad ? mb + A.m_per_block : A.Mpad;
+  const T *X = (const T *)J.X + J.x_col0;
+  const int tid = threadIdx.x;
+  for (int kb = 0; kb < J.K; kb += 512) {
+    const int k = kb + 2 * tid;
+    float s[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    float bs[4] = {0, 0, 0, 0};
+    if (k < J.K) {
+      for (int64_t m = mb; m < me; ++m) {
+        const float x0 = (float)X[m * J.ldx + k], x1 = (float)X[m * J.ldx + k + 1];
+        const float *dp = J.dpre + m * J.ldp + J.p_col0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < J.nc) { const float d = dp[c]; s[c][0] += d * x0; s[c][1] += d * x1; if (kb == 0 && tid == 0) bs[c] += d; }
+      }
+      for (int c = 0; c < J.nc; ++c) {
+        atomicAdd(J.out[c] + k, s[c][0]);
+        atomicAdd(J.out[c] + k + 1, s[c][1]);
+        if (kb == 0 && tid == 0 && J.bias[c]) atomicAdd(J.bias[c], bs[c]);
+      }
+    }
+  }
+}
+
+template <typename T, int MT, int NT> static int launch_bwd(const BwdArgs &a, int64_t tiles, hipStream_t st) {
+  constexpr int BM = MT * 32;
+  const size_t lds = (size_t)BM * (a.g.F + Elem<T>::kPad) * sizeof(T) + (size_t)BM * 16 * sizeof(float);
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute((const void *)field_bwd_kernel<T, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      bn_set_error("field_bwd: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
+      return BN_ELAUNCH;
+    }
+    configured = lds;
+  }
+  field_bwd_kernel<T, MT, NT><<<dim3((unsigned)tiles), BN_THREADS, lds, st>>>(a);
+  BN_LAUNCH_CHECK("field_bwd");
+  return 0;
+}
+
+extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
+                                 const bn_points *pts, const float *out, const float *d_out, void *stash,
+                                 const bn_field_grads *G, void *stream) {
+  BwdArgs a;
+  if (int e = bn_make_geom(desc, &a.g)) return e;
+  BN_REQUIRE(!desc->normal_an, "field_backward: analytic normals not supported by this entry point");
+  BN_REQUIRE(pts && pts->n_points > 0 && packed && out && d_out && stash && G, "field_backward: null argument");
+  const FieldGeom &g = a.g;
+  a.d = *desc; a.p = *params; a.packed = packed; a.M = pts->n_points; a.out = out; a.d_out = d_out; a.stash = (char *)stash;
+  bn_make_packed_layout(g, &a.pl);
+  const bool bf = desc->dtype == BN_BF16;
+  const int BM = bf ? 128 : 64;
+  const size_t esz = bf ? 2 : 4;
+  bn_make_stash_layout(g, pts->n_points, BM, esz, &a.sl);
+  const int64_t tiles = ceil_div64(pts->n_points, BM);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (bf) rc = g.NT == 2 ? launch_bwd<bf16, 4, 2>(a, tiles, st) : launch_bwd<bf16, 4, 1>(a, tiles, st);
+  else rc = g.NT == 2 ? launch_bwd<float, 2, 2>(a, tiles, st) : launch_bwd<float, 2, 1>(a, tiles, st);
+  if (rc) return rc;
+
+  // ---- weight gradients
+  const StashLayout &sl = a.sl;
+  char *S = (char *)stash;
+  const int F = g.F, P0 = g.P;
+  WgradArgs w;
+  w.n_jobs = 0; w.Mpad = sl.Mpad; w.tile0[0] = 0;
+  auto add = [&](const void *A_, int lda, int a0, const void *B_, int ldb, int b0, float *C, int ldc, float *bias, int N, int K) {
+    if (!C) return;
+    WgradJob &j = w.job[w.n_jobs];
+    j.A = A_; j.B = B_; j.C = C; j.bias = bias; j.lda = lda; j.ldb = ldb; j.ldc = ldc; j.a_col0 = a0; j.b_col0 = b0; j.N = N; j.K = K;
+    w.tile0[w.n_jobs + 1] = w.tile0[w.n_jobs] + ((N + 127) / 128) * ((K + 127) / 128);
+    ++w.n_jobs;
+  };
+  for (int l = 0; l < g.L; ++l) {
+    const void *dZ = S + sl.dZ[l];
+    if (l == 0) add(dZ, F, 0, S + sl.pe, g.KP, 0, G->trunk_w[l], P0, G->trunk_b[l], F, P0);
+    else if (l == g.skip) {
+      add(dZ, F, 0, S + sl.pe, g.KP, 0, G->trunk_w[l], F + P0, G->trunk_b[l], F, P0);
+      add(dZ, F, 0, S + sl.Y[l - 1], F, 0, G->trunk_w[l] ? G->trunk_w[l] + P0 : nullptr, F + P0, nullptr, F, F);
+    } else add(dZ, F, 0, S + sl.Y[l - 1], F, 0, G->trunk_w[l], F, G->trunk_b[l], F, F);
+  }
+  add(S + sl.dfeats, F, 0, S + sl.Y[g.L - 1], F, 0, G->feats_w, F, G->feats_b, F, F);
+  for (int hd = 0; hd < g.n_heads; ++hd) {
+    const int p = hd / 2, hl = hd % 2;
+    add(S + sl.dG[p], g.pass_N[p], hl * g.H2, S + sl.feats, F, 0, G->head_w1[hd], F, G->head_b1[hd], g.H2, F);
+  }
+  BN_REQUIRE(w.n_jobs <= BN_MAX_WGRAD_JOBS, "field_backward: too many wgrad jobs");
+  // split the points so that the grid has a few thousand workgroups
+  int64_t splits = 2048 / (w.tile0[w.n_jobs] > 0 ? w.tile0[w.n_jobs] : 1);
+  if (splits < 1) splits = 1;
+  int64_t mpb = ceil_div64(ceil_div64(sl.Mpad, splits), WG_BK) * WG_BK;
+  if (mpb < 256) mpb = 256;
+  w.m_per_block = (int)mpb;
+  if (w.n_jobs > 0) {
+    dim3 grid((unsigned)w.tile0[w.n_jobs], (unsigned)ceil_div64(sl.Mpad, mpb));
+    if (bf) wgrad_kernel<bf16><<<grid, 256, 0, st>>>(w);
+    else wgrad_kernel<float><<<grid, 256, 0, st>>>(w);
+    BN_LAUNCH_CHECK("wgrad");
+  }
+  SkinnyArgs s;
+  s.n_jobs = 0; s.Mpad = sl.Mpad;
+  {
+    SkinnyJob &j = s.job[s.n_jobs];
+    j.X = S + sl.Y[g.L - 1]; j.ldx = F; j.x_col0 = 0; j.K = F; j.dpre = (const float *)(S + sl.dpre_trunk); j.ldp = 4; j.p_col0 = 0;
+    j.nc = g.ch_normal_lr >= 0 ? 4 : 1;
+    for (int c = 0; c < 4; ++c) { j.out[c] = nullptr; j.bias[c] = nullptr; }
+    j.out[0] = G->sigma_w; j.bias[0] = G->sigma_b;
+    if (g.ch_normal_lr >= 0) {
+      BN_REQUIRE(G->normal_w && G->normal_b, "field_backward: normal grads missing");
+      for (int c = 0; c < 3; ++c) { j.out[1 + c] = G->normal_w + (size_t)c * F; j.bias[1 + c] = G->normal_b + c; }
+    }
+    if (j.out[0]) ++s.n_jobs;
+  }
+  for (int hd = 0; hd < g.n_heads; ++hd) {
+    if (!G->head_w2[hd]) continue;
+    const int p = hd / 2, hl = hd % 2;
+    SkinnyJob &j = s.job[s.n_jobs++];
+    j.X = S + sl.G[p]; j.ldx = g.pass_N[p]; j.x_col0 = hl * g.H2; j.K = g.H2;
+    j.dpre = (const float *)(S + sl.dpre_head); j.ldp = 12; j.p_col0 = hd * 3; j.nc = desc->head_out[hd];
+    for (int c = 0; c < 4; ++c) { j.out[c] = nullptr; j.bias[c] = nullptr; }
+    for (int c = 0; c < j.nc; ++c) { j.out[c] = G->head_w2[hd] + (size_t)c * g.H2; j.bias[c] = G->head_b2[hd] ? G->head_b2[hd] + c : nullptr; }
+  }
+  if (s.n_jobs > 0) {
+    int64_t smpb = ceil_div64(sl.Mpad, 1024);
+    if (smpb < 64) smpb = 64;
+    s.m_per_block = (int)smpb;
+    dim3 grid((unsigned)ceil_div64(sl.Mpad, smpb), (unsigned)s.n_jobs);
+    if (bf) skinny_wgrad_kernel<bf16><<<grid, 256, 0, st>>>(s);
+    else skinny_wgrad_kernel<float><<<grid, 256, 0, st>>>(s);
+    BN_LAUNCH_CHECK("skinny_wgrad");
+  }
+  return 0;
+}

@@ -1,0 +1,484 @@
+// Fused field-MLP forward for gfx950: positional encoding -> trunk (Siren/ReLU, skip concat) -> sigma /
+// learned-normal heads -> feats -> two-layer sigmoid heads, one workgroup per tile of BM points, all
+// activations resident in LDS.  Replaces Mapping.forward (models/nerf.py:53-70), calc_features
+// (models/spsbrdfnerf.py:636-646) and SpSBRDFNeRF.forward (:662-757) of the reference.
+#include "field_kernels.h"
+
+struct FwdArgs {
+  FieldGeom g;
+  bn_field_desc d;
+  bn_field_params p;
+  PackedLayout pl;
+  StashLayout sl;
+  const void *packed;
+  bn_points pts;
+  float *out;     // [M][C], or sigma [M] when sigma_only
+  char *stash;    // nullptr: inference, nothing kept
+  int sigma_only;
+};
+
+// One pass over up to two heads: hidden = act(W1 feats + b1) kept in registers, second layer (<= 3 outputs)
+// as per-lane partial dots reduced through LDS.  NTW = 32-column tiles per wave in this pass.
+template <typename T, int MT, int NTW>
+__device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT, float *RED, int64_t m0, int64_t tile) {
+  typedef typename Elem<T>::vec4 vec4;
+  constexpr int BM = MT * 32;
+  constexpr bool FAST = Elem<T>::kFastMath;
+  const FieldGeom &g = A.g;
+  const int F = g.F, LDA = F + Elem<T>::kPad, KSF = F / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t M = A.pts.n_points;
+  const bool keep = A.stash != nullptr;
+  const int N = g.pass_N[p];
+  const int pc0 = wave * 32 * NTW;                // first column of this wave in the pass
+  const bool on = pc0 < N;
+  const int hl = pc0 / g.H2;                      // head inside the pass (0/1)
+  const int hd = 2 * p + hl;
+  f32x16 acc[NTW][MT];
+  zero_acc<MT, NTW>(acc);
+  if (on) {
+    gemm_seg<T, MT, NTW>(acc, (const T *)A.packed + A.pl.fwd_head[p] + (size_t)(pc0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
+    const int nout = A.d.head_out[hd];
+    const float *b1 = A.p.head_b1[hd];
+    const float *w2 = A.p.head_w2[hd];
+    T *Gs = keep ? (T *)(A.stash + A.sl.G[p]) + (size_t)m0 * N : nullptr;
+    T *DGs = keep ? (T *)(A.stash + A.sl.DG[p]) + (size_t)tile * BM * F : nullptr;
+    float part[MT][3];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) part[mt][0] = part[mt][1] = part[mt][2] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = pc0 + nt * 32 + 8 * gq + 4 * h;   // column in the pass
+        const int nl = n - hl * g.H2;                   // column inside the head
+        const f32x4 b4 = *(const f32x4 *)(b1 + nl);
+        f32x4 w2v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w2v[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float y[4], dd[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float zz = acc[nt][mt][4 * gq + e] + b4[e];
+            if (g.act == BN_ACT_SIN) {
+              float s, c;
+              sincos_t<FAST>(zz, s, c);
+              y[e] = s; dd[e] = c;
+            } else {
+              y[e] = zz > 0.f ? zz : 0.f; dd[e] = zz > 0.f ? 1.f : 0.f;
+            }
+          }
+          const vec4 yv = to_vec4(T(), y[0], y[1], y[2], y[3]);
+          if (keep) {
+            const int m = mt * 32 + r;
+            *(vec4 *)(Gs + (size_t)m * N + n) = yv;
+            *(vec4 *)(DGs + native_off<MT, NTW>(wave, nt, mt, gq, lane)) = to_vec4(T(), dd[0], dd[1], dd[2], dd[3]);
+          }
+          // the second layer sees the stored (rounded) hidden value: fwd and bwd stay consistent
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[mt][c] += (float)yv[e] * w2v[c][e];
+        }
+      }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v = part[mt][c];
+        v += __shfl_xor(v, 32);
+        if (h == 0) RED[(wave * 3 + c) * BM + mt * 32 + r] = v;
+      }
+  }
+  __syncthreads();
+  if (tid < BM * g.pass_heads[p]) {
+    const int m = tid % BM, hl2 = tid / BM, hd2 = 2 * p + hl2;
+    const int64_t gm = m0 + m;
+    const int wph = g.H2 / (32 * NTW);  // waves per head
+    const int nout = A.d.head_out[hd2], kind = A.d.head_kind[hd2];
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float s = 0.f;
+      for (int w = hl2 * wph; w < (hl2 + 1) * wph; ++w) s += RED[(w * 3 + c) * BM + m];
+      v[c] = c < nout ? sigmoid_f(s + A.p.head_b2[hd2][c]) : 0.f;
+    }
+    if (gm < M) {
+      float *o = A.out + gm * g.C + g.head_col[hd2];
+      if (kind == BN_HEAD_PLAIN) {
+        for (int c = 0; c < nout; ++c) o[c] = v[c];
+      } else if (kind == BN_HEAD_HAPKE_THETA) {
+        o[0] = v[0] * 0.52359877559829887f;  // pi*30/180
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float y = nout == 1 ? v[0] : v[c];
+          if (kind == BN_HEAD_RPV_K) y = (y - 0.5f) * 2.f + 1.f;
+          else if (kind == BN_HEAD_RPV_THETA) y = (y - 0.5f) * 2.f;
+          o[c] = y;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs A) {
+  typedef typename Elem<T>::vec4 vec4;
+  constexpr int BM = MT * 32;
+  constexpr int PADE = Elem<T>::kPad;
+  constexpr bool FAST = Elem<T>::kFastMath;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const FieldGeom &g = A.g;
+  const int F = g.F, LDA = F + PADE, KP = g.KP, LDP = KP + PADE;
+  T *ACT = (T *)smem;
+  T *PE = ACT + (size_t)BM * LDA;
+  float *RED = (float *)(PE + (size_t)BM * LDP);  // [8 waves][3][BM]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.pts.n_points;
+  const T *packed = (const T *)A.packed;
+  const bool keep = A.stash != nullptr;
+
+  // ---------------------------------------------------------------- points + positional encoding
+  {
+    constexpr int NP = BN_THREADS / BM;
+    const int m = tid % BM, part = tid / BM;
+    const int64_t gm = m0 + m;
+    float x[3] = {0.f, 0.f, 0.f};
+    if (gm < M) {
+      if (A.pts.xyz) {
+        x[0] = A.pts.xyz[gm * 3 + 0]; x[1] = A.pts.xyz[gm * 3 + 1]; x[2] = A.pts.xyz[gm * 3 + 2];
+      } else {
+        const int64_t ray = gm / A.pts.n_samples;
+        const float *rr = A.pts.rays + ray * A.pts.ray_stride;
+        const float zz = A.pts.z[gm];
+        x[0] = rr[0] + rr[3] * zz; x[1] = rr[1] + rr[4] * zz; x[2] = rr[2] + rr[5] * zz;
+      }
+    }
+    T *row = PE + (size_t)m * LDP;
+    if (g.pe_freqs > 0) {
+      for (int k = part; k < g.pe_freqs; k += NP) {
+        const float f = (float)(1 << k);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float s, co;
+          sincos_t<FAST>(f * x[c], s, co);
+          row[6 * k + c] = (T)s;
+          row[6 * k + 3 + c] = (T)co;
+        }
+      }
+      if (part == 0)
+        for (int k = g.P; k < KP; ++k) row[k] = (T)0.f;
+    } else if (part == 0) {
+      for (int k = 0; k < KP; ++k) row[k] = (T)(k < 3 ? x[k] : 0.f);
+    }
+  }
+  __syncthreads();
+  if (keep) {  // PE rows -> stash (row-major [Mpad][KP]), 16-byte chunks
+    T *dst = (T *)(A.stash + A.sl.pe) + (size_t)m0 * KP;
+    constexpr int EPC = 16 / sizeof(T);
+    const int cpr = KP / EPC;
+    for (int c = tid; c < BM * cpr; c += BN_THREADS) {
+      const int m = c / cpr, cc = c % cpr;
+      *(uint4 *)(dst + (size_t)m * KP + cc * EPC) = *(const uint4 *)(PE + (size_t)m * LDP + cc * EPC);
+    }
+  }
+
+  const int ncol0 = wave * 32 * NT;        // first feature of this wave in F-wide phases
+  const bool wave_on = ncol0 < F;
+  const int KSP = KP / 16, KSF = F / 16;
+  f32x16 acc[NT][MT];
+
+  // ---------------------------------------------------------------- trunk
+  for (int l = 0; l < g.L; ++l) {
+    zero_acc<MT, NT>(acc);
+    if (wave_on) {
+      const size_t t0 = (size_t)(ncol0 / 32);
+      if (l == 0) {
+        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512, KSP, PE, LDP, lane);
+      } else if (l == g.skip) {
+        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512, KSP, PE, LDP, lane);
+        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][1] + t0 * KSF * 512, KSF, ACT, LDA, lane);
+      } else {
+        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][0] + t0 * KSF * 512, KSF, ACT, LDA, lane);
+      }
+    }
+    __syncthreads();  // every wave has finished reading ACT (in-place update below)
+    if (wave_on) {
+      const float w0 = (l == 0) ? 30.f : 1.f;
+      const float *bias = A.p.trunk_b[l];
+      T *Ys = keep ? (T *)(A.stash + A.sl.Y[l]) + (size_t)m0 * F : nullptr;
+      T *Ds = keep ? (T *)(A.stash + A.sl.D[l]) + (size_t)tile * BM * F : nullptr;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int n = ncol0 + nt * 32 + 8 * gq + 4 * h;
+          const f32x4 b4 = *(const f32x4 *)(bias + n);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            float y[4], dd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float zz = acc[nt][mt][4 * gq + e] + b4[e];
+              if (g.act == BN_ACT_SIN) {
+                float s, c;
+                sincos_t<FAST>(w0 * zz, s, c);
+                y[e] = s; dd[e] = w0 * c;
+              } else {
+                y[e] = zz > 0.f ? zz : 0.f; dd[e] = zz > 0.f ? 1.f : 0.f;
+              }
+            }
+            const int m = mt * 32 + r;
+            const vec4 yv = to_vec4(T(), y[0], y[1], y[2], y[3]);
+            *(vec4 *)(ACT + (size_t)m * LDA + n) = yv;
+            if (keep) {
+              *(vec4 *)(Ys + (size_t)m * F + n) = yv;
+              *(vec4 *)(Ds + native_off<MT, NT>(wave, nt, mt, gq, lane)) = to_vec4(T(), dd[0], dd[1], dd[2], dd[3]);
+            }
+          }
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- sigma (+ learned normal): VALU dots over h8
+  {
+    constexpr int TPR = BN_THREADS / BM;  // threads per point
+    const int m = tid / TPR, q = tid % TPR;
+    const bool nlr = g.ch_normal_lr >= 0;
+    float ds = 0.f, dn0 = 0.f, dn1 = 0.f, dn2 = 0.f;
+    const T *row = ACT + (size_t)m * LDA;
+    for (int c8 = q; c8 < F / 8; c8 += TPR) {
+      const typename Elem<T>::frag v = lds_frag<T>(row + c8 * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = (float)v[j];
+        const int k = c8 * 8 + j;
+        ds += a * A.p.sigma_w[k];
+        if (nlr) {
+          dn0 += a * A.p.normal_w[k]; dn1 += a * A.p.normal_w[F + k]; dn2 += a * A.p.normal_w[2 * F + k];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) {
+      ds += __shfl_xor(ds, o);
+      if (nlr) { dn0 += __shfl_xor(dn0, o); dn1 += __shfl_xor(dn1, o); dn2 += __shfl_xor(dn2, o); }
+    }
+    const int64_t gm = m0 + m;
+    if (q == 0) {
+      const float sraw = ds + A.p.sigma_b[0];
+      const float sig = softplus_f(sraw);
+      if (keep) ((float *)(A.stash + A.sl.sraw))[gm] = sraw;
+      if (gm < M) {
+        if (A.sigma_only) A.out[gm] = sig;
+        else A.out[gm * g.C + 3] = sig;
+      }
+      if (nlr && !A.sigma_only) {
+        const float v0 = dn0 + A.p.normal_b[0], v1 = dn1 + A.p.normal_b[1], v2 = dn2 + A.p.normal_b[2];
+        if (keep) {
+          float *nr = (float *)(A.stash + A.sl.nraw) + gm * 4;
+          nr[0] = v0; nr[1] = v1; nr[2] = v2; nr[3] = 0.f;
+        }
+        if (gm < M) {
+          const float inv = -1.f / sqrtf(fmaxf(v0 * v0 + v1 * v1 + v2 * v2, 1.1920928955078125e-07f));
+          float *o = A.out + gm * g.C + g.ch_normal_lr;
+          o[0] = v0 * inv; o[1] = v1 * inv; o[2] = v2 * inv;
+        }
+      }
+    }
+  }
+  if (A.sigma_only) return;
+
+  // ---------------------------------------------------------------- feats = Wf h8 + bf (linear)
+  zero_acc<MT, NT>(acc);
+  if (wave_on) gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_feats + (size_t)(ncol0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
+  __syncthreads();
+  if (wave_on) {
+    T *Fs = keep ? (T *)(A.stash + A.sl.feats) + (size_t)m0 * F : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = ncol0 + nt * 32 + 8 * gq + 4 * h;
+        const f32x4 b4 = *(const f32x4 *)(A.p.feats_b + n);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int m = mt * 32 + r;
+          const vec4 yv = to_vec4(T(), acc[nt][mt][4 * gq + 0] + b4[0], acc[nt][mt][4 * gq + 1] + b4[1],
+                                  acc[nt][mt][4 * gq + 2] + b4[2], acc[nt][mt][4 * gq + 3] + b4[3]);
+          *(vec4 *)(ACT + (size_t)m * LDA + n) = yv;
+          if (keep) *(vec4 *)(Fs + (size_t)m * F + n) = yv;
+        }
+      }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- two-layer sigmoid heads, up to 2 per pass
+  for (int p = 0; p < g.n_pass; ++p) {
+    if (g.pass_heads[p] == 2) head_pass<T, MT, NT>(A, p, ACT, RED, m0, tile);
+    else head_pass<T, MT, 1>(A, p, ACT, RED, m0, tile);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ weight packing
+struct PackJob {
+  const float *src;
+  size_t dst;        // element offset in the packed buffer
+  int ld;            // row length of src
+  int rows, K;       // valid extents of the PACKED matrix (rows = A rows, K = contraction)
+  int rows_pad, K_pad;
+  int row_off, col_off;  // offsets into src (in the packed matrix's own row/col sense)
+  int transposed;    // 1: packed[row][k] = src[k - k_lo + col_off][row + row_off]
+  int k_lo;          // first packed k this job owns
+  int masked;        // 1: touch only k in [k_lo, k_lo+K) (several jobs fill one packed matrix)
+};
+#define BN_MAX_PACK_JOBS 48
+struct PackArgs {
+  PackJob job[BN_MAX_PACK_JOBS];
+  int n_jobs;
+  void *dst;
+};
+
+template <typename T> __global__ void pack_kernel(const PackArgs A) {
+  const PackJob &j = A.job[blockIdx.y];
+  T *dst = (T *)A.dst + j.dst;
+  const size_t total = (size_t)j.rows_pad * j.K_pad;
+  const int KS = j.K_pad / 16;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = i & 7, lane = (i >> 3) & 63;
+    const size_t blk = i >> 9;
+    const int ks = blk % KS, rt = blk / KS;
+    const int row = rt * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + e;
+    const int kk = k - j.k_lo;
+    if (j.masked && (kk < 0 || kk >= j.K)) continue;
+    float v = 0.f;
+    if (row < j.rows && kk >= 0 && kk < j.K)
+      v = j.transposed ? j.src[(size_t)(kk + j.col_off) * j.ld + row + j.row_off]
+                       : j.src[(size_t)(row + j.row_off) * j.ld + kk + j.col_off];
+    dst[i] = (T)v;
+  }
+}
+
+static size_t esize(int dtype) { return dtype == BN_BF16 ? 2 : 4; }
+
+extern "C" size_t bn_field_packed_bytes(const bn_field_desc *desc) {
+  FieldGeom g;
+  if (bn_make_geom(desc, &g)) return 0;
+  PackedLayout pl;
+  bn_make_packed_layout(g, &pl);
+  return pl.total * esize(desc->dtype);
+}
+
+extern "C" size_t bn_field_stash_bytes(const bn_field_desc *desc, int64_t n_points) {
+  FieldGeom g;
+  if (bn_make_geom(desc, &g)) return 0;
+  StashLayout sl;
+  bn_make_stash_layout(g, n_points, desc->dtype == BN_BF16 ? 128 : 64, esize(desc->dtype), &sl);
+  return sl.total;
+}
+
+extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P, void *packed, void *stream) {
+  FieldGeom g;
+  if (int e = bn_make_geom(desc, &g)) return e;
+  PackedLayout pl;
+  bn_make_packed_layout(g, &pl);
+  PackArgs a;
+  a.n_jobs = 0;
+  a.dst = packed;
+  auto add = [&](const float *src, size_t dst, int ld, int rows, int K, int row_off, int col_off, int tr) {
+    PackJob &j = a.job[a.n_jobs++];
+    j.src = src; j.dst = dst; j.ld = ld; j.rows = rows; j.K = K;
+    j.rows_pad = (int)bn_pad(rows, 32); j.K_pad = (int)bn_pad(K, 16);
+    j.row_off = row_off; j.col_off = col_off; j.transposed = tr; j.k_lo = 0; j.masked = 0;
+  };
+  const int F = g.F, P0 = g.P;
+  for (int l = 0; l < g.L; ++l) {
+    BN_REQUIRE(P->trunk_w[l] && P->trunk_b[l], "pack: trunk layer %d missing", l);
+    if (l == 0) add(P->trunk_w[l], pl.fwd_trunk[l][0], P0, F, P0, 0, 0, 0);
+    else if (l == g.skip) {
+      add(P->trunk_w[l], pl.fwd_trunk[l][0], F + P0, F, P0, 0, 0, 0);
+      add(P->trunk_w[l], pl.fwd_trunk[l][1], F + P0, F, F, 0, P0, 0);
+    } else add(P->trunk_w[l], pl.fwd_trunk[l][0], F, F, F, 0, 0, 0);
+    if (l >= 1) {  // W_l^T over the h inputs: packed[row j][k n] = W[n][j (+P0 at the skip layer)]
+      const int ld = l == g.skip ? F + P0 : F;
+      add(P->trunk_w[l], pl.bwd_trunk[l], ld, F, F, l == g.skip ? P0 : 0, 0, 1);
+    }
+  }
+  add(P->feats_w, pl.fwd_feats, F, F, F, 0, 0, 0);
+  add(P->feats_w, pl.bwd_feats, F, F, F, 0, 0, 1);
+  for (int p = 0; p < g.n_pass; ++p)
+    for (int hl = 0; hl < g.pass_heads[p]; ++hl) {
+      const int hd = 2 * p + hl;
+      BN_REQUIRE(P->head_w1[hd] && P->head_b1[hd] && P->head_w2[hd] && P->head_b2[hd], "pack: head %d missing", hd);
+      // forward: rows of the pass = [head 2p rows | head 2p+1 rows]; row tiles of a head are contiguous in the pass
+      add(P->head_w1[hd], pl.fwd_head[p] + (size_t)hl * g.H2 * F, F, g.H2, F, 0, 0, 0);
+    }
+  // transposed head-1 weights: packed[row j][k = column in pass] = W1_hd[k - hl*H2][j]; the heads of a pass
+  // interleave along k, so each head fills its own k range of the shared packed matrix (masked job).
+  for (int p = 0; p < g.n_pass; ++p)
+    for (int hl = 0; hl < g.pass_heads[p]; ++hl) {
+      PackJob &j = a.job[a.n_jobs++];
+      j.src = P->head_w1[2 * p + hl]; j.dst = pl.bwd_head[p]; j.ld = F; j.rows = F; j.K = g.H2;
+      j.rows_pad = F; j.K_pad = g.pass_N[p]; j.row_off = 0; j.col_off = 0; j.transposed = 1;
+      j.k_lo = hl * g.H2; j.masked = 1;
+    }
+  BN_REQUIRE(a.n_jobs <= BN_MAX_PACK_JOBS, "pack: too many jobs");
+  dim3 grid(64, a.n_jobs);
+  if (desc->dtype == BN_BF16) pack_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  else pack_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  BN_LAUNCH_CHECK("bn_pack_field");
+  return 0;
+}
+
+template <typename T, int MT, int NT> static int launch_fwd(const FwdArgs &a, int64_t tiles, hipStream_t st) {
+  constexpr int BM = MT * 32;
+  const size_t lds = ((size_t)BM * (a.g.F + Elem<T>::kPad) + (size_t)BM * (a.g.KP + Elem<T>::kPad)) * sizeof(T) +
+                     (size_t)BN_WAVES * 3 * BM * sizeof(float);
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute((const void *)field_fwd_kernel<T, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) {
+      bn_set_error("field_fwd: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
+      return BN_ELAUNCH;
+    }
+    configured = lds;
+  }
+  field_fwd_kernel<T, MT, NT><<<dim3((unsigned)tiles), BN_THREADS, lds, st>>>(a);
+  BN_LAUNCH_CHECK("field_fwd");
+  return 0;
+}
+
+int bn_field_forward_impl(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
+                          const bn_points *pts, float *out, void *stash, int sigma_only, void *stream) {
+  FwdArgs a;
+  if (int e = bn_make_geom(desc, &a.g)) return e;
+  BN_REQUIRE(!desc->normal_an, "field_forward: analytic normals are evaluated by bn_field_sigma_grad");
+  BN_REQUIRE(pts && pts->n_points > 0 && (pts->xyz || (pts->rays && pts->z && pts->n_samples > 0)), "field: bad points");
+  BN_REQUIRE(packed && out, "field: null buffer");
+  a.d = *desc; a.p = *params; a.packed = packed; a.pts = *pts; a.out = out; a.stash = (char *)stash;
+  a.sigma_only = sigma_only;
+  bn_make_packed_layout(a.g, &a.pl);
+  const int BM = desc->dtype == BN_BF16 ? 128 : 64;
+  bn_make_stash_layout(a.g, pts->n_points, BM, esize(desc->dtype), &a.sl);
+  const int64_t tiles = ceil_div64(pts->n_points, BM);
+  hipStream_t st = (hipStream_t)stream;
+  if (desc->dtype == BN_BF16) return a.g.NT == 2 ? launch_fwd<bf16, 4, 2>(a, tiles, st) : launch_fwd<bf16, 4, 1>(a, tiles, st);
+  return a.g.NT == 2 ? launch_fwd<float, 2, 2>(a, tiles, st) : launch_fwd<float, 2, 1>(a, tiles, st);
+}
+
+extern "C" int bn_field_sigma(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
+                              const bn_points *pts, float *sigma, void *stream) {
+  return bn_field_forward_impl(desc, params, packed, pts, sigma, nullptr, 1, stream);
+}
+extern "C" int bn_field_forward(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
+                                const bn_points *pts, float *out, void *stash, void *stream) {
+  return bn_field_forward_impl(desc, params, packed, pts, out, stash, 0, stream);
+}

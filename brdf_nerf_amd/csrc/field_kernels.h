@@ -1,0 +1,81 @@
+// Device building blocks of the fused field MLP: the activation-stationary tile GEMM and the
+// accumulator-register <-> (point, feature) maps shared by the forward and backward chain kernels.
+//
+// Tiling (one 512-thread workgroup = 8 waves = 2 waves per SIMD):
+//   * a tile of BM points (128 for bf16, 64 for fp32) keeps its activations in LDS as ACT[BM][F+pad]
+//     (row-major, k contiguous) for the whole network;
+//   * products are computed "swapped": D[n][m] = sum_k W[n][k] * ACT[m][k], i.e. the WEIGHTS are the MFMA
+//     A operand (rows n) streamed from L2 in pre-packed fragment order (one coalesced 1 KB load per
+//     32x16 block, no LDS), and the ACTIVATIONS are the B operand read from LDS with ds_read_b128;
+//   * wave w owns output features [w*32*NTW, (w+1)*32*NTW) for all BM points: acc[NTW][MT] 32x32 tiles.
+//     In the accumulator a lane owns ONE point (m = mt*32 + (lane&31)) and 4 runs of 4 consecutive features
+//     (n = 8g + 4h + e), so activations are written back to ACT[m][n..n+3] with one 8-byte store.
+#pragma once
+#include "field.h"
+
+#define BN_THREADS 512
+#define BN_WAVES 8
+
+template <typename T> __device__ __forceinline__ typename Elem<T>::frag lds_frag(const T *p);
+template <> __device__ __forceinline__ bf16x8 lds_frag<bf16>(const bf16 *p) { return *(const bf16x8 *)p; }
+template <> __device__ __forceinline__ f32x8 lds_frag<float>(const float *p) {
+  f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
+  f32x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return r;
+}
+template <typename T> __device__ __forceinline__ typename Elem<T>::frag gld_frag(const T *p) { return lds_frag<T>(p); }
+
+// acc[nt][mt] += W_packed(this wave's tiles) x B(lds).  `wp` points at the packed block of the wave's first
+// n-tile for this K segment; consecutive n-tiles are KS*512 elements apart.
+template <typename T, int MT, int NTW>
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb,
+                                         int lane) {
+  typedef typename Elem<T>::frag frag;
+  constexpr int U = Elem<T>::kU;
+  const int r = lane & 31, h = lane >> 5;
+  const T *wl = wp + (size_t)lane * 8;
+  const T *bl = bsrc + (size_t)r * ldb + 8 * h;
+  frag A0[U][NTW], A1[U][NTW];
+  // KS is a multiple of U (every K extent is a multiple of 32): no guards inside the loop, one optional tail block.
+  auto loadA = [&](frag(&A)[U][NTW], int kb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) A[u][nt] = gld_frag<T>(wl + ((size_t)nt * KS + kb + u) * 512);
+  };
+  auto compute = [&](frag(&A)[U][NTW], int kb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      frag B[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) B[mt] = lds_frag<T>(bl + (size_t)mt * 32 * ldb + (kb + u) * 16);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], A[u][nt], B[mt]);
+    }
+  };
+  loadA(A0, 0);
+  int kb = 0;
+  for (; kb + 2 * U <= KS; kb += 2 * U) {
+    loadA(A1, kb + U);
+    compute(A0, kb);
+    loadA(A0, kb + 2 * U < KS ? kb + 2 * U : 0);  // after the last full pair: the tail block, or block 0 (unused)
+    compute(A1, kb + U);
+  }
+  if (kb < KS) compute(A0, kb);
+}
+
+template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NTW][MT]) {
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
+}
+
+// Offset (elements) of the 4-element run (nt, mt, g) of this lane in a "native" stash image of one tile.
+template <int MT, int NTW> __device__ __forceinline__ size_t native_off(int wave, int nt, int mt, int g, int lane) {
+  return ((((size_t)(wave * NTW + nt) * MT + mt) * 4 + g) * 64 + lane) * 4;
+}

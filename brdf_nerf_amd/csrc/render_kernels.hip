@@ -1,0 +1,392 @@
+// Per-ray kernels of the render path (HBM-bound, one 64-lane wavefront per ray):
+//   stratified depths   get_z_vals                 rendering.py:149-166
+//   compositing scan    cal_weight + weighted sums models/spsbrdfnerf.py:50-69, :198-338
+//   guided resampling   GenerateGuidedSamples..sample_pdf + merge   rendering.py:13-91,116-147,263-272
+// fp32 throughout; FMA contraction is disabled so that the depth/sample arithmetic rounds like the
+// reference's separate ATen ops (needed for bit-exact sample indices).
+#include "common.h"
+#pragma clang fp contract(off)
+
+#define WAVES_PER_BLOCK 4
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// torch.linspace(start, end, steps)[i] in fp32 (symmetric formula of ATen's RangeFactories).
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+  const float step = (end - start) / (float)(steps - 1);
+  return i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+
+// ------------------------------------------------------------------------------------------ stratified z
+__global__ void stratified_z_kernel(const float *near, const float *far, int64_t nf_stride, const float *u, int64_t R,
+                                    int S, float *z) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * S) return;
+  const int64_t ray = i / S;
+  const int s = (int)(i % S);
+  const float n = near[ray * nf_stride], f = far[ray * nf_stride];
+  auto zc = [&](int j) {
+    const float t = linspace_at(0.f, 1.f, S, j);
+    return n * (1.f - t) + f * t;
+  };
+  const float zi = zc(s);
+  const float lower = s == 0 ? zi : 0.5f * (zc(s - 1) + zi);
+  const float upper = s == S - 1 ? zi : 0.5f * (zi + zc(s + 1));
+  z[i] = lower + (upper - lower) * u[i];
+}
+
+extern "C" int bn_stratified_z(const float *near, const float *far, int64_t nf_stride, const float *u, int64_t R,
+                               int32_t S, float *z, void *stream) {
+  BN_REQUIRE(near && far && u && z && R > 0 && S >= 2, "stratified_z: bad arguments");
+  const int64_t n = R * S;
+  stratified_z_kernel<<<dim3((unsigned)ceil_div64(n, 256)), 256, 0, (hipStream_t)stream>>>(near, far, nf_stride, u, R, S, z);
+  BN_LAUNCH_CHECK("stratified_z");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ compositing
+// Lane i of the ray's wave owns samples [i*c, (i+1)*c), c = ceil(S/64) <= BN_MAX_C: the exclusive prefix product
+// of (1 - alpha + 1e-10) is a per-lane serial product + a 6-step wavefront shuffle scan.
+#define BN_MAX_CPL 8   // samples per lane -> S <= 512
+#define BN_MAX_CH 16
+
+struct CompArgs {
+  const float *z, *sigma, *noise, *chan;
+  int64_t sigma_stride, chan_stride;
+  float noise_std;
+  int C, S;
+  int64_t R;
+  float *alphas, *trans, *weights, *depth, *acc;
+  // backward
+  const float *d_weights, *d_depth, *d_acc;
+  float *d_sigma, *d_chan;
+  int64_t d_sigma_stride, d_chan_stride;
+};
+
+__device__ __forceinline__ float wave_excl_prod(float v, int lane) {
+  // inclusive Hillis-Steele scan, then shift by one lane
+  float p = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(p, o);
+    if (lane >= o) p *= t;
+  }
+  const float e = __shfl_up(p, 1);
+  return lane == 0 ? 1.f : e;
+}
+__device__ __forceinline__ float wave_excl_sum_rev(float v, int lane) {
+  // exclusive suffix sum: sum of v over lanes > lane
+  float p = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_down(p, o);
+    if (lane + o < 64) p += t;
+  }
+  const float e = __shfl_down(p, 1);
+  return lane == 63 ? 0.f : e;
+}
+
+template <bool BWD> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void composite_kernel(const CompArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (ray >= A.R) return;
+  const int S = A.S, cpl = (S + 63) / 64;
+  const float *z = A.z + ray * S;
+  float zv[BN_MAX_CPL], al[BN_MAX_CPL], u[BN_MAX_CPL], dad[BN_MAX_CPL];  // dad = d alpha / d sigma
+  float lp = 1.f;
+#pragma unroll
+  for (int j = 0; j < BN_MAX_CPL; ++j) {
+    zv[j] = 0.f; al[j] = 0.f; u[j] = 1.f; dad[j] = 0.f;
+    const int s = lane * cpl + j;
+    if (j < cpl && s < S) {
+      zv[j] = z[s];
+      const float delta = s == S - 1 ? 1e10f : z[s + 1] - zv[j];
+      float sg = A.sigma[(ray * S + s) * A.sigma_stride];
+      if (A.noise) sg = sg + A.noise[ray * S + s] * A.noise_std;
+      const float rs = sg > 0.f ? sg : 0.f;
+      const float e = expf(-delta * rs);
+      al[j] = 1.f - e;
+      u[j] = 1.f - al[j] + 1e-10f;
+      dad[j] = sg > 0.f ? delta * e : 0.f;
+      lp *= u[j];
+    }
+  }
+  float T = wave_excl_prod(lp, lane);  // transparency before this lane's first sample
+  float tr[BN_MAX_CPL], w[BN_MAX_CPL];
+#pragma unroll
+  for (int j = 0; j < BN_MAX_CPL; ++j) {
+    tr[j] = T;
+    w[j] = al[j] * T;
+    T *= u[j];
+  }
+  if (!BWD) {
+    float dsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < BN_MAX_CPL; ++j) {
+      const int s = lane * cpl + j;
+      if (j < cpl && s < S) {
+        const int64_t o = ray * S + s;
+        if (A.alphas) A.alphas[o] = al[j];
+        if (A.trans) A.trans[o] = tr[j];
+        if (A.weights) A.weights[o] = w[j];
+        dsum += w[j] * zv[j];
+      }
+    }
+    dsum = wave_sum(dsum);
+    if (lane == 0 && A.depth) A.depth[ray] = dsum;
+    if (A.chan && A.acc) {
+      for (int c = 0; c < A.C; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < BN_MAX_CPL; ++j) {
+          const int s = lane * cpl + j;
+          if (j < cpl && s < S) a += w[j] * A.chan[(ray * S + s) * A.chan_stride + c];
+        }
+        a = wave_sum(a);
+        if (lane == 0) A.acc[ray * A.C + c] = a;
+      }
+    }
+  } else {
+    // g_s = dL/dw_s; dL/dalpha_s = g_s T_s - (1/u_s) sum_{k>s} g_k w_k   
+    const float dd = A.d_depth ? A.d_depth[ray] : 0.f;
+    float dacc[BN_MAX_CH];
+#pragma unroll
+    for (int c = 0; c < BN_MAX_CH; ++c) dacc[c] = (A.d_acc && c < A.C) ? A.d_acc[ray * A.C + c] : 0.f;
+    float g[BN_MAX_CPL], gw = 0.f;
+#pragma unroll
+    for (int j = 0; j < BN_MAX_CPL; ++j) {
+      g[j] = 0.f;
+      const int s = lane * cpl + j;
+      if (j < cpl && s < S) {
+        float gg = dd * zv[j];
+        if (A.d_weights) gg += A.d_weights[ray * S + s];
+        if (A.chan && A.d_acc) {
+          const float *ch = A.chan + (ray * S + s) * A.chan_stride;
+          float *dch = A.d_chan ? A.d_chan + (ray * S + s) * A.d_chan_stride : nullptr;
+#pragma unroll
+          for (int c = 0; c < BN_MAX_CH; ++c)
+            if (c < A.C) {
+              gg += dacc[c] * ch[c];
+              if (dch) dch[c] = w[j] * dacc[c];
+            }
+        }
+        g[j] = gg;
+        gw += gg * w[j];
+      }
+    }
+    float suffix = wave_excl_sum_rev(gw, lane);  // sum of g*w over later lanes
+#pragma unroll
+    for (int j = BN_MAX_CPL - 1; j >= 0; --j) {
+      const int s = lane * cpl + j;
+      if (j < cpl && s < S) {
+        const float dalpha = g[j] * tr[j] - suffix / u[j];
+        A.d_sigma[(ray * S + s) * A.d_sigma_stride] = dalpha * dad[j];
+        suffix += g[j] * w[j];
+      }
+    }
+  }
+}
+
+extern "C" int bn_composite_forward(const float *z, const float *sigma, int64_t sigma_stride, const float *noise,
+                                    float noise_std, const float *chan, int64_t chan_stride, int32_t C, int64_t R,
+                                    int32_t S, float *alphas, float *trans, float *weights, float *depth, float *acc,
+                                    void *stream) {
+  BN_REQUIRE(z && sigma && R > 0 && S >= 1 && S <= 64 * BN_MAX_CPL, "composite: bad arguments (S=%d)", S);
+  BN_REQUIRE(C >= 0 && C <= BN_MAX_CH, "composite: C=%d > %d", C, BN_MAX_CH);
+  CompArgs a = {};
+  a.z = z; a.sigma = sigma; a.noise = noise; a.chan = chan; a.sigma_stride = sigma_stride; a.chan_stride = chan_stride;
+  a.noise_std = noise_std; a.C = C; a.S = S; a.R = R;
+  a.alphas = alphas; a.trans = trans; a.weights = weights; a.depth = depth; a.acc = acc;
+  composite_kernel<false><<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
+  BN_LAUNCH_CHECK("composite_forward");
+  return 0;
+}
+
+extern "C" int bn_composite_backward(const float *z, const float *sigma, int64_t sigma_stride, const float *noise,
+                                     float noise_std, const float *chan, int64_t chan_stride, int32_t C, int64_t R,
+                                     int32_t S, const float *d_weights, const float *d_depth, const float *d_acc,
+                                     float *d_sigma, int64_t d_sigma_stride, float *d_chan, int64_t d_chan_stride,
+                                     void *stream) {
+  BN_REQUIRE(z && sigma && d_sigma && R > 0 && S >= 1 && S <= 64 * BN_MAX_CPL, "composite_backward: bad arguments");
+  BN_REQUIRE(C >= 0 && C <= BN_MAX_CH, "composite_backward: C=%d > %d", C, BN_MAX_CH);
+  CompArgs a = {};
+  a.z = z; a.sigma = sigma; a.noise = noise; a.chan = chan; a.sigma_stride = sigma_stride; a.chan_stride = chan_stride;
+  a.noise_std = noise_std; a.C = C; a.S = S; a.R = R;
+  a.d_weights = d_weights; a.d_depth = d_depth; a.d_acc = d_acc; a.d_sigma = d_sigma; a.d_chan = d_chan;
+  a.d_sigma_stride = d_sigma_stride; a.d_chan_stride = d_chan_stride;
+  composite_kernel<true><<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
+  BN_LAUNCH_CHECK("composite_backward");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ guided resampling
+#define BN_MAX_G 256
+#define BN_MAX_SG 512
+
+struct GuidedArgs {
+  const float *z, *weights, *depth, *u, *use_target, *target_depth, *target_std, *u_target;
+  const int32_t *target_row;
+  int64_t R;
+  int S, G;
+  float near0, far0, d_range;
+  float *z2_sorted, *z_all;
+  int64_t *sort_idx;
+};
+
+// in-LDS bitonic sort of n2 (power of two) (key, index) pairs by one wave; ties broken by index (= stable).
+__device__ __forceinline__ void wave_bitonic(float *key, int *idx, int n2, int lane) {
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = lane; i < n2; i += 64) {
+        const int p = i ^ j;
+        if (p > i) {
+          const float a = key[i], b = key[p];
+          const int ia = idx[i], ib = idx[p];
+          const bool up = (i & k) == 0;
+          const bool gt = a > b || (a == b && ia > ib);
+          if (gt == up) { key[i] = b; key[p] = a; idx[i] = ib; idx[p] = ia; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+    }
+}
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void guided_kernel(const GuidedArgs A) {
+  __shared__ float s_edges[WAVES_PER_BLOCK][BN_MAX_G];
+  __shared__ float s_cdf[WAVES_PER_BLOCK][BN_MAX_G];
+  __shared__ float s_key[WAVES_PER_BLOCK][BN_MAX_SG];
+  __shared__ int s_idx[WAVES_PER_BLOCK][BN_MAX_SG];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv;
+  if (ray >= A.R) return;
+  const int S = A.S, G = A.G;
+  float *edges = s_edges[wv], *cdf = s_cdf[wv], *key = s_key[wv];
+  int *idx = s_idx[wv];
+  const float *z = A.z + ray * S;
+
+  // 1. centre and spread (train_utils.py:35-39), or the ground-truth depth prior (rendering.py:135-145)
+  float centre, std;
+  const float *u;
+  if (A.use_target && A.use_target[ray] > 0.f) {
+    centre = A.target_depth[ray];
+    std = A.target_std[ray];
+    u = A.u_target + (int64_t)A.target_row[ray] * G;
+  } else {
+    centre = A.depth[ray];
+    float acc = 0.f;
+    for (int s = lane; s < S; s += 64) {
+      const float dz = z[s] - centre;
+      acc += dz * dz * A.weights[ray * S + s];
+    }
+    std = sqrtf(wave_sum(acc));
+    u = A.u + ray * G;
+  }
+  // 2. symmetric 3-sigma window inside [near0, far0] (rendering.py:76-83)
+  float lo = centre - A.d_range * std, hi = centre + A.d_range * std;
+  lo = fminf(fmaxf(lo, A.near0), A.far0);
+  hi = fminf(fmaxf(hi, A.near0), A.far0);
+  const float rng = fminf(fabsf(hi - centre), fabsf(lo - centre));
+  lo = centre - rng;
+  hi = centre + rng;
+  // 3. bin edges and Gaussian bin weights (rendering.py:63-69)
+  const float step = (hi - lo) / (float)(G - 1);
+  for (int j = lane; j < G; j += 64) {
+    const float t = linspace_at(0.f, 1.f, G, j);
+    edges[j] = lo * (1.f - t) + hi * t;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  float wsum = 0.f;
+  for (int j = lane; j < G - 1; j += 64) {
+    const float factor = (edges[j + 1] - edges[j]) / (step + 1e-5f);
+    const float x = linspace_at(-A.d_range, A.d_range, G - 1, j);
+    const float bw = factor * (0.3989422804014327f * expf(-0.5f * (x * x)));
+    const float w = bw + 1e-5f;
+    key[j] = w;
+    wsum += w;
+  }
+  wsum = wave_sum(wsum);
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  // 4. cdf: sequential cumsum (rendering.py:27-29); the reference's CPU torch.cumsum accumulates fp32 inputs in
+  //    double and rounds each prefix to fp32 - done the same way so that searchsorted indices agree.
+  if (lane == 0) {
+    double c = 0.0;
+    cdf[0] = 0.f;
+    for (int j = 0; j < G - 1; ++j) {
+      c += (double)(key[j] / wsum);
+      cdf[j + 1] = (float)c;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  // 5. inverse-CDF sampling, searchsorted(right=True) (rendering.py:39-51)
+  const int n2g = G <= 64 ? 64 : (G <= 128 ? 128 : 256);
+  for (int j = lane; j < n2g; j += 64) {
+    float smp = INFINITY;
+    if (j < G) {
+      const float uu = u[j];
+      int lo_i = 0, hi_i = G;  // first index with cdf[i] > uu
+      while (lo_i < hi_i) {
+        const int mid = (lo_i + hi_i) >> 1;
+        if (cdf[mid] > uu) hi_i = mid; else lo_i = mid + 1;
+      }
+      const int inds = lo_i;
+      const int below = inds - 1 > 0 ? inds - 1 : 0;
+      const int above = inds < G - 1 ? inds : G - 1;
+      const float c0 = cdf[below], c1 = cdf[above];
+      float denom = c1 - c0;
+      if (denom < 1e-5f) denom = 1.f;
+      smp = edges[below] + (uu - c0) / denom * (edges[above] - edges[below]);
+    }
+    key[j] = smp;
+    idx[j] = j;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  wave_bitonic(key, idx, n2g, lane);
+  float *z2 = A.z2_sorted + ray * G;
+  for (int j = lane; j < G; j += 64) z2[j] = key[j];
+  if (!A.z_all) return;
+  // 6. merge with the coarse depths: stable sort of cat[z, z2] (rendering.py:271-272)
+  const int N = S + G;
+  int n2 = 64;
+  while (n2 < N) n2 <<= 1;
+  float my[BN_MAX_G / 64];
+  for (int j = lane, q = 0; j < G; j += 64, ++q) my[q] = key[j];
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  for (int j = lane, q = 0; j < G; j += 64, ++q) key[S + j] = my[q];
+  for (int j = lane; j < S; j += 64) key[j] = z[j];
+  for (int j = lane; j < n2; j += 64) {
+    idx[j] = j;
+    if (j >= N) key[j] = INFINITY;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  wave_bitonic(key, idx, n2, lane);
+  for (int j = lane; j < N; j += 64) {
+    A.z_all[ray * N + j] = key[j];
+    if (A.sort_idx) A.sort_idx[ray * N + j] = idx[j];
+  }
+}
+
+extern "C" int bn_guided_samples(const float *z, const float *weights, const float *depth, const float *u, int64_t R,
+                                 int32_t S, int32_t G, float near0, float far0, float d_range, const float *use_target,
+                                 const float *target_depth, const float *target_std, const float *u_target,
+                                 const int32_t *target_row, float *z2_sorted, float *z_all, int64_t *sort_idx,
+                                 void *stream) {
+  BN_REQUIRE(z && weights && depth && u && z2_sorted && R > 0, "guided_samples: null argument");
+  BN_REQUIRE(G >= 3 && G <= BN_MAX_G && S >= 1 && S + G <= BN_MAX_SG, "guided_samples: S=%d G=%d unsupported", S, G);
+  BN_REQUIRE(!use_target || (target_depth && target_std && u_target && target_row), "guided_samples: target arrays");
+  GuidedArgs a = {z, weights, depth, u, use_target, target_depth, target_std, u_target, target_row, R, S, G,
+                  near0, far0, d_range, z2_sorted, z_all, sort_idx};
+  guided_kernel<<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
+  BN_LAUNCH_CHECK("guided_samples");
+  return 0;
+}

@@ -1,0 +1,219 @@
+"""Drop-in `SpSBRDFNeRF` module: the reference's constructor, attributes, method names and state_dict
+keys (models/spsbrdfnerf.py:418-757, models/__init__.py:6-17), evaluated by the fused HIP kernels.
+
+Checkpoint contract: `fc_net.{0,2,..}.{weight,bias}`, `sigma_from_xyz.0.*`,
+`feats_from_xyz.*`, `rgb_from_xyzdir.{0,2}.*`, `grad_from_xyz.*`, `roughness_from_xyz.{0,2}.*`,
+`k_from_xyz.*`, `theta_rpv_from_xyz.*`, `rhoc_from_xyz.*`, `b_from_xyz.*`, `c_from_xyz.*`,
+`theta_from_xyz.*` - a reference checkpoint loads with load_state_dict unchanged.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import functions as Fn
+
+
+class Siren(nn.Module):
+    """Parameter-free placeholder keeping the reference's nn.Sequential indices (models/nerf.py:23-33)."""
+
+    def __init__(self, w0=1.0):
+        super().__init__()
+        self.w0 = w0
+
+    def forward(self, x):  # only used by state_dict-compatible introspection, never on the hot path
+        return torch.sin(self.w0 * x)
+
+
+def _sine_init(m):
+    if hasattr(m, "weight"):
+        with torch.no_grad():
+            n = m.weight.size(-1)
+            m.weight.uniform_(-math.sqrt(6 / n), math.sqrt(6 / n))
+
+
+def _first_layer_sine_init(m):
+    if hasattr(m, "weight"):
+        with torch.no_grad():
+            n = m.weight.size(-1)
+            m.weight.uniform_(-1 / n, 1 / n)
+
+
+_UNSUPPORTED = ("Not implemented by the MI355X build (out of the hot-path scope table, SURVEY.md section 8): ")
+
+
+class SpSBRDFNeRF(nn.Module):
+    def __init__(self, args, layers=8, feat=256, mapping=False, mapping_sizes=[10, 4], skips=[4], siren=True,
+                 t_embedding_dims=16, beta=True, roughness=True, normal="none", sun_v="none", indirect_light=False,
+                 glossy_scale=1.0, MultiBRDF=False, dim_RPV=3, compute_dtype="fp32"):
+        super().__init__()
+        if beta:
+            raise NotImplementedError(_UNSUPPORTED + "--beta (transient embedding; reference README recommends it off)")
+        if sun_v != "none":
+            raise NotImplementedError(_UNSUPPORTED + f"--sun_v {sun_v} (reference quirks 2 and 3: crashes upstream)")
+        if indirect_light:
+            raise NotImplementedError(_UNSUPPORTED + "--indirect_light (needs sun_v)")
+        if getattr(args, "input_viewdir", 0):
+            raise NotImplementedError(_UNSUPPORTED + "--input_viewdir")
+        if normal in ("analystic", "analystic_learned"):
+            raise NotImplementedError(_UNSUPPORTED + "--normal analystic (adjoint chain kernel is the next row)")
+        if len(skips) > 1:
+            raise NotImplementedError(_UNSUPPORTED + "more than one skip layer")
+        self.layers, self.skips, self.t_embedding_dims = layers, list(skips), t_embedding_dims
+        self.input_sizes = [3, 0]
+        self.rgb_padding = 0.001
+        self.beta, self.roughness, self.sun_v, self.indirect_light = beta, roughness, sun_v, indirect_light
+        self.normal, self.glossy_scale, self.MultiBRDF, self.args = normal, glossy_scale, bool(MultiBRDF), args
+        self.RPV = bool(args.funcM == True or args.funcF == True or args.funcH == True)  # noqa: E712 (reference semantics)
+        self.dim_RPV = dim_RPV
+        self.feat, self.siren_on = feat, bool(siren)
+        self.pe_freqs = mapping_sizes[0] if mapping else 0
+        self.compute_dtype = compute_dtype
+
+        self.number_of_outputs = 4
+        self.number_of_outputs_brdf = 4
+        if roughness:
+            self.number_of_outputs_brdf += 1
+        elif self.RPV:
+            self.number_of_outputs_brdf += 3 * (int(args.funcM == True) + int(args.funcF == True) + int(args.funcH == True))  # noqa: E712
+        else:
+            self.number_of_outputs_brdf += 3 * (int(args.b == True) + int(args.c == True))  # noqa: E712
+
+        nl = Siren() if siren else nn.ReLU()
+        in0 = 2 * mapping_sizes[0] * 3 if mapping else 3
+        fc = [nn.Linear(in0, feat), Siren(w0=30.0) if siren else nl]
+        for i in range(1, layers):
+            fc.append(nn.Linear(feat + in0 if i in skips else feat, feat))
+            fc.append(nl)
+        self.fc_net = nn.Sequential(*fc)
+        self.sigma_from_xyz = nn.Sequential(nn.Linear(feat, 1), nn.Softplus())
+        self.feats_from_xyz = nn.Linear(feat, feat)
+
+        def head(n_out):
+            return nn.Sequential(nn.Linear(feat, feat // 2), nl, nn.Linear(feat // 2, n_out), nn.Sigmoid())
+
+        self.rgb_from_xyzdir = head(3)
+        if siren:
+            self.fc_net.apply(_sine_init)
+            self.fc_net[0].apply(_first_layer_sine_init)
+        if normal in ("analystic_learned", "learned"):
+            self.grad_from_xyz = nn.Linear(feat, 3)
+        if roughness:
+            self.roughness_from_xyz = head(1)
+        if args.funcM == True:  # noqa: E712
+            self.k_from_xyz = head(dim_RPV)
+        if args.funcF == True:  # noqa: E712
+            self.theta_rpv_from_xyz = head(dim_RPV)
+        if args.funcH == True:  # noqa: E712
+            self.rhoc_from_xyz = head(dim_RPV)
+        if args.b == True:  # noqa: E712
+            self.b_from_xyz = head(1)
+        if args.c == True:  # noqa: E712
+            self.c_from_xyz = head(1)
+        if args.theta == True:  # noqa: E712
+            self.theta_from_xyz = head(1)
+        self._specs = {}
+        self._packed = {}
+
+    # ------------------------------------------------------------------ reference-compatible helpers
+    def freeze(self, layer_name):
+        for name, p in self.named_parameters():
+            if layer_name in name or layer_name == "all":
+                p.requires_grad = False
+
+    def unfreeze(self, layer_name):
+        for name, p in self.named_parameters():
+            if layer_name in name:
+                p.requires_grad = True
+
+    def freeze_rest(self, layer_name):
+        for name, p in self.named_parameters():
+            if layer_name not in name:
+                p.requires_grad = False
+
+    def print_parms(self, only_name=False):
+        n = 0
+        for name, p in self.named_parameters():
+            print(f"{name} | gra {p.requires_grad} | {tuple(p.shape)}")
+            n += p.numel()
+        print("Total parameter number: ", n)
+
+    def check_nan_parms(self, keyword=""):
+        """The reference syncs the device per parameter here (rendering.py:233,257,276).  Kept as a cheap no-op:
+        NaN replacement happens in-kernel."""
+        return None
+
+    # ------------------------------------------------------------------ HIP plumbing
+    def head_list(self, apply_brdf, apply_theta):
+        heads = [("rgb_from_xyzdir", 3, L.BN_HEAD_PLAIN)]
+        a = self.args
+        if apply_brdf:
+            if self.roughness:
+                heads.append(("roughness_from_xyz", 1, L.BN_HEAD_PLAIN))
+            elif self.RPV:
+                if a.funcM == True:  # noqa: E712
+                    heads.append(("k_from_xyz", self.dim_RPV, L.BN_HEAD_RPV_K))
+                if a.funcF == True:  # noqa: E712
+                    heads.append(("theta_rpv_from_xyz", self.dim_RPV, L.BN_HEAD_RPV_THETA))
+                if a.funcH == True:  # noqa: E712
+                    heads.append(("rhoc_from_xyz", self.dim_RPV, L.BN_HEAD_TILE3))
+            else:
+                if a.b == True:  # noqa: E712
+                    heads.append(("b_from_xyz", 1, L.BN_HEAD_TILE3))
+                if a.c == True:  # noqa: E712
+                    heads.append(("c_from_xyz", 1, L.BN_HEAD_TILE3))
+                if apply_theta and a.theta == True:  # noqa: E712
+                    heads.append(("theta_from_xyz", 1, L.BN_HEAD_HAPKE_THETA))
+        return heads
+
+    def spec(self, apply_brdf=False, apply_theta=False, nr_lr_on=False):
+        dtype = L.BN_BF16 if self.compute_dtype == "bf16" else L.BN_F32
+        key = (bool(apply_brdf), bool(apply_theta), bool(nr_lr_on), dtype)
+        if key not in self._specs:
+            self._specs[key] = Fn.FieldSpec(self.feat, self.layers, self.skips[0] if self.skips else -1, self.pe_freqs,
+                                            L.BN_ACT_SIN if self.siren_on else L.BN_ACT_RELU, dtype,
+                                            self.head_list(apply_brdf, apply_theta), nr_lr_on)
+        return self._specs[key]
+
+    def named(self):
+        return dict(self.named_parameters())
+
+    def repack(self, spec):
+        """Refresh the MFMA-fragment-ordered copy of the weights (call after every optimizer step)."""
+        k = spec.key()
+        buf = self._packed.get(k)
+        if buf is not None and buf.device != self.fc_net[0].weight.device:
+            buf = None
+        with torch.no_grad():
+            self._packed[k] = Fn.pack_field(spec, self.named(), buf)
+        return self._packed[k]
+
+    def forward(self, input_xyz_, input_dir=None, input_sun_dir=None, input_t=None, sigma_only=False, apply_brdf=False,
+                apply_theta=False, nr_an_on=False, nr_lr_on=False, sun_ray=False, mode="train"):
+        """(B,3) points -> (B,C) [rgb3, sigma, (normal_lr3), BRDF head outputs], or (B,1) sigma."""
+        if nr_an_on:
+            raise NotImplementedError(_UNSUPPORTED + "analytic normals (nr_an_on)")
+        spec = self.spec(apply_brdf, apply_theta, nr_lr_on)
+        packed = self.repack(spec)
+        xyz = input_xyz_.detach().float().contiguous()
+        if sigma_only:
+            return Fn.field_sigma(spec, self.named(), packed, xyz=xyz).unsqueeze(-1)
+        return self.evaluate(spec, packed, xyz=xyz)
+
+    def evaluate(self, spec, packed, xyz=None, rays=None, z=None):
+        names = spec.used_param_names()
+        named = self.named()
+        return Fn.FieldFunction.apply(spec, packed, xyz, rays, z, names, *[named[n] for n in names])
+
+
+def load_model(args, compute_dtype=None):
+    """models/__init__.py:6-17 for --model spsbrdf-nerf."""
+    if args.model != "spsbrdf-nerf":
+        raise ValueError(f"model {args.model} is not served by brdf_nerf_amd (spsbrdf-nerf only)")
+    return SpSBRDFNeRF(args, layers=args.fc_layers, mapping=args.mapping, feat=args.fc_feat,
+                       t_embedding_dims=args.t_embbeding_tau, beta=args.beta, roughness=args.roughness, normal=args.normal,
+                       indirect_light=args.indirect_light, glossy_scale=args.glossy_scale, sun_v=args.sun_v,
+                       MultiBRDF=args.MultiBRDF, dim_RPV=args.dim_RPV, siren=args.siren,
+                       compute_dtype=compute_dtype or getattr(args, "compute_dtype", "fp32"))

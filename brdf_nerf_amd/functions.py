@@ -1,0 +1,337 @@
+"""torch.autograd.Function wrappers over the C ABI (include/brdfnerf_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream and stitches the autograd graph;
+every numerical step of the hot path runs in the HIP library.  No CPU fallback exists.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "C ABI needs contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+# ----------------------------------------------------------------------------------------- field MLP
+class FieldSpec:
+    """Host-side description of one evaluation of the field: which heads, which dtype."""
+
+    def __init__(self, feat, layers, skip, pe_freqs, act, dtype, heads, normal_lr):
+        # heads: list of (name, n_out, kind); heads[0] must be ("rgb_from_xyzdir", 3, PLAIN)
+        self.feat, self.layers, self.skip, self.pe_freqs, self.act, self.dtype = feat, layers, skip, pe_freqs, act, dtype
+        self.heads, self.normal_lr = list(heads), bool(normal_lr)
+        d = L.FieldDesc()
+        d.feat, d.layers, d.skip, d.pe_freqs, d.act, d.dtype = feat, layers, skip, pe_freqs, act, dtype
+        d.n_heads = len(self.heads)
+        c = 4 + (3 if normal_lr else 0)
+        self.head_cols = []
+        for i, (_, n_out, kind) in enumerate(self.heads):
+            d.head_out[i], d.head_kind[i] = n_out, kind
+            if i == 0:
+                self.head_cols.append((0, 3))
+            else:
+                w = n_out if kind in (L.BN_HEAD_PLAIN, L.BN_HEAD_HAPKE_THETA) else 3
+                self.head_cols.append((c, w))
+                c += w
+        d.normal_lr, d.normal_an, d.out_channels = int(normal_lr), 0, c
+        self.desc, self.out_channels = d, c
+        self.ch_normal_lr = 4 if normal_lr else -1
+        self.packed_bytes = L.lib().bn_field_packed_bytes(C.byref(d))
+        if self.packed_bytes == 0:
+            raise RuntimeError("bn_field_packed_bytes: " + L.lib().bn_last_error().decode())
+
+    def key(self):
+        return (self.feat, self.layers, self.skip, self.pe_freqs, self.act, self.dtype, tuple(self.heads), self.normal_lr)
+
+    def params_struct(self, named, grads=False):
+        """named: dict state_dict-key -> tensor (parameters, or same-shaped gradient buffers)."""
+        s = L.FieldParams()
+        for l in range(self.layers):
+            s.trunk_w[l] = named[f"fc_net.{2*l}.weight"].data_ptr()
+            s.trunk_b[l] = named[f"fc_net.{2*l}.bias"].data_ptr()
+        s.sigma_w, s.sigma_b = named["sigma_from_xyz.0.weight"].data_ptr(), named["sigma_from_xyz.0.bias"].data_ptr()
+        s.feats_w, s.feats_b = named["feats_from_xyz.weight"].data_ptr(), named["feats_from_xyz.bias"].data_ptr()
+        for i, (name, _, _) in enumerate(self.heads):
+            s.head_w1[i], s.head_b1[i] = named[f"{name}.0.weight"].data_ptr(), named[f"{name}.0.bias"].data_ptr()
+            s.head_w2[i], s.head_b2[i] = named[f"{name}.2.weight"].data_ptr(), named[f"{name}.2.bias"].data_ptr()
+        if self.normal_lr:
+            s.normal_w, s.normal_b = named["grad_from_xyz.weight"].data_ptr(), named["grad_from_xyz.bias"].data_ptr()
+        return s
+
+    def used_param_names(self):
+        names = []
+        for l in range(self.layers):
+            names += [f"fc_net.{2*l}.weight", f"fc_net.{2*l}.bias"]
+        names += ["sigma_from_xyz.0.weight", "sigma_from_xyz.0.bias", "feats_from_xyz.weight", "feats_from_xyz.bias"]
+        for name, _, _ in self.heads:
+            names += [f"{name}.0.weight", f"{name}.0.bias", f"{name}.2.weight", f"{name}.2.bias"]
+        if self.normal_lr:
+            names += ["grad_from_xyz.weight", "grad_from_xyz.bias"]
+        return names
+
+
+def make_points(xyz=None, rays=None, z=None):
+    pts = L.Points()
+    if xyz is not None:
+        pts.xyz, pts.rays, pts.z = xyz.data_ptr(), None, None
+        pts.ray_stride, pts.n_samples, pts.n_points = 0, 0, xyz.shape[0]
+    else:
+        pts.xyz, pts.rays, pts.z = None, rays.data_ptr(), z.data_ptr()
+        pts.ray_stride, pts.n_samples, pts.n_points = rays.shape[1], z.shape[1], z.shape[0] * z.shape[1]
+    return pts
+
+
+def pack_field(spec, named_params, packed=None):
+    dev = named_params["fc_net.0.weight"].device
+    if packed is None:
+        packed = torch.empty(spec.packed_bytes, dtype=torch.uint8, device=dev)
+    ps = spec.params_struct(named_params)
+    L.check(L.lib().bn_pack_field(C.byref(spec.desc), C.byref(ps), _p(packed), _stream()), "bn_pack_field")
+    return packed
+
+
+def field_sigma(spec, named_params, packed, xyz=None, rays=None, z=None):
+    """sigma-only forward, no autograd (pass 1 / sun pass)."""
+    pts = make_points(xyz, rays, z)
+    ref = xyz if xyz is not None else z
+    sigma = torch.empty(pts.n_points, dtype=torch.float32, device=ref.device)
+    ps = spec.params_struct(named_params)
+    L.check(L.lib().bn_field_sigma(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(sigma), _stream()),
+            "bn_field_sigma")
+    return sigma
+
+
+class FieldFunction(torch.autograd.Function):
+    """out[n_points][C] = field(points; params).  Differentiable w.r.t. the parameters only (the reference never
+    needs d/d xyz outside the analytic-normal path: z_vals are detached, rendering.py:262)."""
+
+    @staticmethod
+    def forward(ctx, spec, packed, xyz, rays, z, names, *params):
+        named = dict(zip(names, params))
+        pts = make_points(xyz, rays, z)
+        ref = xyz if xyz is not None else z
+        out = torch.empty(pts.n_points, spec.out_channels, dtype=torch.float32, device=ref.device)
+        need_grad = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        stash = None
+        if need_grad:
+            nbytes = L.lib().bn_field_stash_bytes(C.byref(spec.desc), pts.n_points)
+            stash = torch.empty(nbytes, dtype=torch.uint8, device=ref.device)
+        ps = spec.params_struct(named)
+        L.check(L.lib().bn_field_forward(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(out), _p(stash),
+                                         _stream()), "bn_field_forward")
+        ctx.spec, ctx.packed, ctx.names, ctx.stash = spec, packed, names, stash
+        ctx.pts_t = (xyz, rays, z)
+        ctx.save_for_backward(out, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        out, *params = ctx.saved_tensors
+        spec, names = ctx.spec, ctx.names
+        if ctx.stash is None:
+            raise RuntimeError("FieldFunction.backward without a stash (forward ran under no_grad)")
+        named = dict(zip(names, params))
+        sizes = [p.numel() for p in params]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 3) // 4 * 4
+        flat = torch.zeros(tot, dtype=torch.float32, device=out.device)
+        grads = [flat[o:o + n].view(p.shape) for o, n, p in zip(offs, sizes, params)]
+        gs = spec.params_struct(dict(zip(names, grads)))
+        ps = spec.params_struct(named)
+        xyz, rays, z = ctx.pts_t
+        pts = make_points(xyz, rays, z)
+        d_out = _f32(d_out)
+        L.check(L.lib().bn_field_backward(C.byref(spec.desc), C.byref(ps), _p(ctx.packed), C.byref(pts), _p(out),
+                                          _p(d_out), _p(ctx.stash), C.byref(gs), _stream()), "bn_field_backward")
+        ctx.stash = None
+        return (None, None, None, None, None, None) + tuple(g if p.requires_grad else None
+                                                            for g, p in zip(grads, params))
+
+
+# ----------------------------------------------------------------------------------------- compositing
+class CompositeFunction(torch.autograd.Function):
+    """(z, out[R,S,C] with sigma in channel 3, noise) -> alphas, transparency, weights, depth, acc[R,C]."""
+
+    @staticmethod
+    def forward(ctx, z, out, noise, noise_std):
+        R, S = z.shape
+        Cc = out.shape[-1] if out.dim() == 3 else 1
+        dev = z.device
+        alphas = torch.empty(R, S, dtype=torch.float32, device=dev)
+        trans = torch.empty_like(alphas)
+        weights = torch.empty_like(alphas)
+        depth = torch.empty(R, dtype=torch.float32, device=dev)
+        sigma_only = out.dim() == 2
+        acc = None if sigma_only else torch.empty(R, Cc, dtype=torch.float32, device=dev)
+        base = out.data_ptr()
+        sig_ptr = C.c_void_p(base if sigma_only else base + 3 * 4)
+        L.check(L.lib().bn_composite_forward(_p(z), sig_ptr, 1 if sigma_only else Cc, _p(noise), float(noise_std),
+                                             None if sigma_only else _p(out), Cc, 0 if sigma_only else Cc, R, S,
+                                             _p(alphas), _p(trans), _p(weights), _p(depth), _p(acc), _stream()),
+                "bn_composite_forward")
+        ctx.save_for_backward(z, out, noise)
+        ctx.noise_std, ctx.sigma_only = float(noise_std), sigma_only
+        ctx.mark_non_differentiable(alphas, trans)
+        if sigma_only:
+            return alphas, trans, weights, depth
+        return alphas, trans, weights, depth, acc
+
+    @staticmethod
+    def backward(ctx, d_alphas, d_trans, d_weights, d_depth, d_acc=None):
+        z, out, noise = ctx.saved_tensors
+        R, S = z.shape
+        sigma_only = ctx.sigma_only
+        Cc = 1 if sigma_only else out.shape[-1]
+        d_out = torch.zeros_like(out)
+        base = out.data_ptr()
+        dbase = d_out.data_ptr()
+        sig_ptr = C.c_void_p(base if sigma_only else base + 12)
+        dsig_ptr = C.c_void_p(dbase if sigma_only else dbase + 12)
+        dw = None if d_weights is None else _f32(d_weights)
+        dd = None if d_depth is None else _f32(d_depth)
+        da = None if (d_acc is None or sigma_only) else _f32(d_acc)
+        L.check(L.lib().bn_composite_backward(_p(z), sig_ptr, 1 if sigma_only else Cc, _p(noise), ctx.noise_std,
+                                              None if sigma_only else _p(out), Cc, 0 if sigma_only else Cc, R, S,
+                                              _p(dw), _p(dd), _p(da), dsig_ptr, 1 if sigma_only else Cc,
+                                              None if sigma_only else _p(d_out), Cc, _stream()),
+                "bn_composite_backward")
+        return None, d_out, None, None
+
+
+def composite(z, out, noise=None, noise_std=0.0):
+    return CompositeFunction.apply(z.contiguous(), out.contiguous(), noise, noise_std)
+
+
+# ----------------------------------------------------------------------------------------- sampling
+def stratified_z(near, far, u):
+    """near, far: (R,1) (any stride along R), u: (R,S) -> z (R,S)."""
+    R, S = u.shape
+    near, far, u = _f32(near).reshape(R), _f32(far).reshape(R), _f32(u)
+    z = torch.empty(R, S, dtype=torch.float32, device=u.device)
+    L.check(L.lib().bn_stratified_z(_p(near), _p(far), 1, _p(u), R, S, _p(z), _stream()), "bn_stratified_z")
+    return z
+
+
+def guided_samples(z, weights, depth, u, near0, far0, d_range, use_target=None, target_depth=None, target_std=None,
+                   u_target=None, target_row=None, merge=True):
+    R, S = z.shape
+    G = u.shape[1]
+    dev = z.device
+    z2 = torch.empty(R, G, dtype=torch.float32, device=dev)
+    z_all = torch.empty(R, S + G, dtype=torch.float32, device=dev) if merge else None
+    idx = torch.empty(R, S + G, dtype=torch.int64, device=dev) if merge else None
+    L.check(L.lib().bn_guided_samples(_p(z), _p(weights), _p(depth), _p(u), R, S, G, float(near0), float(far0),
+                                      float(d_range), _p(use_target), _p(target_depth), _p(target_std), _p(u_target),
+                                      _p(target_row), _p(z2), _p(z_all), _p(idx), _stream()), "bn_guided_samples")
+    return z2, z_all, idx
+
+
+# ----------------------------------------------------------------------------------------- BRDFs
+def _opt(t):
+    return None if t is None else _f32(t)
+
+
+class RPVFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, l, v, n, w, k, theta, rhoc):
+        l, v, n, w, k, theta, rhoc = [_opt(t) for t in (l, v, n, w, k, theta, rhoc)]
+        N = n.shape[0]
+        brdf = torch.empty(N, 3, dtype=torch.float32, device=n.device)
+        aux = torch.empty(N, L.BN_BRDF_AUX, dtype=torch.float32, device=n.device)
+        L.check(L.lib().bn_brdf_rpv_forward(_p(l), _p(v), _p(n), _p(w), _p(k), _p(theta), _p(rhoc), N, _p(brdf), _p(aux),
+                                            _stream()), "bn_brdf_rpv_forward")
+        ctx.save_for_backward(*[t if t is not None else torch.empty(0, device=n.device) for t in (l, v, n, w, k, theta, rhoc)])
+        ctx.has = (k is not None, theta is not None, rhoc is not None)
+        ctx.mark_non_differentiable(aux)
+        return brdf, aux
+
+    @staticmethod
+    def backward(ctx, d_brdf, _d_aux):
+        l, v, n, w, k, theta, rhoc = ctx.saved_tensors
+        hk, ht, hr = ctx.has
+        k, theta, rhoc = (k if hk else None), (theta if ht else None), (rhoc if hr else None)
+        N = n.shape[0]
+        mk = lambda on: torch.empty(N, 3, dtype=torch.float32, device=n.device) if on else None
+        d_n, d_w, d_k, d_t, d_r = mk(True), mk(True), mk(hk), mk(ht), mk(hr)
+        L.check(L.lib().bn_brdf_rpv_backward(_p(l), _p(v), _p(n), _p(w), _p(k), _p(theta), _p(rhoc), _p(_f32(d_brdf)), N,
+                                             _p(d_n), _p(d_w), _p(d_k), _p(d_t), _p(d_r), _stream()), "bn_brdf_rpv_backward")
+        return None, None, d_n, d_w, d_k, d_t, d_r
+
+
+class HapkeFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, l, v, n, w, b, c, theta, hpk_scl, shell):
+        l, v, n, w, b, c, theta = [_opt(t) for t in (l, v, n, w, b, c, theta)]
+        N = n.shape[0]
+        brdf = torch.empty(N, 3, dtype=torch.float32, device=n.device)
+        aux = torch.empty(N, L.BN_BRDF_AUX, dtype=torch.float32, device=n.device)
+        L.check(L.lib().bn_brdf_hapke_forward(_p(l), _p(v), _p(n), _p(w), _p(b), _p(c), _p(theta), float(hpk_scl), int(shell),
+                                              N, _p(brdf), _p(aux), _stream()), "bn_brdf_hapke_forward")
+        ctx.save_for_backward(*[t if t is not None else torch.empty(0, device=n.device) for t in (l, v, n, w, b, c, theta)])
+        ctx.has = (b is not None, c is not None, theta is not None)
+        ctx.hpk_scl, ctx.shell = float(hpk_scl), int(shell)
+        ctx.mark_non_differentiable(aux)
+        return brdf, aux
+
+    @staticmethod
+    def backward(ctx, d_brdf, _d_aux):
+        l, v, n, w, b, c, theta = ctx.saved_tensors
+        hb, hc, ht = ctx.has
+        b, c, theta = (b if hb else None), (c if hc else None), (theta if ht else None)
+        N = n.shape[0]
+        mk = lambda on: torch.empty(N, 3, dtype=torch.float32, device=n.device) if on else None
+        d_n, d_w, d_b, d_c = mk(True), mk(True), mk(hb), mk(hc)
+        d_t = torch.empty(N, dtype=torch.float32, device=n.device) if ht else None
+        L.check(L.lib().bn_brdf_hapke_backward(_p(l), _p(v), _p(n), _p(w), _p(b), _p(c), _p(theta), ctx.hpk_scl, ctx.shell,
+                                               _p(_f32(d_brdf)), N, _p(d_n), _p(d_w), _p(d_b), _p(d_c), _p(d_t), _stream()),
+                "bn_brdf_hapke_backward")
+        return None, None, d_n, d_w, d_b, d_c, d_t, None, None
+
+
+class MicrofacetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, l, v, n, albedo, rough, f0):
+        ctx.rough_shape = rough.shape
+        l, v, n, albedo, rough = [_f32(t) for t in (l, v, n, albedo, rough.reshape(-1))]
+        N = n.shape[0]
+        brdf = torch.empty(N, 3, dtype=torch.float32, device=n.device)
+        aux = torch.empty(N, L.BN_BRDF_AUX, dtype=torch.float32, device=n.device)
+        L.check(L.lib().bn_brdf_microfacet_forward(_p(l), _p(v), _p(n), _p(albedo), _p(rough), float(f0), N, _p(brdf), _p(aux),
+                                                   _stream()), "bn_brdf_microfacet_forward")
+        ctx.save_for_backward(l, v, n, albedo, rough)
+        ctx.f0 = float(f0)
+        ctx.mark_non_differentiable(aux)
+        return brdf, aux
+
+    @staticmethod
+    def backward(ctx, d_brdf, _d_aux):
+        l, v, n, albedo, rough = ctx.saved_tensors
+        N = n.shape[0]
+        d_n = torch.empty(N, 3, dtype=torch.float32, device=n.device)
+        d_a = torch.empty_like(d_n)
+        d_r = torch.empty(N, dtype=torch.float32, device=n.device)
+        L.check(L.lib().bn_brdf_microfacet_backward(_p(l), _p(v), _p(n), _p(albedo), _p(rough), ctx.f0, _p(_f32(d_brdf)), N,
+                                                    _p(d_n), _p(d_a), _p(d_r), _stream()), "bn_brdf_microfacet_backward")
+        return None, None, d_n, d_a, d_r.reshape(ctx.rough_shape), None
+
+
+# ----------------------------------------------------------------------------------------- optimizer
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    L.check(L.lib().bn_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr), float(betas[0]),
+                                 float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale), _stream()),
+            "bn_adam_step")

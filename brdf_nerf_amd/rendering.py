@@ -1,0 +1,217 @@
+"""Drop-in `render_rays` / `inference` / `get_z_vals` for the spsbrdf-nerf variant, running on the HIP
+library (reference: rendering.py:149-291, models/spsbrdfnerf.py:50-416).
+
+Same signatures, same result-dict keys, same RNG draw order
+(torch.rand_like (R,S) -> torch.randn (R,S) -> torch.rand (R,G) [-> torch.rand (n_valid,G)] ->
+torch.randn (R,S+G)), so a harness that monkeypatches torch.rand/rand_like/randn replays the
+reference's draws.  Documented differences: the reference's print/`check_nan` host syncs are not
+reproduced; pass 1 runs without autograd (its result is detached upstream, rendering.py:262).
+"""
+import numpy as np
+import torch
+
+from . import functions as Fn
+
+FP32_EPS = float(torch.finfo(torch.float32).eps)
+
+
+def l2_normalize(x):
+    """train_utils.py:28-33."""
+    return x / torch.sqrt(torch.clamp_min((x * x).sum(-1, keepdim=True), FP32_EPS))
+
+
+def get_z_vals(N_samples, device, near, far, use_disp=False, perturb=1.0):
+    if use_disp or perturb != 1.0:
+        raise NotImplementedError("render path always uses linear depth with perturb=1 (rendering.py:175)")
+    u = torch.rand_like(near.expand(-1, N_samples).contiguous())
+    return Fn.stratified_z(near, far, u)
+
+
+def cal_weight(z_vals, sigmas, args):
+    """models/spsbrdfnerf.py:50-69 (standalone form; `inference` uses the fused variant)."""
+    noise = torch.randn(sigmas.shape, device=sigmas.device)
+    a, T, w, d = Fn.composite(z_vals, sigmas.contiguous(), noise, args.noise_std)
+    return a, T, w, d
+
+
+def _per_ray_brdf(model, args, brdf_kind, sun_d, view, normal_s, albedo_s, s):
+    """One BRDF per ray (MultiBRDF == False).  `s` maps head name -> weighted per-ray sum."""
+    if brdf_kind == "Microfacet":
+        brdf, aux = Fn.MicrofacetFunction.apply(sun_d, view, normal_s, albedo_s, s["roughness_from_xyz"], args.fresnel_f0)
+    elif brdf_kind == "RPV":
+        rh = albedo_s if args.funcH == 2 else s.get("rhoc_from_xyz")
+        brdf, aux = Fn.RPVFunction.apply(sun_d, view, normal_s, albedo_s, s.get("k_from_xyz"), s.get("theta_rpv_from_xyz"), rh)
+    else:
+        th = s.get("theta_from_xyz")
+        brdf, aux = Fn.HapkeFunction.apply(sun_d, view, normal_s, albedo_s, s.get("b_from_xyz"), s.get("c_from_xyz"),
+                                           None if th is None else th.reshape(-1), args.hpk_scl, args.shell_hapke)
+    return brdf, aux
+
+
+def inference(model, args, rays_xyz, z_vals, rays_d=None, sun_d=None, rays_t=None, z_vals_unsort=None, apply_brdf=False,
+              print_debuginfo=False, bTestNormal=False, sun_res=[], sort_idx=None, rows=None, cols=None, percent=0,
+              mode="train", apply_theta=False, sigma_only=False, cos_irra_on=False, _rays=None, _packed=None):
+    """inference (models/spsbrdfnerf.py:71-416).  `rays_xyz` (R,S,3) may be None when `_rays` (R,>=8) is given: the
+    kernel then forms xyz = o + d*z itself (what render_rays does)."""
+    if bTestNormal:
+        raise NotImplementedError("bTestNormal needs analytic normals")
+    R, S = z_vals.shape
+    z_vals = z_vals.contiguous()
+    nr_lr = model.normal in ("analystic_learned", "learned")
+    spec = model.spec(apply_brdf and not sigma_only, apply_theta, nr_lr and not sigma_only)
+    packed = _packed if _packed is not None else model.repack(spec)
+    xyz = None if _rays is not None else rays_xyz.reshape(-1, 3).detach().float().contiguous()
+    noise = torch.randn(R, S, device=z_vals.device)   # drawn even when noise_std == 0, like the reference (:58)
+    noise_arg = noise if args.noise_std != 0 else None
+    if sigma_only:
+        with torch.no_grad():
+            sig = Fn.field_sigma(spec, model.named(), packed, xyz=xyz, rays=_rays, z=z_vals).view(R, S)
+            a, T, w, d = Fn.composite(z_vals, sig, noise_arg, args.noise_std)
+        return {"sigmas": sig.unsqueeze(-1), "depth": d, "alphas": a, "weights": w, "transparency": T,
+                "z_vals": z_vals}, "Lambertian"
+
+    out = model.evaluate(spec, packed, xyz=xyz, rays=_rays, z=None if _rays is None else z_vals).view(R, S, spec.out_channels)
+    if S == 1:
+        raise NotImplementedError("single-sample pass 2 is undefined in the reference (SURVEY quirk 4)")
+    alphas, transparency, weights, depth, acc = Fn.composite(z_vals, out, noise_arg, args.noise_std)
+    albedo, sigmas = out[..., :3], out[..., 3]
+    result = {"sigmas": sigmas.unsqueeze(-1), "albedo": albedo, "albedo_accu": acc[:, :3].clamp(0.0, 1.0), "depth": depth,
+              "alphas": alphas, "weights": weights, "transparency": transparency, "z_vals": z_vals}
+    if sort_idx is not None:
+        result["sort_idx"] = sort_idx
+    if z_vals_unsort is not None:
+        result["z_vals_unsort"] = z_vals_unsort
+    normal = normal_s = None
+    if nr_lr:
+        c0 = spec.ch_normal_lr
+        result["normal_lr"] = normal = out[..., c0:c0 + 3]
+        normal_s = l2_normalize(acc[:, c0:c0 + 3])
+        view = -rays_d
+        result["nr_vw"] = (normal_s * view).sum(-1).reshape(R, 1, 1)
+        result["nr_sun"] = (normal_s * sun_d).sum(-1).reshape(R, 1, 1)
+        result["hpk_scl"] = 1.0 / (args.hpk_scl * (result["nr_vw"] + result["nr_sun"]))
+    pad = model.rgb_padding
+    wsum = weights.sum(-1, keepdim=True)
+    albedo_s = acc[:, :3] * (1 + 2 * pad) - pad * wsum          # sum_s w (albedo (1+2p) - p)   (:270,:275)
+    irr_ray = None
+    if cos_irra_on and normal is not None:
+        irr_ray = sun_d[:, 2:3].abs()                            # upward normal (0,0,1): irradiance = |sun_z| (:260-264)
+    rgb = albedo_s if irr_ray is None else albedo_s * irr_ray
+    result["rgb"] = rgb.clamp(0.0, 1.0)
+    heads = {}
+    for (name, n_out, kind), (c0, wdt) in zip(spec.heads[1:], spec.head_cols[1:]):
+        heads[name] = out[..., c0:c0 + wdt]
+    if normal is None and not heads:
+        return result, "Lambertian"
+
+    brdf_type = "Lambertian"
+    extra = {}
+    view = -rays_d
+    irr = torch.ones_like(albedo) if irr_ray is None else irr_ray[:, None, :].expand(R, S, 3)
+    shell = getattr(args, "shell_hapke", 0)
+    kind = None
+    if model.roughness and apply_brdf:
+        kind = "Microfacet"
+    elif model.RPV and apply_brdf:
+        kind = "RPV"
+    elif (apply_brdf and args.b == True) or shell > 0:  # noqa: E712
+        kind = "Hapke"
+    if kind is not None:
+        if normal is None:
+            raise RuntimeError("BRDF shading needs a normal (--normal learned); analytic normals are not implemented")
+        brdf_type = kind
+        if model.MultiBRDF:
+            rep = lambda t: t.repeat_interleave(S, 0)
+            flat = {k: v.reshape(R * S, -1) for k, v in heads.items()}
+            brdf, aux = _per_ray_brdf(model, args, kind, rep(sun_d), rep(view), normal.reshape(-1, 3), albedo.reshape(-1, 3), flat)
+            nb = S
+        else:
+            sums = {name: acc[:, c0:c0 + wdt] for (name, _, _), (c0, wdt) in zip(spec.heads[1:], spec.head_cols[1:])}
+            brdf, aux = _per_ray_brdf(model, args, kind, sun_d, view, normal_s, albedo_s, sums)
+            nb = 1
+        if model.MultiBRDF:
+            bp = brdf.reshape(R, S, 3) * (1 + 2 * pad) - pad
+            rgb = (weights.unsqueeze(-1) * bp * irr).sum(-2)
+        else:
+            rgb = brdf if irr_ray is None else irr_ray * brdf        # irradiance of the last sample (:354)
+        if apply_brdf:
+            if kind == "Microfacet":
+                extra = {"roughness": heads["roughness_from_xyz"], "glossy": aux[:, 0].reshape(R, nb, 1),
+                         "brdf": brdf.reshape(R, nb, 3), "f": aux[:, 1].reshape(R, nb, 1), "g": aux[:, 2].reshape(R, nb, 1),
+                         "d": aux[:, 3].reshape(R, nb, 1), "l_dot_n": aux[:, 4].reshape(R, nb, 1),
+                         "v_dot_n": aux[:, 5].reshape(R, nb, 1), "halfvec": aux[:, 6:9].reshape(R, nb, 3),
+                         "n_h": aux[:, 9].reshape(R, nb, 1)}
+            elif kind == "RPV":
+                for key, name in (("rpv_k", "k_from_xyz"), ("rpv_theta", "theta_rpv_from_xyz"), ("rpv_rhoc", "rhoc_from_xyz")):
+                    if name in heads:
+                        extra[key] = heads[name]
+            else:
+                extra = {"brdf": brdf.reshape(R, nb, 3), "hpk_P": aux[:, 0:3].reshape(R, nb, 3),
+                         "hpk_Hi": aux[:, 3:6].reshape(R, nb, 3), "hpk_Hv": aux[:, 3:6].reshape(R, nb, 3),  # quirk 6
+                         "hpk_ci": aux[:, 10].reshape(R, nb, 1), "hpk_cv": aux[:, 11].reshape(R, nb, 1),
+                         "hpk_ShadFunc": aux[:, 9].reshape(R, nb, 1)}
+                for key, name in (("hpk_b", "b_from_xyz"), ("hpk_c", "c_from_xyz"), ("hpk_theta", "theta_from_xyz")):
+                    if name in heads:
+                        extra[key] = heads[name]
+    result["rgb"] = rgb.clamp(0.0, 1.0)
+    result["irradiance"] = irr
+    result.update(extra)
+    if rays_d is not None:
+        result["rays_d"] = view.reshape(R, 1, 3)
+    if sun_d is not None:
+        result["sun_d"] = sun_d.reshape(R, 1, 3)
+    return result, brdf_type
+
+
+def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_depths=None, target_std=None,
+                apply_brdf=False, print_debuginfo=False, bTestNormal=False, bTestSun_v=False, gsam_only=False, rows=None,
+                cols=None, percent=0, apply_theta=False, cos_irra_on=False):
+    """render_rays, spsbrdf-nerf branch (rendering.py:168-291)."""
+    if args.model != "spsbrdf-nerf":
+        raise ValueError("brdf_nerf_amd.render_rays serves --model spsbrdf-nerf only")
+    if args.n_importance > 0:
+        raise NotImplementedError("fine pass (n_importance > 0) is an optional extension (SURVEY.md section 8f rank 4)")
+    if bTestSun_v or rows is not None or cols is not None:
+        raise NotImplementedError("bTestSun_v / ref_sphere visualisation are out of the hot-path scope")
+    model = models["coarse"]
+    G, S = args.guided_samples, args.n_samples
+    if G <= 0:
+        raise NotImplementedError("guided_samples <= 0 returns an un-suffixed dict upstream (SURVEY quirk 1)")
+    if G == 2:
+        raise NotImplementedError("guided_samples == 2 (single mean sample) hits SURVEY quirk 4 upstream")
+    rays = rays.float().contiguous()
+    R = rays.shape[0]
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    rays_d = rays[:, 3:6]
+    sun_d = rays[:, 8:11] if args.data == "sat" else torch.ones_like(rays[:, 0:3])
+
+    nr_lr = model.normal in ("analystic_learned", "learned")
+    spec = model.spec(apply_brdf, apply_theta, nr_lr)
+    packed = model.repack(spec)
+
+    z_vals = get_z_vals(S, rays.device, near, far)
+    res1, _ = inference(model, args, None, z_vals, rays_d=rays_d, sun_d=sun_d, mode=mode, sigma_only=True, _rays=rays,
+                        _packed=packed)
+    # guided samples around the pass-1 depth (or the ground-truth depth prior in training)
+    u = torch.rand(R, G, device=rays.device)
+    use_t = tdep = tstd = u_t = trow = None
+    if mode == "train" and valid_depth is not None:
+        valid = (valid_depth > 0)
+        n_valid = int(valid.sum())            # one host sync per step; the reference does three (np.where(...cpu()))
+        if n_valid > 0:
+            u_t = torch.rand(n_valid, G, device=rays.device)
+            use_t = valid.float().contiguous()
+            tdep = target_depths[:, 0].float().contiguous()
+            tstd = target_std.float().reshape(-1).contiguous()
+            trow = (torch.cumsum(valid.int(), 0) - 1).clamp_min(0).int().contiguous()
+    with torch.no_grad():
+        z2, z_all, idx = Fn.guided_samples(z_vals, res1["weights"], res1["depth"], u, float(near[0, 0]), float(far[0, 0]),
+                                           args.std_range, use_t, tdep, tstd, u_t, trow, merge=not gsam_only)
+    if gsam_only:
+        z_unsort, z_all, idx = z2, z2, None
+    else:
+        z_unsort = torch.cat([z_vals, z2], -1)
+    result, brdf_type = inference(model, args, None, z_all, rays_d=rays_d, sun_d=sun_d, z_vals_unsort=z_unsort,
+                                  apply_brdf=apply_brdf, sun_res={}, sort_idx=idx, mode=mode, apply_theta=apply_theta,
+                                  cos_irra_on=cos_irra_on, _rays=rays, _packed=packed)
+    return {f"{k}_coarse": v for k, v in result.items()}, brdf_type
