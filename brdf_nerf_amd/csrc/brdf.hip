@@ -8,6 +8,9 @@
 // inclusive, where() passes it to the selected branch only, nan_to_num blocks it where it replaced.
 // NaN replacement values are the reference's check_nan(val_rep=...) ones.
 #include "common.h"
+// no FMA contraction: dot products and angle differences must round like the reference's separate ATen ops,
+// otherwise degenerate geometry (v == n: 0/0 -> NaN -> replacement value) takes a different branch.
+#pragma clang fp contract(off)
 
 #define PI_F 3.14159265358979323846f
 
@@ -29,8 +32,9 @@ __device__ __forceinline__ float sqrt_(float a) { return sqrtf(a); }
 __device__ __forceinline__ float abs_(float a) { return fabsf(a); }
 __device__ __forceinline__ float pow_(float a, float b) { return powf(a, b); }
 __device__ __forceinline__ float powc_(float a, float c) { return powf(a, c); }
-__device__ __forceinline__ float clamp_(float a, float lo, float hi) { return fminf(fmaxf(a, lo), hi); }
-__device__ __forceinline__ float clamp_min_(float a, float lo) { return fmaxf(a, lo); }
+// torch.clamp propagates NaN (C fmin/fmax would drop it and change which NaN-replacement branch fires)
+__device__ __forceinline__ float clamp_(float a, float lo, float hi) { return isnan(a) ? a : fminf(fmaxf(a, lo), hi); }
+__device__ __forceinline__ float clamp_min_(float a, float lo) { return isnan(a) ? a : fmaxf(a, lo); }
 __device__ __forceinline__ float nan_to(float y, float rep) { return isnan(y) ? rep : y; }
 __device__ __forceinline__ float nan_to_num_(float y) {
   return isnan(y) ? 0.f : (isinf(y) ? (y > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f) : y);
@@ -46,10 +50,13 @@ template <int N> __device__ __forceinline__ Dual<N> cst(const Dual<N> &, float c
   for (int i = 0; i < N; ++i) r.d[i] = 0.f;
   return r;
 }
+// A partial that is structurally zero (the input does not reach this value) must stay zero even when the local
+// derivative is inf/NaN (acos' at 1, 1/0 ...): reverse-mode autograd never visits such a path, 0 * inf would.
+__device__ __forceinline__ float mz(float d, float x) { return d == 0.f ? 0.f : d * x; }
 template <int N> __device__ __forceinline__ Dual<N> chain(const Dual<N> &a, float v, float dv) {
   Dual<N> r; r.v = v;
 #pragma unroll
-  for (int i = 0; i < N; ++i) r.d[i] = dv * a.d[i];
+  for (int i = 0; i < N; ++i) r.d[i] = mz(a.d[i], dv);
   return r;
 }
 template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N> &a, const Dual<N> &b) {
@@ -68,14 +75,14 @@ template <int N> __device__ __forceinline__ Dual<N> operator-(const Dual<N> &a) 
 template <int N> __device__ __forceinline__ Dual<N> operator*(const Dual<N> &a, const Dual<N> &b) {
   Dual<N> r; r.v = a.v * b.v;
 #pragma unroll
-  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+  for (int i = 0; i < N; ++i) r.d[i] = mz(a.d[i], b.v) + mz(b.d[i], a.v);
   return r;
 }
 template <int N> __device__ __forceinline__ Dual<N> operator/(const Dual<N> &a, const Dual<N> &b) {
   Dual<N> r; r.v = a.v / b.v;
   const float ib = 1.f / b.v, q = r.v * ib;   // d(a/b) = da/b - a db / b^2
 #pragma unroll
-  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * ib - q * b.d[i];
+  for (int i = 0; i < N; ++i) r.d[i] = mz(a.d[i], ib) - mz(b.d[i], q);
   return r;
 }
 template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N> &a, float c) { Dual<N> r = a; r.v += c; return r; }
@@ -120,14 +127,14 @@ template <int N> __device__ __forceinline__ Dual<N> pow_(const Dual<N> &a, const
   const float da = b.v == 0.f ? 0.f : b.v * powf(a.v, b.v - 1.f);
   const float db = (a.v == 0.f && b.v >= 0.f) ? 0.f : r.v * logf(a.v);
 #pragma unroll
-  for (int i = 0; i < N; ++i) r.d[i] = da * a.d[i] + db * b.d[i];
+  for (int i = 0; i < N; ++i) r.d[i] = mz(a.d[i], da) + mz(b.d[i], db);
   return r;
 }
 template <int N> __device__ __forceinline__ Dual<N> clamp_(const Dual<N> &a, float lo, float hi) {
-  return chain(a, fminf(fmaxf(a.v, lo), hi), (a.v >= lo && a.v <= hi) ? 1.f : 0.f);
+  return chain(a, clamp_(a.v, lo, hi), (a.v >= lo && a.v <= hi) ? 1.f : 0.f);
 }
 template <int N> __device__ __forceinline__ Dual<N> clamp_min_(const Dual<N> &a, float lo) {
-  return chain(a, fmaxf(a.v, lo), a.v >= lo ? 1.f : 0.f);
+  return chain(a, clamp_min_(a.v, lo), a.v >= lo ? 1.f : 0.f);
 }
 template <int N> __device__ __forceinline__ Dual<N> nan_to(const Dual<N> &y, const Dual<N> &rep) { return isnan(y.v) ? rep : y; }
 template <int N> __device__ __forceinline__ Dual<N> nan_to_num_(const Dual<N> &y) {

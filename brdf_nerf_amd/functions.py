@@ -124,7 +124,7 @@ class FieldFunction(torch.autograd.Function):
         pts = make_points(xyz, rays, z)
         ref = xyz if xyz is not None else z
         out = torch.empty(pts.n_points, spec.out_channels, dtype=torch.float32, device=ref.device)
-        need_grad = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        need_grad = any(ctx.needs_input_grad[6:])   # grad mode is off inside Function.forward
         stash = None
         if need_grad:
             nbytes = L.lib().bn_field_stash_bytes(C.byref(spec.desc), pts.n_points)
