@@ -74,7 +74,24 @@ _SIGS = {
     "bn_brdf_microfacet_backward": (C.c_int, [fptr] * 5 + [C.c_float, fptr, C.c_int64] + [fptr] * 4),
     "bn_adam_step": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_int32, C.c_float, fptr]),
+    "bn_prof_enable": (C.c_int, [C.c_int]),
+    "bn_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
 }
+
+PROF_NAMES = ["pack", "field_fwd_sigma", "field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad", "composite_fwd",
+              "composite_bwd", "guided_samples", "stratified_z", "adam", "brdf"]
+
+
+def prof_enable(on):
+    lib().bn_prof_enable(int(bool(on)))
+
+
+def prof_collect():
+    """-> {kernel name: (total ms, launches)} since the last collect (synchronises the recorded events)."""
+    n = len(PROF_NAMES)
+    ms, cnt = (C.c_double * n)(), (C.c_int * n)()
+    lib().bn_prof_collect(ms, cnt, n)
+    return {PROF_NAMES[i]: (ms[i], cnt[i]) for i in range(n) if cnt[i]}
 
 
 def exported_symbols():

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "brdfnerf_hip.h"
+#include "prof.h"
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

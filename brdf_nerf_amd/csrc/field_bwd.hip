@@ -48,27 +48,32 @@ __device__ __forceinline__ void bwd_head_dG(const BwdArgs &A, int p, T *ACT, con
   const int nout = A.d.head_out[hd];
   const float *w2 = A.p.head_w2[hd];
   const T *DGs = (const T *)(A.stash + A.sl.DG[p]) + (size_t)tile * BM * F;
-  T *dGs = (T *)(A.stash + A.sl.dG[p]) + (size_t)m0 * N;
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const int n = pc0 + nt * 32 + 8 * gq + 4 * h;
-      const int nl = n - hl * g.H2;
-      f32x4 w2v[3];
+    for (int gp = 0; gp < 2; ++gp) {
+      const int n0 = pc0 + nt * 32 + 16 * gp + 4 * h;
+      const int nl = n0 - hl * g.H2;
+      f32x4 wa[3], wb[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) w2v[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl) : f32x4{0, 0, 0, 0};
+      for (int c = 0; c < 3; ++c) {
+        wa[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl) : f32x4{0, 0, 0, 0};
+        wb[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl + 8) : f32x4{0, 0, 0, 0};
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m = mt * 32 + r;
         const float d0 = DPH[m * 12 + hd * 3 + 0], d1 = DPH[m * 12 + hd * 3 + 1], d2 = DPH[m * 12 + hd * 3 + 2];
-        const vec4 dg = *(const vec4 *)(DGs + native_off<MT, NTW>(wave, nt, mt, gq, lane));
-        float v[4];
+        float dg[8];
+        ld8(DGs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), dg);
+        float va[4], vb[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (d0 * w2v[0][e] + d1 * w2v[1][e] + d2 * w2v[2][e]) * (float)dg[e];
-        const vec4 o = to_vec4(T(), v[0], v[1], v[2], v[3]);
-        *(vec4 *)(ACT + (size_t)m * LDA + n) = o;
-        *(vec4 *)(dGs + (size_t)m * N + n) = o;
+        for (int e = 0; e < 4; ++e) {
+          va[e] = (d0 * wa[0][e] + d1 * wa[1][e] + d2 * wa[2][e]) * dg[e];
+          vb[e] = (d0 * wb[0][e] + d1 * wb[1][e] + d2 * wb[2][e]) * dg[4 + e];
+        }
+        *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), va[0], va[1], va[2], va[3]);
+        *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), vb[0], vb[1], vb[2], vb[3]);
       }
     }
 }
@@ -139,13 +144,13 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_bwd_kernel(const BwdArgs 
     if (g.pass_heads[p] == 2) bwd_head_dG<T, MT, NT>(A, p, ACT, DPH, m0, tile);
     else bwd_head_dG<T, MT, 1>(A, p, ACT, DPH, m0, tile);
     __syncthreads();
+    tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dG[p]) + (size_t)m0 * g.pass_N[p], g.pass_N[p], BM, g.pass_N[p]);
     const int KSp = g.pass_N[p] / 16;
     if (wave_on) gemm_seg<T, MT, NT>(acc, packed + A.pl.bwd_head[p] + (size_t)(ncol0 / 32) * KSp * 512, KSp, ACT, LDA, lane);
     __syncthreads();
   }
-  // dFeats -> LDS + stash
+  // dFeats -> LDS (+ stash below)
   if (wave_on) {
-    T *dFs = (T *)(A.stash + A.sl.dfeats) + (size_t)m0 * F;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -154,13 +159,13 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_bwd_kernel(const BwdArgs 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int m = mt * 32 + r;
-          const vec4 o = to_vec4(T(), acc[nt][mt][4 * gq], acc[nt][mt][4 * gq + 1], acc[nt][mt][4 * gq + 2], acc[nt][mt][4 * gq + 3]);
-          *(vec4 *)(ACT + (size_t)m * LDA + n) = o;
-          *(vec4 *)(dFs + (size_t)m * F + n) = o;
+          *(vec4 *)(ACT + (size_t)m * LDA + n) =
+              to_vec4(T(), acc[nt][mt][4 * gq], acc[nt][mt][4 * gq + 1], acc[nt][mt][4 * gq + 2], acc[nt][mt][4 * gq + 3]);
         }
       }
   }
   __syncthreads();
+  tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dfeats) + (size_t)m0 * F, F, BM, F);
 
   // ---------------------------------------------------------------- trunk, top layer first
   for (int l = g.L; l >= 1; --l) {
@@ -174,42 +179,42 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_bwd_kernel(const BwdArgs 
     if (wave_on) {
       const int lo = l - 1;  // layer whose pre-activation gradient is produced
       const T *Ds = (const T *)(A.stash + A.sl.D[lo]) + (size_t)tile * BM * F;
-      T *dZs = (T *)(A.stash + A.sl.dZ[lo]) + (size_t)m0 * F;
       const bool top = l == g.L, nlr = g.ch_normal_lr >= 0;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int n = ncol0 + nt * 32 + 8 * gq + 4 * h;
-          f32x4 ws = {0, 0, 0, 0}, wn0 = ws, wn1 = ws, wn2 = ws;
-          if (top) {
-            ws = *(const f32x4 *)(A.p.sigma_w + n);
-            if (nlr) { wn0 = *(const f32x4 *)(A.p.normal_w + n); wn1 = *(const f32x4 *)(A.p.normal_w + F + n); wn2 = *(const f32x4 *)(A.p.normal_w + 2 * F + n); }
-          }
+        for (int gp = 0; gp < 2; ++gp) {
+          const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const int m = mt * 32 + r;
-            const vec4 dv = *(const vec4 *)(Ds + native_off<MT, NT>(wave, nt, mt, gq, lane));
-            float v[4];
+            float dv[8], v[8];
+            ld8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dv);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * gq + e];
-            if (top) {
-              const float ds = DPT[m * 4];
+            for (int e = 0; e < 8; ++e) v[e] = acc[nt][mt][8 * gp + e];
+            if (top) {  // rank-1 terms of the sigma head and the learned-normal head
+              const float ds = DPT[m * 4], a0 = DPT[m * 4 + 1], a1 = DPT[m * 4 + 2], a2 = DPT[m * 4 + 3];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += ws[e] * ds;
-              if (nlr) {
-                const float a0 = DPT[m * 4 + 1], a1 = DPT[m * 4 + 2], a2 = DPT[m * 4 + 3];
+              for (int half = 0; half < 2; ++half) {
+                const int n = n0 + 8 * half;
+                const f32x4 ws = *(const f32x4 *)(A.p.sigma_w + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += wn0[e] * a0 + wn1[e] * a1 + wn2[e] * a2;
+                for (int e = 0; e < 4; ++e) v[4 * half + e] += ws[e] * ds;
+                if (nlr) {
+                  const f32x4 wn0 = *(const f32x4 *)(A.p.normal_w + n), wn1 = *(const f32x4 *)(A.p.normal_w + F + n),
+                              wn2 = *(const f32x4 *)(A.p.normal_w + 2 * F + n);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[4 * half + e] += wn0[e] * a0 + wn1[e] * a1 + wn2[e] * a2;
+                }
               }
             }
-            const vec4 o = to_vec4(T(), v[0] * (float)dv[0], v[1] * (float)dv[1], v[2] * (float)dv[2], v[3] * (float)dv[3]);
-            *(vec4 *)(ACT + (size_t)m * LDA + n) = o;
-            *(vec4 *)(dZs + (size_t)m * F + n) = o;
+            *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), v[0] * dv[0], v[1] * dv[1], v[2] * dv[2], v[3] * dv[3]);
+            *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), v[4] * dv[4], v[5] * dv[5], v[6] * dv[6], v[7] * dv[7]);
           }
         }
     }
     __syncthreads();
+    tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dZ[l - 1]) + (size_t)m0 * F, F, BM, F);
   }
 }
 
@@ -401,6 +406,7 @@ template <typename T, int MT, int NT> static int launch_bwd(const BwdArgs &a, in
     }
     configured = lds;
   }
+  BnProfScope prof_(BN_K_BWD_CHAIN, st);
   field_bwd_kernel<T, MT, NT><<<dim3((unsigned)tiles), BN_THREADS, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_bwd");
   return 0;
@@ -462,6 +468,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   w.m_per_block = (int)mpb;
   if (w.n_jobs > 0) {
     dim3 grid((unsigned)w.tile0[w.n_jobs], (unsigned)ceil_div64(sl.Mpad, mpb));
+    BnProfScope prof_(BN_K_WGRAD, st);
     if (bf) wgrad_kernel<bf16><<<grid, 256, 0, st>>>(w);
     else wgrad_kernel<float><<<grid, 256, 0, st>>>(w);
     BN_LAUNCH_CHECK("wgrad");
@@ -494,6 +501,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     if (smpb < 64) smpb = 64;
     s.m_per_block = (int)smpb;
     dim3 grid((unsigned)ceil_div64(sl.Mpad, smpb), (unsigned)s.n_jobs);
+    BnProfScope prof_(BN_K_SKINNY, st);
     if (bf) skinny_wgrad_kernel<bf16><<<grid, 256, 0, st>>>(s);
     else skinny_wgrad_kernel<float><<<grid, 256, 0, st>>>(s);
     BN_LAUNCH_CHECK("skinny_wgrad");

@@ -17,6 +17,16 @@ struct FwdArgs {
   int sigma_only;
 };
 
+template <bool FAST> __device__ __forceinline__ void act_eval(int act, float z, float w0, float &y, float &d) {
+  if (act == BN_ACT_SIN) {
+    float s, c;
+    sincos_t<FAST>(w0 * z, s, c);
+    y = s; d = w0 * c;
+  } else {
+    y = z > 0.f ? z : 0.f; d = z > 0.f ? 1.f : 0.f;
+  }
+}
+
 // One pass over up to two heads: hidden = act(W1 feats + b1) kept in registers, second layer (<= 3 outputs)
 // as per-lane partial dots reduced through LDS.  NTW = 32-column tiles per wave in this pass.
 template <typename T, int MT, int NTW>
@@ -49,38 +59,36 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int n = pc0 + nt * 32 + 8 * gq + 4 * h;   // column in the pass
-        const int nl = n - hl * g.H2;                   // column inside the head
-        const f32x4 b4 = *(const f32x4 *)(b1 + nl);
-        f32x4 w2v[3];
+      for (int gp = 0; gp < 2; ++gp) {
+        const int n0 = pc0 + nt * 32 + 16 * gp + 4 * h;   // column in the pass of the first run (second: +8)
+        const int nl = n0 - hl * g.H2;                     // column inside the head
+        const f32x4 ba = *(const f32x4 *)(b1 + nl), bb = *(const f32x4 *)(b1 + nl + 8);
+        f32x4 wa[3], wb[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) w2v[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl) : f32x4{0, 0, 0, 0};
+        for (int c = 0; c < 3; ++c) {
+          wa[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl) : f32x4{0, 0, 0, 0};
+          wb[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl + 8) : f32x4{0, 0, 0, 0};
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          float y[4], dd[4];
+          float y[8], dd[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float zz = acc[nt][mt][4 * gq + e] + b4[e];
-            if (g.act == BN_ACT_SIN) {
-              float s, c;
-              sincos_t<FAST>(zz, s, c);
-              y[e] = s; dd[e] = c;
-            } else {
-              y[e] = zz > 0.f ? zz : 0.f; dd[e] = zz > 0.f ? 1.f : 0.f;
-            }
+            act_eval<FAST>(g.act, acc[nt][mt][8 * gp + e] + ba[e], 1.f, y[e], dd[e]);
+            act_eval<FAST>(g.act, acc[nt][mt][8 * gp + 4 + e] + bb[e], 1.f, y[4 + e], dd[4 + e]);
           }
-          const vec4 yv = to_vec4(T(), y[0], y[1], y[2], y[3]);
+          const vec4 ya = to_vec4(T(), y[0], y[1], y[2], y[3]), yb = to_vec4(T(), y[4], y[5], y[6], y[7]);
           if (keep) {
             const int m = mt * 32 + r;
-            *(vec4 *)(Gs + (size_t)m * N + n) = yv;
-            *(vec4 *)(DGs + native_off<MT, NTW>(wave, nt, mt, gq, lane)) = to_vec4(T(), dd[0], dd[1], dd[2], dd[3]);
+            *(vec4 *)(Gs + (size_t)m * N + n0) = ya;
+            *(vec4 *)(Gs + (size_t)m * N + n0 + 8) = yb;
+            st8(DGs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), dd);
           }
           // the second layer sees the stored (rounded) hidden value: fwd and bwd stay consistent
 #pragma unroll
           for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) part[mt][c] += (float)yv[e] * w2v[c][e];
+            for (int e = 0; e < 4; ++e) part[mt][c] += (float)ya[e] * wa[c][e] + (float)yb[e] * wb[c][e];
         }
       }
 #pragma unroll
@@ -179,15 +187,7 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
     }
   }
   __syncthreads();
-  if (keep) {  // PE rows -> stash (row-major [Mpad][KP]), 16-byte chunks
-    T *dst = (T *)(A.stash + A.sl.pe) + (size_t)m0 * KP;
-    constexpr int EPC = 16 / sizeof(T);
-    const int cpr = KP / EPC;
-    for (int c = tid; c < BM * cpr; c += BN_THREADS) {
-      const int m = c / cpr, cc = c % cpr;
-      *(uint4 *)(dst + (size_t)m * KP + cc * EPC) = *(const uint4 *)(PE + (size_t)m * LDP + cc * EPC);
-    }
-  }
+  if (keep) tile_to_global<T>(PE, LDP, (T *)(A.stash + A.sl.pe) + (size_t)m0 * KP, KP, BM, KP);
 
   const int ncol0 = wave * 32 * NT;        // first feature of this wave in F-wide phases
   const bool wave_on = ncol0 < F;
@@ -212,39 +212,30 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
     if (wave_on) {
       const float w0 = (l == 0) ? 30.f : 1.f;
       const float *bias = A.p.trunk_b[l];
-      T *Ys = keep ? (T *)(A.stash + A.sl.Y[l]) + (size_t)m0 * F : nullptr;
       T *Ds = keep ? (T *)(A.stash + A.sl.D[l]) + (size_t)tile * BM * F : nullptr;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int n = ncol0 + nt * 32 + 8 * gq + 4 * h;
-          const f32x4 b4 = *(const f32x4 *)(bias + n);
+        for (int gp = 0; gp < 2; ++gp) {
+          const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
+          const f32x4 ba = *(const f32x4 *)(bias + n0), bb = *(const f32x4 *)(bias + n0 + 8);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            float y[4], dd[4];
+            float y[8], dd[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float zz = acc[nt][mt][4 * gq + e] + b4[e];
-              if (g.act == BN_ACT_SIN) {
-                float s, c;
-                sincos_t<FAST>(w0 * zz, s, c);
-                y[e] = s; dd[e] = w0 * c;
-              } else {
-                y[e] = zz > 0.f ? zz : 0.f; dd[e] = zz > 0.f ? 1.f : 0.f;
-              }
+              act_eval<FAST>(g.act, acc[nt][mt][8 * gp + e] + ba[e], w0, y[e], dd[e]);
+              act_eval<FAST>(g.act, acc[nt][mt][8 * gp + 4 + e] + bb[e], w0, y[4 + e], dd[4 + e]);
             }
             const int m = mt * 32 + r;
-            const vec4 yv = to_vec4(T(), y[0], y[1], y[2], y[3]);
-            *(vec4 *)(ACT + (size_t)m * LDA + n) = yv;
-            if (keep) {
-              *(vec4 *)(Ys + (size_t)m * F + n) = yv;
-              *(vec4 *)(Ds + native_off<MT, NT>(wave, nt, mt, gq, lane)) = to_vec4(T(), dd[0], dd[1], dd[2], dd[3]);
-            }
+            *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), y[0], y[1], y[2], y[3]);
+            *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), y[4], y[5], y[6], y[7]);
+            if (keep) st8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dd);
           }
         }
     }
     __syncthreads();
+    if (keep) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[l]) + (size_t)m0 * F, F, BM, F);
   }
 
   // ---------------------------------------------------------------- sigma (+ learned normal): VALU dots over h8
@@ -301,7 +292,6 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
   if (wave_on) gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_feats + (size_t)(ncol0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
   __syncthreads();
   if (wave_on) {
-    T *Fs = keep ? (T *)(A.stash + A.sl.feats) + (size_t)m0 * F : nullptr;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -311,14 +301,13 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int m = mt * 32 + r;
-          const vec4 yv = to_vec4(T(), acc[nt][mt][4 * gq + 0] + b4[0], acc[nt][mt][4 * gq + 1] + b4[1],
-                                  acc[nt][mt][4 * gq + 2] + b4[2], acc[nt][mt][4 * gq + 3] + b4[3]);
-          *(vec4 *)(ACT + (size_t)m * LDA + n) = yv;
-          if (keep) *(vec4 *)(Fs + (size_t)m * F + n) = yv;
+          *(vec4 *)(ACT + (size_t)m * LDA + n) = to_vec4(T(), acc[nt][mt][4 * gq + 0] + b4[0], acc[nt][mt][4 * gq + 1] + b4[1],
+                                                         acc[nt][mt][4 * gq + 2] + b4[2], acc[nt][mt][4 * gq + 3] + b4[3]);
         }
       }
   }
   __syncthreads();
+  if (keep) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.feats) + (size_t)m0 * F, F, BM, F);
 
   // ---------------------------------------------------------------- two-layer sigmoid heads, up to 2 per pass
   for (int p = 0; p < g.n_pass; ++p) {
@@ -401,9 +390,12 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
   const int F = g.F, P0 = g.P;
   for (int l = 0; l < g.L; ++l) {
     BN_REQUIRE(P->trunk_w[l] && P->trunk_b[l], "pack: trunk layer %d missing", l);
-    if (l == 0) add(P->trunk_w[l], pl.fwd_trunk[l][0], P0, F, P0, 0, 0, 0);
-    else if (l == g.skip) {
+    if (l == 0) {
+      add(P->trunk_w[l], pl.fwd_trunk[l][0], P0, F, P0, 0, 0, 0);
+      a.job[a.n_jobs - 1].K_pad = g.KP;                 // the PE operand is padded to 4 MFMA k-steps
+    } else if (l == g.skip) {
       add(P->trunk_w[l], pl.fwd_trunk[l][0], F + P0, F, P0, 0, 0, 0);
+      a.job[a.n_jobs - 1].K_pad = g.KP;
       add(P->trunk_w[l], pl.fwd_trunk[l][1], F + P0, F, F, 0, P0, 0);
     } else add(P->trunk_w[l], pl.fwd_trunk[l][0], F, F, F, 0, 0, 0);
     if (l >= 1) {  // W_l^T over the h inputs: packed[row j][k n] = W[n][j (+P0 at the skip layer)]
@@ -431,6 +423,7 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
     }
   BN_REQUIRE(a.n_jobs <= BN_MAX_PACK_JOBS, "pack: too many jobs");
   dim3 grid(64, a.n_jobs);
+  BnProfScope prof_(BN_K_PACK, (hipStream_t)stream);
   if (desc->dtype == BN_BF16) pack_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   else pack_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   BN_LAUNCH_CHECK("bn_pack_field");
@@ -451,6 +444,7 @@ template <typename T, int MT, int NT> static int launch_fwd(const FwdArgs &a, in
     }
     configured = lds;
   }
+  BnProfScope prof_(a.sigma_only ? BN_K_FWD_SIGMA : BN_K_FWD_FULL, st);
   field_fwd_kernel<T, MT, NT><<<dim3((unsigned)tiles), BN_THREADS, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_fwd");
   return 0;
@@ -460,7 +454,7 @@ int bn_field_forward_impl(const bn_field_desc *desc, const bn_field_params *para
                           const bn_points *pts, float *out, void *stash, int sigma_only, void *stream) {
   FwdArgs a;
   if (int e = bn_make_geom(desc, &a.g)) return e;
-  BN_REQUIRE(!desc->normal_an, "field_forward: analytic normals are evaluated by bn_field_sigma_grad");
+  BN_REQUIRE(!desc->normal_an, "field_forward: analytic normals are not implemented by this entry point");
   BN_REQUIRE(pts && pts->n_points > 0 && (pts->xyz || (pts->rays && pts->z && pts->n_samples > 0)), "field: bad points");
   BN_REQUIRE(packed && out, "field: null buffer");
   a.d = *desc; a.p = *params; a.packed = packed; a.pts = *pts; a.out = out; a.stash = (char *)stash;

@@ -75,7 +75,41 @@ template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x16 (&acc
       for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
 }
 
-// Offset (elements) of the 4-element run (nt, mt, g) of this lane in a "native" stash image of one tile.
-template <int MT, int NTW> __device__ __forceinline__ size_t native_off(int wave, int nt, int mt, int g, int lane) {
-  return ((((size_t)(wave * NTW + nt) * MT + mt) * 4 + g) * 64 + lane) * 4;
+// Offset (elements) of the 8-element chunk (nt, mt, gp) of this lane in a "native" stash image of one tile:
+// chunk gp holds accumulator registers 8*gp .. 8*gp+7 (feature runs 16*gp + 4h + {0..3} and 16*gp + 8 + 4h + {0..3}).
+// One wave instruction moves 64 lanes x 16 B (bf16) fully coalesced.
+template <int MT, int NTW> __device__ __forceinline__ size_t native_off8(int wave, int nt, int mt, int gp, int lane) {
+  return ((((size_t)(wave * NTW + nt) * MT + mt) * 2 + gp) * 64 + lane) * 8;
+}
+__device__ __forceinline__ void st8(bf16 *p, const float (&v)[8]) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
+  *(bf16x8 *)p = o;
+}
+__device__ __forceinline__ void st8(float *p, const float (&v)[8]) {
+  *(f32x4 *)p = f32x4{v[0], v[1], v[2], v[3]};
+  *(f32x4 *)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void ld8(const bf16 *p, float (&v)[8]) {
+  const bf16x8 o = *(const bf16x8 *)p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)o[i];
+}
+__device__ __forceinline__ void ld8(const float *p, float (&v)[8]) {
+  const f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+
+// Copy the workgroup's LDS tile [rows][width] (row stride ld) to a row-major global array [rows][gld] in 16-byte
+// chunks: every wave instruction writes 1 KB of consecutive bytes (full 128-B lines) instead of the 32 x 16 B
+// fragments the accumulator layout would give.
+template <typename T> __device__ __forceinline__ void tile_to_global(const T *lds, int ld, T *g, int gld, int rows, int width) {
+  constexpr int EPC = 16 / sizeof(T);
+  const int cpr = width / EPC;
+  for (int c = threadIdx.x; c < rows * cpr; c += BN_THREADS) {
+    const int row = c / cpr, cc = (c % cpr) * EPC;
+    *(uint4 *)(g + (size_t)row * gld + cc) = *(const uint4 *)(lds + (size_t)row * ld + cc);
+  }
 }

@@ -38,6 +38,7 @@ extern "C" int bn_adam_step(float *param, const float *grad, float *exp_avg, flo
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
   const int64_t blocks = ceil_div64(ceil_div64(n, 4), 256);
+  BnProfScope prof_(BN_K_ADAM, (hipStream_t)stream);
   adam_kernel<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), 256, 0, (hipStream_t)stream>>>(
       param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
   BN_LAUNCH_CHECK("adam_step");

@@ -43,6 +43,7 @@ extern "C" int bn_stratified_z(const float *near, const float *far, int64_t nf_s
                                int32_t S, float *z, void *stream) {
   BN_REQUIRE(near && far && u && z && R > 0 && S >= 2, "stratified_z: bad arguments");
   const int64_t n = R * S;
+  BnProfScope prof_(BN_K_STRATIFIED, (hipStream_t)stream);
   stratified_z_kernel<<<dim3((unsigned)ceil_div64(n, 256)), 256, 0, (hipStream_t)stream>>>(near, far, nf_stride, u, R, S, z);
   BN_LAUNCH_CHECK("stratified_z");
   return 0;
@@ -201,6 +202,7 @@ extern "C" int bn_composite_forward(const float *z, const float *sigma, int64_t 
   a.z = z; a.sigma = sigma; a.noise = noise; a.chan = chan; a.sigma_stride = sigma_stride; a.chan_stride = chan_stride;
   a.noise_std = noise_std; a.C = C; a.S = S; a.R = R;
   a.alphas = alphas; a.trans = trans; a.weights = weights; a.depth = depth; a.acc = acc;
+  BnProfScope prof_(BN_K_COMPOSITE_FWD, (hipStream_t)stream);
   composite_kernel<false><<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
   BN_LAUNCH_CHECK("composite_forward");
   return 0;
@@ -218,6 +220,7 @@ extern "C" int bn_composite_backward(const float *z, const float *sigma, int64_t
   a.noise_std = noise_std; a.C = C; a.S = S; a.R = R;
   a.d_weights = d_weights; a.d_depth = d_depth; a.d_acc = d_acc; a.d_sigma = d_sigma; a.d_chan = d_chan;
   a.d_sigma_stride = d_sigma_stride; a.d_chan_stride = d_chan_stride;
+  BnProfScope prof_(BN_K_COMPOSITE_BWD, (hipStream_t)stream);
   composite_kernel<true><<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
   BN_LAUNCH_CHECK("composite_backward");
   return 0;
@@ -386,6 +389,7 @@ extern "C" int bn_guided_samples(const float *z, const float *weights, const flo
   BN_REQUIRE(!use_target || (target_depth && target_std && u_target && target_row), "guided_samples: target arrays");
   GuidedArgs a = {z, weights, depth, u, use_target, target_depth, target_std, u_target, target_row, R, S, G,
                   near0, far0, d_range, z2_sorted, z_all, sort_idx};
+  BnProfScope prof_(BN_K_GUIDED, (hipStream_t)stream);
   guided_kernel<<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
   BN_LAUNCH_CHECK("guided_samples");
   return 0;

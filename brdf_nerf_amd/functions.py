@@ -217,6 +217,54 @@ def composite(z, out, noise=None, noise_std=0.0):
     return CompositeFunction.apply(z.contiguous(), out.contiguous(), noise, noise_std)
 
 
+def composite_forward_raw(z, out, noise=None, noise_std=0.0, bufs=None):
+    """No-autograd compositing of out[R,S,C] (sigma = channel 3): -> alphas, trans, weights, depth, acc.
+    `bufs` (optional dict) supplies preallocated outputs so a training loop does not hit the allocator."""
+    R, S = z.shape
+    Cc = out.shape[-1]
+    dev = z.device
+    b = bufs if bufs is not None else {}
+    mk = lambda k, shape: b.get(k) if k in b else torch.empty(shape, dtype=torch.float32, device=dev)
+    alphas, trans, weights = mk("alphas", (R, S)), mk("trans", (R, S)), mk("weights", (R, S))
+    depth, acc = mk("depth", (R,)), mk("acc", (R, Cc))
+    L.check(L.lib().bn_composite_forward(_p(z), C.c_void_p(out.data_ptr() + 12), Cc, _p(noise), float(noise_std), _p(out), Cc,
+                                         Cc, R, S, _p(alphas), _p(trans), _p(weights), _p(depth), _p(acc), _stream()),
+            "bn_composite_forward")
+    return alphas, trans, weights, depth, acc
+
+
+def composite_backward_raw(z, out, d_weights, d_depth, d_acc, noise=None, noise_std=0.0, d_out=None):
+    """-> d_out[R,S,C].  Channel 3 of d_out receives d sigma; d_acc[:, 3] must be zero (acc[:, 3] is not an output)."""
+    R, S = z.shape
+    Cc = out.shape[-1]
+    if d_out is None:
+        d_out = torch.empty_like(out)
+    L.check(L.lib().bn_composite_backward(_p(z), C.c_void_p(out.data_ptr() + 12), Cc, _p(noise), float(noise_std), _p(out), Cc,
+                                          Cc, R, S, _p(d_weights), _p(d_depth), _p(d_acc),
+                                          C.c_void_p(d_out.data_ptr() + 12), Cc, _p(d_out), Cc, _stream()),
+            "bn_composite_backward")
+    return d_out
+
+
+def field_forward_raw(spec, named_params, packed, out, stash, xyz=None, rays=None, z=None):
+    pts = make_points(xyz, rays, z)
+    ps = spec.params_struct(named_params)
+    L.check(L.lib().bn_field_forward(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(out), _p(stash), _stream()),
+            "bn_field_forward")
+    return out
+
+
+def field_backward_raw(spec, named_params, named_grads, packed, out, d_out, stash, xyz=None, rays=None, z=None):
+    pts = make_points(xyz, rays, z)
+    ps, gs = spec.params_struct(named_params), spec.params_struct(named_grads)
+    L.check(L.lib().bn_field_backward(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(out), _p(d_out), _p(stash),
+                                      C.byref(gs), _stream()), "bn_field_backward")
+
+
+def field_stash_bytes(spec, n_points):
+    return L.lib().bn_field_stash_bytes(C.byref(spec.desc), int(n_points))
+
+
 # ----------------------------------------------------------------------------------------- sampling
 def stratified_z(near, far, u):
     """near, far: (R,1) (any stride along R), u: (R,S) -> z (R,S)."""

@@ -74,6 +74,15 @@ def inference(model, args, rays_xyz, z_vals, rays_d=None, sun_d=None, rays_t=Non
     if S == 1:
         raise NotImplementedError("single-sample pass 2 is undefined in the reference (SURVEY quirk 4)")
     alphas, transparency, weights, depth, acc = Fn.composite(z_vals, out, noise_arg, args.noise_std)
+    return shade(model, args, spec, out, z_vals, alphas, transparency, weights, depth, acc, rays_d, sun_d, apply_brdf,
+                 cos_irra_on, sort_idx, z_vals_unsort)
+
+
+def shade(model, args, spec, out, z_vals, alphas, transparency, weights, depth, acc, rays_d, sun_d, apply_brdf,
+          cos_irra_on, sort_idx=None, z_vals_unsort=None):
+    """Ray-level part of inference() (models/spsbrdfnerf.py:198-416) from the composited sums `acc` = sum_s w * out."""
+    R, S = z_vals.shape
+    nr_lr = spec.normal_lr
     albedo, sigmas = out[..., :3], out[..., 3]
     result = {"sigmas": sigmas.unsqueeze(-1), "albedo": albedo, "albedo_accu": acc[:, :3].clamp(0.0, 1.0), "depth": depth,
               "alphas": alphas, "weights": weights, "transparency": transparency, "z_vals": z_vals}

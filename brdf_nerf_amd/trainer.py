@@ -1,0 +1,142 @@
+"""Fused training step for spsbrdf-nerf on one GPU per process (reference: NeRF_pl.training_step, main.py:194-353,
++ Adam, main.py:147-168, + Lightning DDP's gradient all-reduce, main.py:720-731).
+
+One step = render_rays (pass 1 sigma-only, depth-guided resampling, pass 2) + SNerfLoss [+ DepthLoss] + backward +
+[RCCL all-reduce of ONE flat fp32 gradient buffer] + Adam.  Everything numerical runs in the HIP library; torch
+autograd is used only for the per-ray loss glue ((R,3)/(R,) tensors).  Parameters live in one flat buffer (the
+nn.Parameters of the drop-in module are views into it, state_dict keys unchanged), so the optimizer and the
+collective are single launches over ~10 MB.
+"""
+import torch
+
+from . import functions as Fn
+from . import losses
+from .rendering import shade
+
+
+class FusedTrainer:
+    def __init__(self, model, args, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lambda_rgb=1.0, ds_lambda=0.0,
+                 usealldepth=False, process_group=None, strict_rng=True):
+        self.model, self.args = model, args
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.lambda_rgb, self.ds_lambda, self.usealldepth = lambda_rgb, ds_lambda, usealldepth
+        self.pg, self.strict_rng = process_group, strict_rng
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.nr_lr = model.normal in ("analystic_learned", "learned")
+        self._flatten()
+        self.steps_a = self.steps_b = 0
+        self._bufs = {}
+
+    # ------------------------------------------------------------------ flat parameter / gradient storage
+    def _flatten(self):
+        model = self.model
+        named = dict(model.named_parameters())
+        base = set(model.spec(False, False, self.nr_lr).used_param_names())
+        order = [n for n in named if n in base] + [n for n in named if n not in base]
+        offs, tot = {}, 0
+        for n in order:
+            offs[n] = tot
+            tot += (named[n].numel() + 3) // 4 * 4
+            if n in base:
+                self.n_base = tot
+        dev = next(model.parameters()).device
+        self.flat_param = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros_like(self.flat_param)
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        self.grad_views = {}
+        with torch.no_grad():
+            for n in order:
+                p, o = named[n], offs[n]
+                view = self.flat_param[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view                     # the module's parameters now alias the flat buffer
+                self.grad_views[n] = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def _buf(self, key, shape, dtype=torch.float32):
+        b = self._bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
+            b = torch.empty(shape, dtype=dtype, device=self.flat_param.device)
+            self._bufs[key] = b
+        return b
+
+    # ------------------------------------------------------------------ one step
+    def step(self, rays, rgbs, valid_depth=None, depths=None, depth_std=None, apply_brdf=False, apply_theta=False,
+             cos_irra_on=False, depth_loss_on=True, near_far=None):
+        model, args = self.model, self.args
+        S, G = args.n_samples, args.guided_samples
+        R = rays.shape[0]
+        dev = rays.device
+        spec = model.spec(apply_brdf, apply_theta, self.nr_lr)
+        named = model.named()
+        packed = model.repack(spec)
+        near, far = rays[:, 6:7], rays[:, 7:8]
+        rays_d = rays[:, 3:6]
+        sun_d = rays[:, 8:11] if args.data == "sat" else torch.ones_like(rays[:, 0:3])
+        need_noise = self.strict_rng or args.noise_std != 0
+        with torch.no_grad():
+            # pass 1: sigma only, no stash
+            z = Fn.stratified_z(near, far, torch.rand(R, S, device=dev))
+            noise1 = torch.randn(R, S, device=dev) if need_noise else None
+            sig = Fn.field_sigma(spec, named, packed, rays=rays, z=z).view(R, S)
+            _, _, w1, d1 = Fn.composite(z, sig, noise1 if args.noise_std != 0 else None, args.noise_std)
+            # depth-guided resampling + merge
+            u = torch.rand(R, G, device=dev)
+            use_t = tdep = tstd = u_t = trow = None
+            if valid_depth is not None:
+                valid = valid_depth > 0
+                # the reference draws rand(n_valid, G); a (R, G) draw indexed by the valid-row rank is the same
+                # distribution and needs no host sync
+                u_t = torch.rand(R, G, device=dev)
+                use_t = valid.float().contiguous()
+                tdep = depths[:, 0].float().contiguous()
+                tstd = depth_std.float().reshape(-1).contiguous()
+                trow = (torch.cumsum(valid.int(), 0) - 1).clamp_min(0).int().contiguous()
+            # the clamp window is the FIRST ray's (near, far) (rendering.py:133); satellite batches share one pair, so
+            # callers pass it to avoid a device->host read per step
+            near0, far0 = near_far if near_far is not None else (float(rays[0, 6]), float(rays[0, 7]))
+            _, z_all, _ = Fn.guided_samples(z, w1, d1, u, near0, far0, args.std_range, use_t, tdep, tstd, u_t, trow)
+            S2 = S + G
+            noise2 = torch.randn(R, S2, device=dev) if need_noise else None
+            noise2 = noise2 if args.noise_std != 0 else None
+            # pass 2: full field with activation stash
+            out = self._buf("out", (R * S2, spec.out_channels))
+            stash = self._buf("stash", (Fn.field_stash_bytes(spec, R * S2),), torch.uint8)
+            Fn.field_forward_raw(spec, named, packed, out, stash, rays=rays, z=z_all)
+            out3 = out.view(R, S2, spec.out_channels)
+            alphas, trans, weights, depth, acc = Fn.composite_forward_raw(z_all, out3, noise2, args.noise_std)
+        # ray-level loss glue under autograd (leaves: acc, depth, weights)
+        acc_l, depth_l, weights_l = acc.requires_grad_(True), depth.requires_grad_(True), weights.requires_grad_(True)
+        res, _ = shade(model, args, spec, out3, z_all, alphas, trans, weights_l, depth_l, acc_l, rays_d, sun_d, apply_brdf,
+                       cos_irra_on)
+        loss = losses.snerf_loss(res["rgb"], rgbs, self.lambda_rgb)
+        if self.ds_lambda > 0 and depth_loss_on and valid_depth is not None:
+            loss = loss + losses.depth_loss(z_all, depth_l, weights_l, depths[:, 0], depths[:, 1], valid_depth, depth_std,
+                                            self.ds_lambda, self.usealldepth)
+        d_acc, d_depth, d_weights = torch.autograd.grad(loss, [acc_l, depth_l, weights_l], allow_unused=True)
+        with torch.no_grad():
+            if d_acc is not None:
+                d_acc = d_acc.contiguous()
+                d_acc[:, 3] = 0
+            d_out = Fn.composite_backward_raw(z_all, out3, None if d_weights is None else d_weights.contiguous(),
+                                              None if d_depth is None else d_depth.contiguous(), d_acc, noise2, args.noise_std,
+                                              self._buf("d_out", tuple(out3.shape)))
+            self.flat_grad.zero_()
+            Fn.field_backward_raw(spec, named, self.grad_views, packed, out, d_out.view(R * S2, -1), stash, rays=rays, z=z_all)
+            if self.world > 1:
+                torch.distributed.all_reduce(self.flat_grad, group=self.pg)   # RCCL over xGMI: one ~10 MB buffer
+            self._adam(apply_brdf)
+        return loss.detach(), res["rgb"].detach()
+
+    def _adam(self, apply_brdf):
+        scale = 1.0 / self.world          # DDP averages gradients
+        nb = self.n_base
+        self.steps_a += 1
+        Fn.adam_step(self.flat_param[:nb], self.flat_grad[:nb], self.exp_avg[:nb], self.exp_avg_sq[:nb], self.steps_a, self.lr,
+                     self.betas, self.eps, self.wd, scale)
+        if apply_brdf and self.flat_param.numel() > nb:
+            self.steps_b += 1
+            Fn.adam_step(self.flat_param[nb:], self.flat_grad[nb:], self.exp_avg[nb:], self.exp_avg_sq[nb:], self.steps_b,
+                         self.lr, self.betas, self.eps, self.wd, scale)

@@ -194,6 +194,18 @@ int bn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
                  float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
                  void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Measurement hooks (no reference counterpart; the reference only has Lightning's wall-clock
+ * "simple" profiler, main.py:731).  When enabled, every kernel launch of this library is
+ * bracketed by HIP events on the caller's stream; bn_prof_collect() synchronises them, adds the
+ * durations per kernel id (order below) and clears the log.
+ * ids: 0 pack, 1 field_fwd(sigma only), 2 field_fwd(full), 3 field_bwd chain, 4 wgrad, 5 skinny
+ * wgrad, 6 composite fwd, 7 composite bwd, 8 guided samples, 9 stratified z, 10 adam, 11 brdf.
+ * ------------------------------------------------------------------------------------------- */
+#define BN_PROF_IDS 12
+int bn_prof_enable(int on);
+int bn_prof_collect(double *ms_sum, int *count, int n_ids);
+
 #ifdef __cplusplus
 }
 #endif
