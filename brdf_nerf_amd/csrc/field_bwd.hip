@@ -352,6 +352,116 @@ template <typename T> __global__ __launch_bounds__(256) void wgrad_kernel(const 
   if (do_bias && n0 + tid < J.N) atomicAdd(J.bias + n0 + tid, bsum);
 }
 
+// ---- bf16 throughput variant: 256(n) x 256(k) output tile per 8-wave workgroup, 32-point stages double-buffered in
+// LDS (one barrier per stage; the next stage's global loads are in flight during the MFMAs), transposing
+// ds_read_b64_tr_b16 fragment reads.  Each wave owns 64(n) x 128(k): 2 x 4 accumulator tiles.  Blocks that share an
+// (job, point-split) - i.e. the same A rows - get consecutive ids on ONE XCD so the second read of a tile hits L2.
+#define W2_LD (256 + 32)       // 576-byte rows: the 4 rows of a tr-read block fall on disjoint bank groups
+#define W2_STAGE (WG_BK * W2_LD)
+__device__ __forceinline__ bf16x8 w2_frag(const bf16 *tile, int mm, int col0, int lane) {
+  const int h = lane >> 5, grp = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
+  const bf16 *a = tile + (size_t)(mm + 8 * h + q) * W2_LD + col0 + 16 * grp + 4 * p;
+  typedef __attribute__((address_space(3))) s16x4 lds_v4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)a);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a + 4 * W2_LD));
+  union { s16x4 s[2]; bf16x8 b; } u;
+  u.s[0] = lo; u.s[1] = hi;
+  return u.b;
+}
+
+__global__ __launch_bounds__(512, 2) void wgrad256_kernel(const WgradArgs A, int n_split, int n_blocks) {
+  extern __shared__ __attribute__((aligned(16))) char smem_w[];
+  bf16 *sA = (bf16 *)smem_w;                 // [2][32][W2_LD]
+  bf16 *sB = sA + 2 * W2_STAGE;
+  // XCD-aware id: hardware deals consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous range
+  const int per = n_blocks / 8;              // n_blocks is a multiple of 8
+  const int lid = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  const int total_tiles = A.tile0[A.n_jobs];
+  if (lid >= total_tiles * n_split) return;
+  const int split = lid / total_tiles, tt = lid % total_tiles;
+  int jb = 0;
+  while (jb + 1 < A.n_jobs && tt >= A.tile0[jb + 1]) ++jb;
+  const WgradJob &J = A.job[jb];
+  const int t = tt - A.tile0[jb];
+  const int tiles_k = (J.K + 255) / 256;
+  const int n0 = (t / tiles_k) * 256, k0 = (t % tiles_k) * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int64_t mb = (int64_t)split * A.m_per_block;
+  const int64_t me = mb + A.m_per_block < A.Mpad ? mb + A.m_per_block : A.Mpad;
+  if (mb >= me) return;
+  const bf16 *gA = (const bf16 *)J.A + J.a_col0 + n0;
+  const bf16 *gB = (const bf16 *)J.B + J.b_col0 + k0;
+  // 32 rows x 32 chunks (16 B) per operand = 1024 chunks: 2 per thread
+  const int row0 = tid >> 5, cc = (tid & 31) * 8;            // rows row0 and row0 + 16
+  const bool a_ok = n0 + cc < J.N, b_ok = k0 + cc < J.K;
+  uint4 ra[2], rb[2];
+  auto gload = [&](int64_t m) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int64_t row = m + row0 + 16 * c;
+      ra[c] = a_ok ? *(const uint4 *)(gA + row * J.lda + cc) : uint4{0, 0, 0, 0};
+      rb[c] = b_ok ? *(const uint4 *)(gB + row * J.ldb + cc) : uint4{0, 0, 0, 0};
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      *(uint4 *)(sA + buf * W2_STAGE + (row0 + 16 * c) * W2_LD + cc) = ra[c];
+      *(uint4 *)(sB + buf * W2_STAGE + (row0 + 16 * c) * W2_LD + cc) = rb[c];
+    }
+  };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = J.bias != nullptr && k0 == 0 && tid < 256;
+  gload(mb);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t m = mb; m < me; m += WG_BK) {
+    const bool more = m + WG_BK < me;
+    if (more) gload(m + WG_BK);
+    const bf16 *cA = sA + buf * W2_STAGE, *cB = sB + buf * W2_STAGE;
+#pragma unroll
+    for (int mm = 0; mm < WG_BK; mm += 16) {
+      bf16x8 fa[2], fb[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = w2_frag(cA, mm, wr * 64 + a * 32, lane);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fb[b] = w2_frag(cB, mm, wc * 128 + b * 32, lane);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) mma32(acc[a][b], fa[a], fb[b]);
+    }
+    if (do_bias) {
+#pragma unroll 8
+      for (int row = 0; row < WG_BK; ++row) bsum += (float)cA[row * W2_LD + tid];
+    }
+    if (more) sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int k = k0 + wc * 128 + b * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = n0 + wr * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (n < J.N && k < J.K) atomicAdd(J.C + (size_t)n * J.ldc + k, acc[a][b][i]);
+      }
+    }
+  if (do_bias && n0 + tid < J.N) atomicAdd(J.bias + n0 + tid, bsum);
+}
+
 struct SkinnyJob {
   const void *X;       // [Mpad][ldx] T
   const float *dpre;   // [Mpad][ldp] fp32
@@ -373,25 +483,48 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
   const int64_t me = mb + A.m_per_block < A.Mpad ? mb + A.m_per_block : A.Mpad;
   const T *X = (const T *)J.X + J.x_col0;
   const int tid = threadIdx.x;
-  for (int kb = 0; kb < J.K; kb += 512) {
-    const int k = kb + 2 * tid;
-    float s[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-    float bs[4] = {0, 0, 0, 0};
-    if (k < J.K) {
-      for (int64_t m = mb; m < me; ++m) {
-        const float x0 = (float)X[m * J.ldx + k], x1 = (float)X[m * J.ldx + k + 1];
-        const float *dp = J.dpre + m * J.ldp + J.p_col0;
+  // thread = (row group rg, 8-column group cg): every wave instruction reads whole 16-byte chunks of consecutive
+  // rows (K <= 512 columns -> K/8 <= 64 column groups, 256/(K/8) rows in flight per block)
+  const int ncg = J.K / 8, nrg = 256 / ncg;
+  const int cg = tid % ncg, rg = tid / ncg;
+  float s[4][8], bs[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (c < J.nc) { const float d = dp[c]; s[c][0] += d * x0; s[c][1] += d * x1; if (kb == 0 && tid == 0) bs[c] += d; }
-      }
-      for (int c = 0; c < J.nc; ++c) {
-        atomicAdd(J.out[c] + k, s[c][0]);
-        atomicAdd(J.out[c] + k + 1, s[c][1]);
-        if (kb == 0 && tid == 0 && J.bias[c]) atomicAdd(J.bias[c], bs[c]);
-      }
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[c][e] = 0.f;
+  if (rg < nrg) {
+    for (int64_t m = mb + rg; m < me; m += nrg) {
+      float x[8];
+      ld8(X + m * J.ldx + cg * 8, x);
+      const float *dp = J.dpre + m * J.ldp + J.p_col0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < J.nc) {
+          const float d = dp[c];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s[c][e] += d * x[e];
+          if (cg == 0) bs[c] += d;
+        }
     }
   }
+  // reduce the row groups through LDS, then ONE atomic per output element per block (same-address atomics
+  // from thousands of adders serialise at the memory side)
+  __shared__ float red[4 * 512 + 4];
+  for (int i = tid; i < 4 * 512 + 4; i += 256) red[i] = 0.f;
+  __syncthreads();
+  if (rg < nrg) {
+    for (int c = 0; c < J.nc; ++c) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(&red[c * 512 + cg * 8 + e], s[c][e]);   // LDS atomic, nrg-way
+      if (cg == 0) atomicAdd(&red[4 * 512 + c], bs[c]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < J.nc * J.K; i += 256) {
+    const int c = i / J.K, k = i % J.K;
+    atomicAdd(J.out[c] + k, red[c * 512 + k]);
+  }
+  if (tid < J.nc && J.bias[tid]) atomicAdd(J.bias[tid], red[4 * 512 + tid]);
 }
 
 template <typename T, int MT, int NT> static int launch_bwd(const BwdArgs &a, int64_t tiles, hipStream_t st) {
@@ -460,7 +593,36 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     add(S + sl.dG[p], g.pass_N[p], hl * g.H2, S + sl.feats, F, 0, G->head_w1[hd], F, G->head_b1[hd], g.H2, F);
   }
   BN_REQUIRE(w.n_jobs <= BN_MAX_WGRAD_JOBS, "field_backward: too many wgrad jobs");
-  // split the points so that the grid has a few thousand workgroups
+  if (bf && w.n_jobs > 0) {
+    // 256 x 256 tiles, one 8-wave workgroup per CU: size the point splits for ~4 workgroups per CU in total
+    for (int j = 0; j < w.n_jobs; ++j)
+      w.tile0[j + 1] = w.tile0[j] + ((w.job[j].N + 255) / 256) * ((w.job[j].K + 255) / 256);
+    const int tiles = w.tile0[w.n_jobs];
+    int64_t n_split = 1024 / tiles;
+    if (n_split < 1) n_split = 1;
+    int64_t mpb2 = ceil_div64(ceil_div64(sl.Mpad, n_split), WG_BK) * WG_BK;
+    if (mpb2 < 512) mpb2 = 512;
+    n_split = ceil_div64(sl.Mpad, mpb2);
+    w.m_per_block = (int)mpb2;
+    const int n_blocks = (int)ceil_div64((int64_t)tiles * n_split, 8) * 8;
+    const size_t lds = (size_t)4 * W2_STAGE * sizeof(bf16);
+    static bool configured = false;
+    if (!configured) {
+      hipError_t e = hipFuncSetAttribute((const void *)wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        bn_set_error("wgrad256: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
+        return BN_ELAUNCH;
+      }
+      configured = true;
+    }
+    {
+      BnProfScope prof_(BN_K_WGRAD, st);
+      wgrad256_kernel<<<dim3((unsigned)n_blocks), 512, lds, st>>>(w, (int)n_split, n_blocks);
+      BN_LAUNCH_CHECK("wgrad256");
+    }
+    w.n_jobs = 0;  // done
+  }
+  // fp32 parity path: 128 x 128 tiles; split the points so that the grid has a few thousand workgroups
   int64_t splits = 2048 / (w.tile0[w.n_jobs] > 0 ? w.tile0[w.n_jobs] : 1);
   if (splits < 1) splits = 1;
   int64_t mpb = ceil_div64(ceil_div64(sl.Mpad, splits), WG_BK) * WG_BK;
@@ -497,7 +659,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     for (int c = 0; c < j.nc; ++c) { j.out[c] = G->head_w2[hd] + (size_t)c * g.H2; j.bias[c] = G->head_b2[hd] ? G->head_b2[hd] + c : nullptr; }
   }
   if (s.n_jobs > 0) {
-    int64_t smpb = ceil_div64(sl.Mpad, 1024);
+    int64_t smpb = ceil_div64(sl.Mpad, 512);
     if (smpb < 64) smpb = 64;
     s.m_per_block = (int)smpb;
     dim3 grid((unsigned)ceil_div64(sl.Mpad, smpb), (unsigned)s.n_jobs);

@@ -29,7 +29,7 @@ template <bool FAST> __device__ __forceinline__ void act_eval(int act, float z, 
 
 // One pass over up to two heads: hidden = act(W1 feats + b1) kept in registers, second layer (<= 3 outputs)
 // as per-lane partial dots reduced through LDS.  NTW = 32-column tiles per wave in this pass.
-template <typename T, int MT, int NTW>
+template <typename T, int MT, int NTW, bool KEEP>
 __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT, float *RED, int64_t m0, int64_t tile) {
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
@@ -38,7 +38,7 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
   const int F = g.F, LDA = F + Elem<T>::kPad, KSF = F / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t M = A.pts.n_points;
-  const bool keep = A.stash != nullptr;
+  constexpr bool keep = KEEP;   // compile-time: the inference variant drops every derivative (cos) computation
   const int N = g.pass_N[p];
   const int pc0 = wave * 32 * NTW;                // first column of this wave in the pass
   const bool on = pc0 < N;
@@ -133,7 +133,7 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
   __syncthreads();
 }
 
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, bool KEEP>
 __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs A) {
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
   const int r = lane & 31, h = lane >> 5;
   const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.pts.n_points;
   const T *packed = (const T *)A.packed;
-  const bool keep = A.stash != nullptr;
+  constexpr bool keep = KEEP;   // compile-time: the inference variant drops every derivative (cos) computation
 
   // ---------------------------------------------------------------- points + positional encoding
   {
@@ -311,8 +311,8 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
 
   // ---------------------------------------------------------------- two-layer sigmoid heads, up to 2 per pass
   for (int p = 0; p < g.n_pass; ++p) {
-    if (g.pass_heads[p] == 2) head_pass<T, MT, NT>(A, p, ACT, RED, m0, tile);
-    else head_pass<T, MT, 1>(A, p, ACT, RED, m0, tile);
+    if (g.pass_heads[p] == 2) head_pass<T, MT, NT, KEEP>(A, p, ACT, RED, m0, tile);
+    else head_pass<T, MT, 1, KEEP>(A, p, ACT, RED, m0, tile);
   }
 }
 
@@ -430,13 +430,17 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
   return 0;
 }
 
+template <typename T, int MT, int NT, bool KEEP> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st);
 template <typename T, int MT, int NT> static int launch_fwd(const FwdArgs &a, int64_t tiles, hipStream_t st) {
+  return a.stash ? launch_fwd_k<T, MT, NT, true>(a, tiles, st) : launch_fwd_k<T, MT, NT, false>(a, tiles, st);
+}
+template <typename T, int MT, int NT, bool KEEP> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = ((size_t)BM * (a.g.F + Elem<T>::kPad) + (size_t)BM * (a.g.KP + Elem<T>::kPad)) * sizeof(T) +
                      (size_t)BN_WAVES * 3 * BM * sizeof(float);
   static size_t configured = 0;
   if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)field_fwd_kernel<T, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void *)field_fwd_kernel<T, MT, NT, KEEP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) {
       bn_set_error("field_fwd: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
@@ -445,7 +449,7 @@ template <typename T, int MT, int NT> static int launch_fwd(const FwdArgs &a, in
     configured = lds;
   }
   BnProfScope prof_(a.sigma_only ? BN_K_FWD_SIGMA : BN_K_FWD_FULL, st);
-  field_fwd_kernel<T, MT, NT><<<dim3((unsigned)tiles), BN_THREADS, lds, st>>>(a);
+  field_fwd_kernel<T, MT, NT, KEEP><<<dim3((unsigned)tiles), BN_THREADS, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_fwd");
   return 0;
 }

@@ -35,35 +35,50 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__rest
   const int r = lane & 31, h = lane >> 5;
   const T *wl = wp + (size_t)lane * 8;
   const T *bl = bsrc + (size_t)r * ldb + 8 * h;
-  frag A0[U][NTW], A1[U][NTW];
-  // KS is a multiple of U (every K extent is a multiple of 32): no guards inside the loop, one optional tail block.
-  auto loadA = [&](frag(&A)[U][NTW], int kb) {
+  frag A0[U][NTW], A1[U][NTW], Bc[MT];
+  // KS is a multiple of U (every K extent is a multiple of 32).  Software pipeline: two weight blocks (U k-steps
+  // each) are always in flight from L2 - a block is re-filled right after its last MFMA has issued and consumed one
+  // whole block later - and the LDS fragments of k-step s+1 are read while the MFMAs of k-step s run.
+  // sched_barrier pins that order (hipcc otherwise sinks the prefetch loads next to their use).
+  const int nb = KS / U;
+  auto loadA = [&](frag(&A)[U][NTW], int blk) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) A[u][nt] = gld_frag<T>(wl + ((size_t)nt * KS + kb + u) * 512);
+      for (int nt = 0; nt < NTW; ++nt) A[u][nt] = gld_frag<T>(wl + ((size_t)nt * KS + blk * U + u) * 512);
   };
-  auto compute = [&](frag(&A)[U][NTW], int kb) {
+  auto loadB = [&](frag(&B)[MT], int ks) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) B[mt] = lds_frag<T>(bl + (size_t)mt * 32 * ldb + ks * 16);
+  };
+  auto compute = [&](frag(&A)[U][NTW], int blk) {   // consumes Bc (fragments of k-step blk*U), leaves the next ones in Bc
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      frag B[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) B[mt] = lds_frag<T>(bl + (size_t)mt * 32 * ldb + (kb + u) * 16);
+      frag Bn[MT];
+      const int nxt = blk * U + u + 1;
+      loadB(Bn, nxt < KS ? nxt : 0);
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], A[u][nt], B[mt]);
+        for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], A[u][nt], Bc[mt]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) Bc[mt] = Bn[mt];
     }
   };
   loadA(A0, 0);
-  int kb = 0;
-  for (; kb + 2 * U <= KS; kb += 2 * U) {
-    loadA(A1, kb + U);
-    compute(A0, kb);
-    loadA(A0, kb + 2 * U < KS ? kb + 2 * U : 0);  // after the last full pair: the tail block, or block 0 (unused)
-    compute(A1, kb + U);
+  loadA(A1, nb > 1 ? 1 : 0);
+  loadB(Bc, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  int b = 0;
+  for (; b + 2 <= nb; b += 2) {
+    compute(A0, b);
+    loadA(A0, b + 2 < nb ? b + 2 : nb - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(A1, b + 1);
+    loadA(A1, b + 3 < nb ? b + 3 : nb - 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  if (kb < KS) compute(A0, kb);
+  if (b < nb) compute(A0, b);
 }
 
 template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NTW][MT]) {
