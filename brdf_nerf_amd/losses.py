@@ -27,5 +27,5 @@ def depth_loss(z_vals, depth, weights, target_depth, target_weight, valid_depth,
 
 
 def psnr(rgb, target):
-    """metrics.py:318-325."""
-    return -10.0 * torch.log10(torch.mean((rgb - target) ** 2))
+    """metrics.py:292-325: the reference normalises the squared error by max(target)^2."""
+    return -10.0 * torch.log10(torch.mean((rgb - target) ** 2 / (torch.max(target) ** 2)))
