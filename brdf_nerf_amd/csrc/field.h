@@ -65,6 +65,7 @@ struct PackedLayout {
   size_t fwd_feats, fwd_head[BN_MAX_PASS];
   size_t bwd_trunk[BN_MAX_LAYERS];     // W_l^T restricted to the h inputs, l >= 1
   size_t bwd_feats, bwd_head[BN_MAX_PASS];
+  size_t bwd_pe[2];                    // (W_l[:, :P])^T for l = 0 and l = skip: [KP rows][F k], analytic-normal adjoint only
   size_t total;
 };
 
@@ -84,6 +85,8 @@ static inline void bn_make_packed_layout(const FieldGeom &g, PackedLayout *pl) {
   for (int l = 0; l < g.L; ++l) pl->bwd_trunk[l] = l >= 1 ? take(g.F, g.F) : 0;
   pl->bwd_feats = take(g.F, g.F);
   for (int p = 0; p < g.n_pass; ++p) pl->bwd_head[p] = take(g.F, g.pass_N[p]);
+  pl->bwd_pe[0] = take(g.KP, g.F);
+  pl->bwd_pe[1] = g.skip > 0 ? take(g.KP, g.F) : 0;
   pl->total = off;
 }
 

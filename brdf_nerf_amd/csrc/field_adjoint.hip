@@ -1,0 +1,181 @@
+// Analytic normals: normal_an = -l2_normalize(d sigma / d xyz)  (calc_normals, models/spsbrdfnerf.py:648-660, :713-716).
+// The reference recomputes the trunk and runs autograd; here the gradient is the explicit adjoint chain (SURVEY.md
+// section 8 row a8, validated against autograd in fp64 by the oracle tests):
+//   a_L = sigmoid(sigma_raw) * w_sigma ;  for l = L-1 .. 0:  delta_l = a_{l+1} (.) D_l ,  [g_PE ; a_l] += W_l^T delta_l
+//   d sigma/d x_c = sum_k f_k ( cos(f_k x_c) g_PE[sin,k,c] - sin(f_k x_c) g_PE[cos,k,c] ),  f_k = 2^k
+// It reuses the backward-chain tiling: delta tiles live in LDS, W_l^T streams from L2 in packed fragment order, D_l
+// comes from the forward's stash.  The two PE-part products (l = skip and l = 0; 64 x BM outputs) are spread over all
+// 8 waves (one 32x32 tile each) and accumulated in an fp32 LDS image.
+#include "field_kernels.h"
+
+struct AdjArgs {
+  FieldGeom g;
+  bn_field_params p;
+  PackedLayout pl;
+  StashLayout sl;
+  const void *packed;
+  bn_points pts;
+  float *out;       // [M][C]: channels ch_normal_an..+3 are written
+  float *grad_x;    // optional [M][3]: raw d sigma / d xyz
+  const char *stash;
+};
+
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(BN_THREADS, 2) void field_adjoint_kernel(const AdjArgs A) {
+  typedef typename Elem<T>::vec4 vec4;
+  constexpr int BM = MT * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const FieldGeom &g = A.g;
+  const int F = g.F, LDA = F + Elem<T>::kPad, KSF = F / 16, P = g.P;
+  T *ACT = (T *)smem;
+  float *GP = (float *)(ACT + (size_t)BM * LDA);     // [BM][P] fp32: gradient w.r.t. the positional encoding
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.pts.n_points;
+  const T *packed = (const T *)A.packed;
+  const int ncol0 = wave * 32 * NT;
+  const bool wave_on = ncol0 < F;
+  const float *sraw = (const float *)(A.stash + A.sl.sraw);
+
+  for (int i = tid; i < BM * P; i += BN_THREADS) GP[i] = 0.f;
+
+  // delta_{L-1} = (sigmoid(s_raw) w_sigma) (.) D_{L-1}
+  if (wave_on) {
+    const T *Ds = (const T *)(A.stash + A.sl.D[g.L - 1]) + (size_t)tile * BM * F;
+    float sp[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) sp[mt] = sigmoid_f(sraw[m0 + mt * 32 + r]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
+        const f32x4 wa = *(const f32x4 *)(A.p.sigma_w + n0), wb = *(const f32x4 *)(A.p.sigma_w + n0 + 8);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float dv[8];
+          ld8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dv);
+          const int m = mt * 32 + r;
+          *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), wa[0] * sp[mt] * dv[0], wa[1] * sp[mt] * dv[1], wa[2] * sp[mt] * dv[2], wa[3] * sp[mt] * dv[3]);
+          *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), wb[0] * sp[mt] * dv[4], wb[1] * sp[mt] * dv[5], wb[2] * sp[mt] * dv[6], wb[3] * sp[mt] * dv[7]);
+        }
+      }
+  }
+  __syncthreads();
+
+  f32x16 acc[NT][MT];
+  for (int l = g.L - 1; l >= 0; --l) {
+    // ACT holds delta_l.  PE-part product (only where the layer reads the encoding): wave -> (p-tile, m-tile)
+    if (l == 0 || l == g.skip) {
+      const int ptile = wave & 1, mtile = wave >> 1;
+      if (ptile * 32 < g.KP && mtile < MT) {
+        f32x16 pacc[1][1];
+        zero_acc<1, 1>(pacc);
+        const size_t off = A.pl.bwd_pe[l == 0 ? 0 : 1] + (size_t)ptile * KSF * 512;
+        gemm_seg<T, 1, 1>(pacc, packed + off, KSF, ACT + (size_t)mtile * 32 * LDA, LDA, lane);
+        const int m = mtile * 32 + r;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int p0 = ptile * 32 + 8 * gq + 4 * h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (p0 + e < P) GP[m * P + p0 + e] += pacc[0][0][4 * gq + e];
+        }
+      }
+    }
+    if (l == 0) break;
+    zero_acc<MT, NT>(acc);
+    if (wave_on) gemm_seg<T, MT, NT>(acc, packed + A.pl.bwd_trunk[l] + (size_t)(ncol0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
+    __syncthreads();
+    if (wave_on) {
+      const T *Ds = (const T *)(A.stash + A.sl.D[l - 1]) + (size_t)tile * BM * F;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            float dv[8];
+            ld8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dv);
+            const int m = mt * 32 + r;
+            *(vec4 *)(ACT + (size_t)m * LDA + n0) =
+                to_vec4(T(), acc[nt][mt][8 * gp] * dv[0], acc[nt][mt][8 * gp + 1] * dv[1], acc[nt][mt][8 * gp + 2] * dv[2], acc[nt][mt][8 * gp + 3] * dv[3]);
+            *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) =
+                to_vec4(T(), acc[nt][mt][8 * gp + 4] * dv[4], acc[nt][mt][8 * gp + 5] * dv[5], acc[nt][mt][8 * gp + 6] * dv[6], acc[nt][mt][8 * gp + 7] * dv[7]);
+          }
+        }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+
+  // chain through the positional encoding (fp32, accurate sincos in both precision modes) and normalise
+  if (tid < BM) {
+    const int64_t gm = m0 + tid;
+    if (gm < M) {
+      float x[3];
+      if (A.pts.xyz) {
+        x[0] = A.pts.xyz[gm * 3]; x[1] = A.pts.xyz[gm * 3 + 1]; x[2] = A.pts.xyz[gm * 3 + 2];
+      } else {
+        const float *rr = A.pts.rays + (gm / A.pts.n_samples) * A.pts.ray_stride;
+        const float zz = A.pts.z[gm];
+        x[0] = rr[0] + rr[3] * zz; x[1] = rr[1] + rr[4] * zz; x[2] = rr[2] + rr[5] * zz;
+      }
+      const float *gp = GP + tid * P;
+      float gx[3] = {0.f, 0.f, 0.f};
+      if (g.pe_freqs > 0) {
+        for (int k = 0; k < g.pe_freqs; ++k) {
+          const float f = (float)(1 << k);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            float s, co;
+            sincos_cw(f * x[c], s, co);
+            gx[c] += f * (co * gp[6 * k + c] - s * gp[6 * k + 3 + c]);
+          }
+        }
+      } else {
+        gx[0] = gp[0]; gx[1] = gp[1]; gx[2] = gp[2];
+      }
+      if (A.grad_x) { A.grad_x[gm * 3] = gx[0]; A.grad_x[gm * 3 + 1] = gx[1]; A.grad_x[gm * 3 + 2] = gx[2]; }
+      const float inv = -1.f / sqrtf(fmaxf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2], 1.1920928955078125e-07f));
+      float *o = A.out + gm * g.C + g.ch_normal_an;
+      o[0] = gx[0] * inv; o[1] = gx[1] * inv; o[2] = gx[2] * inv;
+    }
+  }
+}
+
+template <typename T, int MT, int NT> static int launch_adj(const AdjArgs &a, int64_t tiles, hipStream_t st) {
+  constexpr int BM = MT * 32;
+  const size_t lds = (size_t)BM * (a.g.F + Elem<T>::kPad) * sizeof(T) + (size_t)BM * a.g.P * sizeof(float);
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute((const void *)field_adjoint_kernel<T, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      bn_set_error("field_normals: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
+      return BN_ELAUNCH;
+    }
+    configured = lds;
+  }
+  BnProfScope prof_(BN_K_ADJOINT, st);
+  field_adjoint_kernel<T, MT, NT><<<dim3((unsigned)tiles), BN_THREADS, lds, st>>>(a);
+  BN_LAUNCH_CHECK("field_normals");
+  return 0;
+}
+
+extern "C" int bn_field_normals(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
+                                const bn_points *pts, const void *stash, float *out, float *grad_x, void *stream) {
+  AdjArgs a;
+  if (int e = bn_make_geom(desc, &a.g)) return e;
+  BN_REQUIRE(desc->normal_an && a.g.ch_normal_an >= 0, "field_normals: desc.normal_an is not set");
+  BN_REQUIRE(desc->act == BN_ACT_SIN || desc->act == BN_ACT_RELU, "field_normals: bad activation");
+  BN_REQUIRE(pts && pts->n_points > 0 && packed && stash && out, "field_normals: null argument");
+  a.p = *params; a.packed = packed; a.pts = *pts; a.out = out; a.grad_x = grad_x; a.stash = (const char *)stash;
+  bn_make_packed_layout(a.g, &a.pl);
+  const bool bf = desc->dtype == BN_BF16;
+  const int BM = bf ? 128 : 64;
+  bn_make_stash_layout(a.g, pts->n_points, BM, bf ? 2 : 4, &a.sl);
+  const int64_t tiles = ceil_div64(pts->n_points, BM);
+  hipStream_t st = (hipStream_t)stream;
+  if (bf) return a.g.NT == 2 ? launch_adj<bf16, 4, 2>(a, tiles, st) : launch_adj<bf16, 4, 1>(a, tiles, st);
+  return a.g.NT == 2 ? launch_adj<float, 2, 2>(a, tiles, st) : launch_adj<float, 2, 1>(a, tiles, st);
+}

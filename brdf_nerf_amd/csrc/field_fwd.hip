@@ -405,6 +405,13 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
   }
   add(P->feats_w, pl.fwd_feats, F, F, F, 0, 0, 0);
   add(P->feats_w, pl.bwd_feats, F, F, F, 0, 0, 1);
+  // (W_l[:, :P])^T for the analytic-normal adjoint: packed[row p][k n] = W_l[n][p]
+  add(P->trunk_w[0], pl.bwd_pe[0], P0, P0, F, 0, 0, 1);
+  a.job[a.n_jobs - 1].rows_pad = g.KP;
+  if (g.skip > 0) {
+    add(P->trunk_w[g.skip], pl.bwd_pe[1], F + P0, P0, F, 0, 0, 1);
+    a.job[a.n_jobs - 1].rows_pad = g.KP;
+  }
   for (int p = 0; p < g.n_pass; ++p)
     for (int hl = 0; hl < g.pass_heads[p]; ++hl) {
       const int hd = 2 * p + hl;
@@ -458,7 +465,8 @@ int bn_field_forward_impl(const bn_field_desc *desc, const bn_field_params *para
                           const bn_points *pts, float *out, void *stash, int sigma_only, void *stream) {
   FwdArgs a;
   if (int e = bn_make_geom(desc, &a.g)) return e;
-  BN_REQUIRE(!desc->normal_an, "field_forward: analytic normals are not implemented by this entry point");
+  // desc->normal_an only reserves 3 output channels here; bn_field_normals() fills them from the stash
+  BN_REQUIRE(!desc->normal_an || sigma_only || stash, "field_forward: analytic normals need the activation stash");
   BN_REQUIRE(pts && pts->n_points > 0 && (pts->xyz || (pts->rays && pts->z && pts->n_samples > 0)), "field: bad points");
   BN_REQUIRE(packed && out, "field: null buffer");
   a.d = *desc; a.p = *params; a.packed = packed; a.pts = *pts; a.out = out; a.stash = (char *)stash;

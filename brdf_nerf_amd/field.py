@@ -57,8 +57,6 @@ class SpSBRDFNeRF(nn.Module):
             raise NotImplementedError(_UNSUPPORTED + "--indirect_light (needs sun_v)")
         if getattr(args, "input_viewdir", 0):
             raise NotImplementedError(_UNSUPPORTED + "--input_viewdir")
-        if normal in ("analystic", "analystic_learned"):
-            raise NotImplementedError(_UNSUPPORTED + "--normal analystic (adjoint chain kernel is the next row)")
         if len(skips) > 1:
             raise NotImplementedError(_UNSUPPORTED + "more than one skip layer")
         self.layers, self.skips, self.t_embedding_dims = layers, list(skips), t_embedding_dims
@@ -168,13 +166,13 @@ class SpSBRDFNeRF(nn.Module):
                     heads.append(("theta_from_xyz", 1, L.BN_HEAD_HAPKE_THETA))
         return heads
 
-    def spec(self, apply_brdf=False, apply_theta=False, nr_lr_on=False):
+    def spec(self, apply_brdf=False, apply_theta=False, nr_lr_on=False, nr_an_on=False):
         dtype = L.BN_BF16 if self.compute_dtype == "bf16" else L.BN_F32
-        key = (bool(apply_brdf), bool(apply_theta), bool(nr_lr_on), dtype)
+        key = (bool(apply_brdf), bool(apply_theta), bool(nr_lr_on), bool(nr_an_on), dtype)
         if key not in self._specs:
             self._specs[key] = Fn.FieldSpec(self.feat, self.layers, self.skips[0] if self.skips else -1, self.pe_freqs,
                                             L.BN_ACT_SIN if self.siren_on else L.BN_ACT_RELU, dtype,
-                                            self.head_list(apply_brdf, apply_theta), nr_lr_on)
+                                            self.head_list(apply_brdf, apply_theta), nr_lr_on, nr_an_on)
         return self._specs[key]
 
     def named(self):
@@ -193,9 +191,7 @@ class SpSBRDFNeRF(nn.Module):
     def forward(self, input_xyz_, input_dir=None, input_sun_dir=None, input_t=None, sigma_only=False, apply_brdf=False,
                 apply_theta=False, nr_an_on=False, nr_lr_on=False, sun_ray=False, mode="train"):
         """(B,3) points -> (B,C) [rgb3, sigma, (normal_lr3), BRDF head outputs], or (B,1) sigma."""
-        if nr_an_on:
-            raise NotImplementedError(_UNSUPPORTED + "analytic normals (nr_an_on)")
-        spec = self.spec(apply_brdf, apply_theta, nr_lr_on)
+        spec = self.spec(apply_brdf, apply_theta, nr_lr_on, nr_an_on and not sigma_only)
         packed = self.repack(spec)
         xyz = input_xyz_.detach().float().contiguous()
         if sigma_only:
@@ -205,7 +201,7 @@ class SpSBRDFNeRF(nn.Module):
     def evaluate(self, spec, packed, xyz=None, rays=None, z=None):
         names = spec.used_param_names()
         named = self.named()
-        return Fn.FieldFunction.apply(spec, packed, xyz, rays, z, names, *[named[n] for n in names])
+        return Fn.FieldFunction.apply(spec, packed, xyz, rays, z, (names, torch.is_grad_enabled()), *[named[n] for n in names])
 
 
 def load_model(args, compute_dtype=None):

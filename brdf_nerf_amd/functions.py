@@ -29,14 +29,14 @@ def _f32(t):
 class FieldSpec:
     """Host-side description of one evaluation of the field: which heads, which dtype."""
 
-    def __init__(self, feat, layers, skip, pe_freqs, act, dtype, heads, normal_lr):
+    def __init__(self, feat, layers, skip, pe_freqs, act, dtype, heads, normal_lr, normal_an=False):
         # heads: list of (name, n_out, kind); heads[0] must be ("rgb_from_xyzdir", 3, PLAIN)
         self.feat, self.layers, self.skip, self.pe_freqs, self.act, self.dtype = feat, layers, skip, pe_freqs, act, dtype
-        self.heads, self.normal_lr = list(heads), bool(normal_lr)
+        self.heads, self.normal_lr, self.normal_an = list(heads), bool(normal_lr), bool(normal_an)
         d = L.FieldDesc()
         d.feat, d.layers, d.skip, d.pe_freqs, d.act, d.dtype = feat, layers, skip, pe_freqs, act, dtype
         d.n_heads = len(self.heads)
-        c = 4 + (3 if normal_lr else 0)
+        c = 4 + (3 if normal_an else 0) + (3 if normal_lr else 0)
         self.head_cols = []
         for i, (_, n_out, kind) in enumerate(self.heads):
             d.head_out[i], d.head_kind[i] = n_out, kind
@@ -46,15 +46,17 @@ class FieldSpec:
                 w = n_out if kind in (L.BN_HEAD_PLAIN, L.BN_HEAD_HAPKE_THETA) else 3
                 self.head_cols.append((c, w))
                 c += w
-        d.normal_lr, d.normal_an, d.out_channels = int(normal_lr), 0, c
+        d.normal_lr, d.normal_an, d.out_channels = int(normal_lr), int(normal_an), c
         self.desc, self.out_channels = d, c
-        self.ch_normal_lr = 4 if normal_lr else -1
+        self.ch_normal_an = 4 if normal_an else -1
+        self.ch_normal_lr = (7 if normal_an else 4) if normal_lr else -1
         self.packed_bytes = L.lib().bn_field_packed_bytes(C.byref(d))
         if self.packed_bytes == 0:
             raise RuntimeError("bn_field_packed_bytes: " + L.lib().bn_last_error().decode())
 
     def key(self):
-        return (self.feat, self.layers, self.skip, self.pe_freqs, self.act, self.dtype, tuple(self.heads), self.normal_lr)
+        return (self.feat, self.layers, self.skip, self.pe_freqs, self.act, self.dtype, tuple(self.heads), self.normal_lr,
+                self.normal_an)
 
     def params_struct(self, named, grads=False):
         """named: dict state_dict-key -> tensor (parameters, or same-shaped gradient buffers)."""
@@ -119,19 +121,27 @@ class FieldFunction(torch.autograd.Function):
     needs d/d xyz outside the analytic-normal path: z_vals are detached, rendering.py:262)."""
 
     @staticmethod
-    def forward(ctx, spec, packed, xyz, rays, z, names, *params):
+    def forward(ctx, spec, packed, xyz, rays, z, names_grad, *params):
+        names, grad_enabled = names_grad            # grad mode is always off inside Function.forward: passed in
         named = dict(zip(names, params))
         pts = make_points(xyz, rays, z)
         ref = xyz if xyz is not None else z
         out = torch.empty(pts.n_points, spec.out_channels, dtype=torch.float32, device=ref.device)
-        need_grad = any(ctx.needs_input_grad[6:])   # grad mode is off inside Function.forward
+        need_grad = grad_enabled and any(p.requires_grad for p in params)
         stash = None
-        if need_grad:
+        if need_grad and spec.normal_an:
+            raise NotImplementedError("training through analytic normals needs the double backward of the adjoint chain "
+                                      "(next row, DESIGN.md section 7); run under torch.no_grad() or use --normal learned")
+        if need_grad or spec.normal_an:
             nbytes = L.lib().bn_field_stash_bytes(C.byref(spec.desc), pts.n_points)
             stash = torch.empty(nbytes, dtype=torch.uint8, device=ref.device)
         ps = spec.params_struct(named)
         L.check(L.lib().bn_field_forward(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(out), _p(stash),
                                          _stream()), "bn_field_forward")
+        if spec.normal_an:
+            L.check(L.lib().bn_field_normals(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(stash), _p(out), None,
+                                             _stream()), "bn_field_normals")
+            stash = None
         ctx.spec, ctx.packed, ctx.names, ctx.stash = spec, packed, names, stash
         ctx.pts_t = (xyz, rays, z)
         ctx.save_for_backward(out, *params)

@@ -53,12 +53,11 @@ def inference(model, args, rays_xyz, z_vals, rays_d=None, sun_d=None, rays_t=Non
               mode="train", apply_theta=False, sigma_only=False, cos_irra_on=False, _rays=None, _packed=None):
     """inference (models/spsbrdfnerf.py:71-416).  `rays_xyz` (R,S,3) may be None when `_rays` (R,>=8) is given: the
     kernel then forms xyz = o + d*z itself (what render_rays does)."""
-    if bTestNormal:
-        raise NotImplementedError("bTestNormal needs analytic normals")
     R, S = z_vals.shape
     z_vals = z_vals.contiguous()
     nr_lr = model.normal in ("analystic_learned", "learned")
-    spec = model.spec(apply_brdf and not sigma_only, apply_theta, nr_lr and not sigma_only)
+    nr_an = model.normal in ("analystic_learned", "analystic") or bTestNormal
+    spec = model.spec(apply_brdf and not sigma_only, apply_theta, nr_lr and not sigma_only, nr_an and not sigma_only)
     packed = _packed if _packed is not None else model.repack(spec)
     xyz = None if _rays is not None else rays_xyz.reshape(-1, 3).detach().float().contiguous()
     noise = torch.randn(R, S, device=z_vals.device)   # drawn even when noise_std == 0, like the reference (:58)
@@ -91,9 +90,13 @@ def shade(model, args, spec, out, z_vals, alphas, transparency, weights, depth, 
     if z_vals_unsort is not None:
         result["z_vals_unsort"] = z_vals_unsort
     normal = normal_s = None
-    if nr_lr:
+    if spec.normal_an:
+        c0 = spec.ch_normal_an
+        result["normal_an"] = normal = out[..., c0:c0 + 3]
+    if nr_lr:                                   # learned wins when both are present (spsbrdfnerf.py:234-239)
         c0 = spec.ch_normal_lr
         result["normal_lr"] = normal = out[..., c0:c0 + 3]
+    if normal is not None:
         normal_s = l2_normalize(acc[:, c0:c0 + 3])
         view = -rays_d
         result["nr_vw"] = (normal_s * view).sum(-1).reshape(R, 1, 1)
@@ -195,7 +198,8 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
     sun_d = rays[:, 8:11] if args.data == "sat" else torch.ones_like(rays[:, 0:3])
 
     nr_lr = model.normal in ("analystic_learned", "learned")
-    spec = model.spec(apply_brdf, apply_theta, nr_lr)
+    nr_an = model.normal in ("analystic_learned", "analystic") or bTestNormal
+    spec = model.spec(apply_brdf, apply_theta, nr_lr, nr_an)
     packed = model.repack(spec)
 
     z_vals = get_z_vals(S, rays.device, near, far)
@@ -221,6 +225,7 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
     else:
         z_unsort = torch.cat([z_vals, z2], -1)
     result, brdf_type = inference(model, args, None, z_all, rays_d=rays_d, sun_d=sun_d, z_vals_unsort=z_unsort,
-                                  apply_brdf=apply_brdf, sun_res={}, sort_idx=idx, mode=mode, apply_theta=apply_theta,
+                                  apply_brdf=apply_brdf, bTestNormal=bTestNormal, sun_res={}, sort_idx=idx, mode=mode,
+                                  apply_theta=apply_theta,
                                   cos_irra_on=cos_irra_on, _rays=rays, _packed=packed)
     return {f"{k}_coarse": v for k, v in result.items()}, brdf_type

@@ -19,6 +19,8 @@ CONFIGS = {
     "rpv333_nlr": dict(funcM=1, funcF=1, funcH=1, dim_RPV=3, normal="learned"),
     "hapke_bct": dict(b=1, c=1, theta=1, normal="learned"),
     "microfacet": dict(roughness=True, normal="learned"),
+    "rpv111_nan": dict(funcM=1, funcF=1, funcH=1, normal="analystic"),
+    "hapke_bc_both": dict(b=1, c=1, normal="analystic_learned"),
 }
 
 
@@ -71,7 +73,8 @@ def test_module_contract_and_channel_layout(name):
     assert got == want                                   # reference state_dict keys and shapes
     assert list(got) == list(want)                       # and registration order
     for apply_brdf in (False, True):
-        spec = model.spec(apply_brdf, True, cfg.normal == "learned")
+        spec = model.spec(apply_brdf, True, cfg.normal in ("learned", "analystic_learned"),
+                          cfg.normal in ("analystic", "analystic_learned"))
         assert spec.out_channels == cfg.out_channels(apply_brdf, True)
         assert spec.packed_bytes > 0
     assert model.number_of_outputs == 4
@@ -93,7 +96,7 @@ def test_init_ranges_follow_reference():
 
 def test_unsupported_flags_raise():
     from brdf_nerf_amd import load_model
-    for over in (dict(normal="analystic"), dict(beta=True), dict(sun_v="analystic"), dict(input_viewdir=1)):
+    for over in (dict(beta=True), dict(sun_v="analystic"), dict(input_viewdir=1), dict(indirect_light=True)):
         with pytest.raises(NotImplementedError):
             load_model(make_args(FieldConfig(feat=64), **over))
     with pytest.raises(ValueError):
@@ -107,7 +110,7 @@ def test_packed_and_stash_sizes():
     spec = model.spec(False, False, False)
     F, P = 512, 64
     fwd = F * P + 6 * F * F + (F * P + F * F) + F * F + 256 * F
-    bwd = 7 * F * F + F * F + F * 256
+    bwd = 7 * F * F + F * F + F * 256 + 2 * P * F            # + (W_0[:, :P])^T and (W_skip[:, :P])^T for the normals adjoint
     assert spec.packed_bytes == (fwd + bwd) * 4                      # fp32 parity mode
     n = Fn.field_stash_bytes(spec, 1000)
     assert n > 1024 * F * 4 * 16 and n % 256 == 0
