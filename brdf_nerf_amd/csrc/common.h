@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <type_traits>
 #include "brdfnerf_hip.h"
 #include "prof.h"
 

@@ -17,14 +17,27 @@ struct FwdArgs {
   int sigma_only;
 };
 
-template <bool FAST> __device__ __forceinline__ void act_eval(int act, float z, float w0, float &y, float &d) {
-  if (act == BN_ACT_SIN) {
-    float s, c;
-    sincos_t<FAST>(w0 * z, s, c);
-    y = s; d = w0 * c;
+// Activation + derivative of one pre-activation.  ACT is compile-time (the epilogues branch once, outside their
+// element loops).  In the bf16 throughput mode (FAST) the Siren layers' packed weights and biases are pre-scaled by
+// w0/(2 pi) (bn_pack_field), so `z` already is the argument of v_sin_f32/v_cos_f32 in revolutions: one transcendental
+// per output, no range-reduction multiplies.  The parity mode keeps z = W x + b and the accurate sincos.
+#define BN_INV_2PI 0.15915494309189535f
+template <bool FAST, int ACT> __device__ __forceinline__ void act_eval(float z, float w0, float &y, float &d) {
+  if (ACT == BN_ACT_SIN) {
+    if (FAST) {
+      y = __builtin_amdgcn_sinf(z);
+      d = w0 * __builtin_amdgcn_cosf(z);
+    } else {
+      float s, c;
+      sincos_cw(w0 * z, s, c);
+      y = s; d = w0 * c;
+    }
   } else {
     y = z > 0.f ? z : 0.f; d = z > 0.f ? 1.f : 0.f;
   }
+}
+template <bool FAST> __device__ __forceinline__ float act_prescale(int act, float w0) {
+  return (FAST && act == BN_ACT_SIN) ? w0 * BN_INV_2PI : 1.f;
 }
 
 // One pass over up to two heads: hidden = act(W1 feats + b1) kept in registers, second layer (<= 3 outputs)
@@ -56,41 +69,47 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
     float part[MT][3];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) part[mt][0] = part[mt][1] = part[mt][2] = 0.f;
+    const float bscale = act_prescale<FAST>(g.act, 1.f);
+    auto epilogue = [&](auto act_tag) {
+      constexpr int ACTK = decltype(act_tag)::value;
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
+      for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        const int n0 = pc0 + nt * 32 + 16 * gp + 4 * h;   // column in the pass of the first run (second: +8)
-        const int nl = n0 - hl * g.H2;                     // column inside the head
-        const f32x4 ba = *(const f32x4 *)(b1 + nl), bb = *(const f32x4 *)(b1 + nl + 8);
-        f32x4 wa[3], wb[3];
+        for (int gp = 0; gp < 2; ++gp) {
+          const int n0 = pc0 + nt * 32 + 16 * gp + 4 * h;   // column in the pass of the first run (second: +8)
+          const int nl = n0 - hl * g.H2;                     // column inside the head
+          const f32x4 ba = *(const f32x4 *)(b1 + nl) * bscale, bb = *(const f32x4 *)(b1 + nl + 8) * bscale;
+          f32x4 wa[3], wb[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          wa[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl) : f32x4{0, 0, 0, 0};
-          wb[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl + 8) : f32x4{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          float y[8], dd[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            act_eval<FAST>(g.act, acc[nt][mt][8 * gp + e] + ba[e], 1.f, y[e], dd[e]);
-            act_eval<FAST>(g.act, acc[nt][mt][8 * gp + 4 + e] + bb[e], 1.f, y[4 + e], dd[4 + e]);
+          for (int c = 0; c < 3; ++c) {
+            wa[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl) : f32x4{0, 0, 0, 0};
+            wb[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl + 8) : f32x4{0, 0, 0, 0};
           }
-          const vec4 ya = to_vec4(T(), y[0], y[1], y[2], y[3]), yb = to_vec4(T(), y[4], y[5], y[6], y[7]);
-          if (keep) {
-            const int m = mt * 32 + r;
-            *(vec4 *)(Gs + (size_t)m * N + n0) = ya;
-            *(vec4 *)(Gs + (size_t)m * N + n0 + 8) = yb;
-            st8(DGs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), dd);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            float y[8], dd[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              act_eval<FAST, ACTK>(acc[nt][mt][8 * gp + e] + ba[e], 1.f, y[e], dd[e]);
+              act_eval<FAST, ACTK>(acc[nt][mt][8 * gp + 4 + e] + bb[e], 1.f, y[4 + e], dd[4 + e]);
+            }
+            const vec4 ya = to_vec4(T(), y[0], y[1], y[2], y[3]), yb = to_vec4(T(), y[4], y[5], y[6], y[7]);
+            if (keep) {
+              const int m = mt * 32 + r;
+              *(vec4 *)(Gs + (size_t)m * N + n0) = ya;
+              *(vec4 *)(Gs + (size_t)m * N + n0 + 8) = yb;
+              st8(DGs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), dd);
+            }
+            // the second layer sees the stored (rounded) hidden value: fwd and bwd stay consistent
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) part[mt][c] += (float)ya[e] * wa[c][e] + (float)yb[e] * wb[c][e];
           }
-          // the second layer sees the stored (rounded) hidden value: fwd and bwd stay consistent
-#pragma unroll
-          for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) part[mt][c] += (float)ya[e] * wa[c][e] + (float)yb[e] * wb[c][e];
         }
-      }
+    };
+    if (g.act == BN_ACT_SIN) epilogue(std::integral_constant<int, BN_ACT_SIN>());
+    else epilogue(std::integral_constant<int, BN_ACT_RELU>());
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -211,28 +230,34 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
     __syncthreads();  // every wave has finished reading ACT (in-place update below)
     if (wave_on) {
       const float w0 = (l == 0) ? 30.f : 1.f;
+      const float bscale = act_prescale<FAST>(g.act, w0);
       const float *bias = A.p.trunk_b[l];
       T *Ds = keep ? (T *)(A.stash + A.sl.D[l]) + (size_t)tile * BM * F : nullptr;
+      auto epilogue = [&](auto act_tag) {
+        constexpr int ACTK = decltype(act_tag)::value;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
-          const f32x4 ba = *(const f32x4 *)(bias + n0), bb = *(const f32x4 *)(bias + n0 + 8);
+          for (int gp = 0; gp < 2; ++gp) {
+            const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
+            const f32x4 ba = *(const f32x4 *)(bias + n0) * bscale, bb = *(const f32x4 *)(bias + n0 + 8) * bscale;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            float y[8], dd[8];
+            for (int mt = 0; mt < MT; ++mt) {
+              float y[8], dd[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              act_eval<FAST>(g.act, acc[nt][mt][8 * gp + e] + ba[e], w0, y[e], dd[e]);
-              act_eval<FAST>(g.act, acc[nt][mt][8 * gp + 4 + e] + bb[e], w0, y[4 + e], dd[4 + e]);
+              for (int e = 0; e < 4; ++e) {
+                act_eval<FAST, ACTK>(acc[nt][mt][8 * gp + e] + ba[e], w0, y[e], dd[e]);
+                act_eval<FAST, ACTK>(acc[nt][mt][8 * gp + 4 + e] + bb[e], w0, y[4 + e], dd[4 + e]);
+              }
+              const int m = mt * 32 + r;
+              *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), y[0], y[1], y[2], y[3]);
+              *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), y[4], y[5], y[6], y[7]);
+              if (keep) st8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dd);
             }
-            const int m = mt * 32 + r;
-            *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), y[0], y[1], y[2], y[3]);
-            *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), y[4], y[5], y[6], y[7]);
-            if (keep) st8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dd);
           }
-        }
+      };
+      if (g.act == BN_ACT_SIN) epilogue(std::integral_constant<int, BN_ACT_SIN>());
+      else epilogue(std::integral_constant<int, BN_ACT_RELU>());
     }
     __syncthreads();
     if (keep) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[l]) + (size_t)m0 * F, F, BM, F);
@@ -327,6 +352,7 @@ struct PackJob {
   int transposed;    // 1: packed[row][k] = src[k - k_lo + col_off][row + row_off]
   int k_lo;          // first packed k this job owns
   int masked;        // 1: touch only k in [k_lo, k_lo+K) (several jobs fill one packed matrix)
+  float scale;       // multiplies every element (w0/(2 pi) for the forward Siren matrices in bf16 mode)
 };
 #define BN_MAX_PACK_JOBS 48
 struct PackArgs {
@@ -351,7 +377,7 @@ template <typename T> __global__ void pack_kernel(const PackArgs A) {
     if (row < j.rows && kk >= 0 && kk < j.K)
       v = j.transposed ? j.src[(size_t)(kk + j.col_off) * j.ld + row + j.row_off]
                        : j.src[(size_t)(row + j.row_off) * j.ld + kk + j.col_off];
-    dst[i] = (T)v;
+    dst[i] = (T)(v * j.scale);
   }
 }
 
@@ -385,7 +411,13 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
     PackJob &j = a.job[a.n_jobs++];
     j.src = src; j.dst = dst; j.ld = ld; j.rows = rows; j.K = K;
     j.rows_pad = (int)bn_pad(rows, 32); j.K_pad = (int)bn_pad(K, 16);
-    j.row_off = row_off; j.col_off = col_off; j.transposed = tr; j.k_lo = 0; j.masked = 0;
+    j.row_off = row_off; j.col_off = col_off; j.transposed = tr; j.k_lo = 0; j.masked = 0; j.scale = 1.f;
+  };
+  // bf16 Siren: forward matrices carry w0/(2 pi) so the epilogue feeds v_sin/v_cos directly (see act_eval)
+  const bool prescale = desc->dtype == BN_BF16 && desc->act == BN_ACT_SIN;
+  auto fwd_scale = [&](int n_last, float w0) {
+    if (prescale)
+      for (int q = 0; q < n_last; ++q) a.job[a.n_jobs - 1 - q].scale = w0 * BN_INV_2PI;
   };
   const int F = g.F, P0 = g.P;
   for (int l = 0; l < g.L; ++l) {
@@ -393,11 +425,16 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
     if (l == 0) {
       add(P->trunk_w[l], pl.fwd_trunk[l][0], P0, F, P0, 0, 0, 0);
       a.job[a.n_jobs - 1].K_pad = g.KP;                 // the PE operand is padded to 4 MFMA k-steps
+      fwd_scale(1, 30.f);
     } else if (l == g.skip) {
       add(P->trunk_w[l], pl.fwd_trunk[l][0], F + P0, F, P0, 0, 0, 0);
       a.job[a.n_jobs - 1].K_pad = g.KP;
       add(P->trunk_w[l], pl.fwd_trunk[l][1], F + P0, F, F, 0, P0, 0);
-    } else add(P->trunk_w[l], pl.fwd_trunk[l][0], F, F, F, 0, 0, 0);
+      fwd_scale(2, 1.f);
+    } else {
+      add(P->trunk_w[l], pl.fwd_trunk[l][0], F, F, F, 0, 0, 0);
+      fwd_scale(1, 1.f);
+    }
     if (l >= 1) {  // W_l^T over the h inputs: packed[row j][k n] = W[n][j (+P0 at the skip layer)]
       const int ld = l == g.skip ? F + P0 : F;
       add(P->trunk_w[l], pl.bwd_trunk[l], ld, F, F, l == g.skip ? P0 : 0, 0, 1);
@@ -418,6 +455,7 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
       BN_REQUIRE(P->head_w1[hd] && P->head_b1[hd] && P->head_w2[hd] && P->head_b2[hd], "pack: head %d missing", hd);
       // forward: rows of the pass = [head 2p rows | head 2p+1 rows]; row tiles of a head are contiguous in the pass
       add(P->head_w1[hd], pl.fwd_head[p] + (size_t)hl * g.H2 * F, F, g.H2, F, 0, 0, 0);
+      fwd_scale(1, 1.f);
     }
   // transposed head-1 weights: packed[row j][k = column in pass] = W1_hd[k - hl*H2][j]; the heads of a pass
   // interleave along k, so each head fills its own k range of the shared packed matrix (masked job).
@@ -426,7 +464,7 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
       PackJob &j = a.job[a.n_jobs++];
       j.src = P->head_w1[2 * p + hl]; j.dst = pl.bwd_head[p]; j.ld = F; j.rows = F; j.K = g.H2;
       j.rows_pad = F; j.K_pad = g.pass_N[p]; j.row_off = 0; j.col_off = 0; j.transposed = 1;
-      j.k_lo = hl * g.H2; j.masked = 1;
+      j.k_lo = hl * g.H2; j.masked = 1; j.scale = 1.f;
     }
   BN_REQUIRE(a.n_jobs <= BN_MAX_PACK_JOBS, "pack: too many jobs");
   dim3 grid(64, a.n_jobs);
