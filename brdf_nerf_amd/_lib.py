@@ -60,7 +60,7 @@ _SIGS = {
     "bn_field_backward": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), fptr, C.POINTER(Points), fptr, fptr,
                                     fptr, C.POINTER(FieldGrads), fptr]),
     "bn_field_normals": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), fptr, C.POINTER(Points), fptr, fptr, fptr,
-                                   fptr]),
+                                   C.c_int32, fptr]),
     "bn_composite_forward": (C.c_int, [fptr, fptr, C.c_int64, fptr, C.c_float, fptr, C.c_int64, C.c_int32, C.c_int64,
                                        C.c_int32, fptr, fptr, fptr, fptr, fptr, fptr]),
     "bn_composite_backward": (C.c_int, [fptr, fptr, C.c_int64, fptr, C.c_float, fptr, C.c_int64, C.c_int32, C.c_int64,
@@ -81,7 +81,7 @@ _SIGS = {
 }
 
 PROF_NAMES = ["pack", "field_fwd_sigma", "field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad", "composite_fwd",
-              "composite_bwd", "guided_samples", "stratified_z", "adam", "brdf", "field_adjoint"]
+              "composite_bwd", "guided_samples", "stratified_z", "adam", "brdf", "field_adjoint", "field_adjoint_bwd"]
 
 
 def prof_enable(on):

@@ -108,6 +108,15 @@ struct StashLayout {
   size_t dZ[BN_MAX_LAYERS];       // T [Mpad][F]                                          (bwd-produced)
   size_t dfeats;                  // T [Mpad][F]                                          (bwd-produced)
   size_t dG[BN_MAX_PASS];         // T [Mpad][pass_N]                                     (bwd-produced)
+  // analytic-normal training (double backward of the adjoint chain); allocated only when desc.normal_an
+  size_t gradx;                   // fp32 [Mpad][4]  raw d sigma / d xyz
+  size_t sbar;                    // fp32 [Mpad]     extra d L / d sigma_raw from the adjoint's sigmoid seed  (bwd-produced)
+  size_t sprime;                  // fp32 [Mpad]     sigmoid(sigma_raw)
+  size_t gbar_pe;                 // T [Mpad][KP]    d L / d g_PE                                           (bwd-produced)
+  size_t adj_delta[BN_MAX_LAYERS];  // T [Mpad][F]   delta_l = a_{l+1} (.) D_l
+  size_t adj_a[BN_MAX_LAYERS];      // T native      a_{l+1}
+  size_t adj_abar[BN_MAX_LAYERS + 1];  // T [Mpad][F] abar_l, l = 1..L                                       (bwd-produced)
+  size_t adj_zbar[BN_MAX_LAYERS];   // T native      extra d L / d z_l through D_l                          (bwd-produced)
   size_t total;
   int64_t Mpad;
 };
@@ -135,5 +144,20 @@ static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, in
   for (int l = 0; l < g.L; ++l) s->dZ[l] = take((size_t)Mpad * g.F * esz);
   s->dfeats = take((size_t)Mpad * g.F * esz);
   for (int p = 0; p < g.n_pass; ++p) s->dG[p] = take((size_t)Mpad * g.pass_N[p] * esz);
+  s->gradx = s->sbar = s->sprime = s->gbar_pe = 0;
+  for (int l = 0; l < BN_MAX_LAYERS; ++l) s->adj_delta[l] = s->adj_a[l] = s->adj_abar[l] = s->adj_zbar[l] = 0;
+  s->adj_abar[BN_MAX_LAYERS] = 0;
+  if (g.ch_normal_an >= 0) {
+    s->gradx = take((size_t)Mpad * 16);
+    s->sbar = take((size_t)Mpad * 4);
+    s->sprime = take((size_t)Mpad * 4);
+    s->gbar_pe = take((size_t)Mpad * g.KP * esz);
+    for (int l = 0; l < g.L; ++l) {
+      s->adj_delta[l] = take((size_t)Mpad * g.F * esz);
+      s->adj_a[l] = take((size_t)Mpad * g.F * esz);
+      s->adj_abar[l + 1] = take((size_t)Mpad * g.F * esz);
+      s->adj_zbar[l] = take((size_t)Mpad * g.F * esz);
+    }
+  }
   s->total = off;
 }

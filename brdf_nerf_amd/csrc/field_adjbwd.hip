@@ -1,0 +1,191 @@
+// Backward of the analytic-normal adjoint chain (the "double backward" of calc_normals with create_graph=True,
+// models/spsbrdfnerf.py:648-660, in training with --normal analystic).
+//
+// Forward adjoint (field_adjoint.hip):  a_L = s' w_sigma ; delta_l = a_{l+1} (.) D_l ; [g_PE ; a_l] += W_l^T delta_l ;
+//                                        g = J_PE(x)^T g_PE ; n = -g / |g|.
+// Given dL/dn this kernel walks the chain the other way, which has the shape of a FORWARD pass of the field:
+//   gbar_PE = J_PE(x) gbar ;   for l = 0 .. L-1:  dbar_l = W_l [gbar_PE ; abar_l]      (same packed weights as the forward)
+//                                                  abar_{l+1} = dbar_l (.) D_l
+//                                                  zbar_l = dbar_l (.) a_{l+1} (.) dD_l/dz_l = -w0^2 y_l dbar_l a_{l+1}
+//   sbar = (w_sigma . abar_L) s'(1 - s')
+// and stashes what the parameter gradients need:  dW_l += delta_l^T [gbar_PE ; abar_l]  (weight-gradient GEMMs),
+// dw_sigma += s'^T abar_L (skinny), zbar_l and sbar (added to the primal backward chain's pre-activation gradients).
+#include "field_kernels.h"
+
+struct AdjBwdArgs {
+  FieldGeom g;
+  bn_field_params p;
+  PackedLayout pl;
+  StashLayout sl;
+  const void *packed;
+  bn_points pts;
+  const float *d_out;
+  char *stash;
+  int prescaled;   // forward packs carry w0/(2 pi) (bf16 Siren): undo it here
+};
+
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(BN_THREADS, 2) void field_adjbwd_kernel(const AdjBwdArgs A) {
+  typedef typename Elem<T>::vec4 vec4;
+  constexpr int BM = MT * 32;
+  constexpr int PADE = Elem<T>::kPad;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const FieldGeom &g = A.g;
+  const int F = g.F, LDA = F + PADE, KP = g.KP, LDP = KP + PADE, P = g.P;
+  T *ACT = (T *)smem;
+  T *PE = ACT + (size_t)BM * LDA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.pts.n_points;
+  const T *packed = (const T *)A.packed;
+
+  // ---------------------------------------------------------------- dL/dn -> dL/dg -> dL/dg_PE
+  if (tid < BM) {
+    const int64_t gm = m0 + tid;
+    T *row = PE + (size_t)tid * LDP;
+    float gb[3] = {0.f, 0.f, 0.f}, x[3] = {0.f, 0.f, 0.f};
+    if (gm < M) {
+      const float *gx = (const float *)(A.stash + A.sl.gradx) + gm * 4;
+      const float *dn = A.d_out + gm * g.C + g.ch_normal_an;
+      const float n2 = gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2];
+      const float eps = 1.1920928955078125e-07f;
+      const float inv = 1.f / sqrtf(fmaxf(n2, eps));
+      const float gd = gx[0] * dn[0] + gx[1] * dn[1] + gx[2] * dn[2];
+      const float k = n2 > eps ? gd * inv * inv * inv : 0.f;     // n = -g * inv
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gb[c] = -(dn[c] * inv - gx[c] * k);
+      if (A.pts.xyz) {
+        x[0] = A.pts.xyz[gm * 3]; x[1] = A.pts.xyz[gm * 3 + 1]; x[2] = A.pts.xyz[gm * 3 + 2];
+      } else {
+        const float *rr = A.pts.rays + (gm / A.pts.n_samples) * A.pts.ray_stride;
+        const float zz = A.pts.z[gm];
+        x[0] = rr[0] + rr[3] * zz; x[1] = rr[1] + rr[4] * zz; x[2] = rr[2] + rr[5] * zz;
+      }
+    }
+    if (g.pe_freqs > 0) {
+      for (int k = 0; k < g.pe_freqs; ++k) {
+        const float f = (float)(1 << k);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float s, co;
+          sincos_cw(f * x[c], s, co);
+          row[6 * k + c] = (T)(f * co * gb[c]);          // g_c = sum f (cos g_PE[sin] - sin g_PE[cos])
+          row[6 * k + 3 + c] = (T)(-f * s * gb[c]);
+        }
+      }
+      for (int k = P; k < KP; ++k) row[k] = (T)0.f;
+    } else {
+      for (int k = 0; k < KP; ++k) row[k] = (T)(k < 3 ? gb[k] : 0.f);
+    }
+  }
+  __syncthreads();
+  tile_to_global<T>(PE, LDP, (T *)(A.stash + A.sl.gbar_pe) + (size_t)m0 * KP, KP, BM, KP);
+
+  const int ncol0 = wave * 32 * NT;
+  const bool wave_on = ncol0 < F;
+  const int KSP = KP / 16, KSF = F / 16;
+  f32x16 acc[NT][MT];
+  for (int l = 0; l < g.L; ++l) {
+    zero_acc<MT, NT>(acc);
+    if (wave_on) {
+      const size_t t0 = (size_t)(ncol0 / 32);
+      if (l == 0) {
+        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512, KSP, PE, LDP, lane);
+      } else if (l == g.skip) {
+        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512, KSP, PE, LDP, lane);
+        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][1] + t0 * KSF * 512, KSF, ACT, LDA, lane);
+      } else {
+        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][0] + t0 * KSF * 512, KSF, ACT, LDA, lane);
+      }
+    }
+    __syncthreads();
+    if (wave_on) {
+      const float w0 = (l == 0) ? 30.f : 1.f;
+      const float unscale = A.prescaled ? 6.283185307179586f / w0 : 1.f;
+      const float e2 = g.act == BN_ACT_SIN ? -w0 * w0 : 0.f;      // dD/dz = -w0^2 sin(w0 z) = -w0^2 y (0 for ReLU)
+      const T *Ds = (const T *)(A.stash + A.sl.D[l]) + (size_t)tile * BM * F;
+      const T *As = (const T *)(A.stash + A.sl.adj_a[l]) + (size_t)tile * BM * F;
+      const T *Ys = (const T *)(A.stash + A.sl.Y[l]) + (size_t)m0 * F;
+      T *Zs = (T *)(A.stash + A.sl.adj_zbar[l]) + (size_t)tile * BM * F;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const int m = mt * 32 + r;
+            float dv[8], av[8], zb[8], db[8];
+            ld8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dv);
+            ld8(As + native_off8<MT, NT>(wave, nt, mt, gp, lane), av);
+            const vec4 ya = *(const vec4 *)(Ys + (size_t)m * F + n0), yb = *(const vec4 *)(Ys + (size_t)m * F + n0 + 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) db[e] = acc[nt][mt][8 * gp + e] * unscale;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              zb[e] = e2 * (float)ya[e] * db[e] * av[e];
+              zb[4 + e] = e2 * (float)yb[e] * db[4 + e] * av[4 + e];
+            }
+            st8(Zs + native_off8<MT, NT>(wave, nt, mt, gp, lane), zb);
+            *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), db[0] * dv[0], db[1] * dv[1], db[2] * dv[2], db[3] * dv[3]);
+            *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), db[4] * dv[4], db[5] * dv[5], db[6] * dv[6], db[7] * dv[7]);
+          }
+        }
+    }
+    __syncthreads();
+    tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.adj_abar[l + 1]) + (size_t)m0 * F, F, BM, F);
+  }
+
+  // ---------------------------------------------------------------- sbar = (w_sigma . abar_L) s'(1-s')
+  {
+    constexpr int TPR = BN_THREADS / BM;
+    const int m = tid / TPR, q = tid % TPR;
+    float ds = 0.f;
+    const T *row = ACT + (size_t)m * LDA;
+    for (int c8 = q; c8 < F / 8; c8 += TPR) {
+      const typename Elem<T>::frag v = lds_frag<T>(row + c8 * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ds += (float)v[j] * A.p.sigma_w[c8 * 8 + j];
+    }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) ds += __shfl_xor(ds, o);
+    if (q == 0) {
+      const float sp = ((const float *)(A.stash + A.sl.sprime))[m0 + m];
+      ((float *)(A.stash + A.sl.sbar))[m0 + m] = ds * sp * (1.f - sp);
+    }
+  }
+}
+
+template <typename T, int MT, int NT> static int launch_adjbwd(const AdjBwdArgs &a, int64_t tiles, hipStream_t st) {
+  constexpr int BM = MT * 32;
+  const size_t lds = ((size_t)BM * (a.g.F + Elem<T>::kPad) + (size_t)BM * (a.g.KP + Elem<T>::kPad)) * sizeof(T);
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute((const void *)field_adjbwd_kernel<T, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      bn_set_error("field_adjbwd: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
+      return BN_ELAUNCH;
+    }
+    configured = lds;
+  }
+  BnProfScope prof_(BN_K_ADJBWD, st);
+  field_adjbwd_kernel<T, MT, NT><<<dim3((unsigned)tiles), BN_THREADS, lds, st>>>(a);
+  BN_LAUNCH_CHECK("field_adjbwd");
+  return 0;
+}
+
+// called by bn_field_backward() before the primal backward chain when desc->normal_an is set
+int bn_field_adjoint_backward(const bn_field_desc *desc, const bn_field_params *params, const void *packed, const bn_points *pts,
+                              const float *d_out, void *stash, void *stream) {
+  AdjBwdArgs a;
+  if (int e = bn_make_geom(desc, &a.g)) return e;
+  a.p = *params; a.packed = packed; a.pts = *pts; a.d_out = d_out; a.stash = (char *)stash;
+  bn_make_packed_layout(a.g, &a.pl);
+  const bool bf = desc->dtype == BN_BF16;
+  a.prescaled = bf && desc->act == BN_ACT_SIN;
+  const int BM = bf ? 128 : 64;
+  bn_make_stash_layout(a.g, pts->n_points, BM, bf ? 2 : 4, &a.sl);
+  const int64_t tiles = ceil_div64(pts->n_points, BM);
+  hipStream_t st = (hipStream_t)stream;
+  if (bf) return a.g.NT == 2 ? launch_adjbwd<bf16, 4, 2>(a, tiles, st) : launch_adjbwd<bf16, 4, 1>(a, tiles, st);
+  return a.g.NT == 2 ? launch_adjbwd<float, 2, 2>(a, tiles, st) : launch_adjbwd<float, 2, 1>(a, tiles, st);
+}

@@ -18,6 +18,7 @@ struct AdjArgs {
   float *out;       // [M][C]: channels ch_normal_an..+3 are written
   float *grad_x;    // optional [M][3]: raw d sigma / d xyz
   const char *stash;
+  int keep;         // 1: training - also stash delta_l (row-major), a_{l+1} (native), sigmoid(s_raw), grad_x
 };
 
 template <typename T, int MT, int NT>
@@ -37,6 +38,9 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_adjoint_kernel(const AdjA
   const float *sraw = (const float *)(A.stash + A.sl.sraw);
 
   for (int i = tid; i < BM * P; i += BN_THREADS) GP[i] = 0.f;
+  char *wstash = const_cast<char *>(A.stash);
+  const bool keep = A.keep != 0;
+  if (keep && tid < BM) ((float *)(wstash + A.sl.sprime))[m0 + tid] = sigmoid_f(sraw[m0 + tid]);
 
   // delta_{L-1} = (sigmoid(s_raw) w_sigma) (.) D_{L-1}
   if (wave_on) {
@@ -55,8 +59,12 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_adjoint_kernel(const AdjA
           float dv[8];
           ld8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dv);
           const int m = mt * 32 + r;
-          *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), wa[0] * sp[mt] * dv[0], wa[1] * sp[mt] * dv[1], wa[2] * sp[mt] * dv[2], wa[3] * sp[mt] * dv[3]);
-          *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), wb[0] * sp[mt] * dv[4], wb[1] * sp[mt] * dv[5], wb[2] * sp[mt] * dv[6], wb[3] * sp[mt] * dv[7]);
+          float av[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { av[e] = wa[e] * sp[mt]; av[4 + e] = wb[e] * sp[mt]; }
+          if (keep) st8((T *)(wstash + A.sl.adj_a[g.L - 1]) + (size_t)tile * BM * F + native_off8<MT, NT>(wave, nt, mt, gp, lane), av);
+          *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), av[0] * dv[0], av[1] * dv[1], av[2] * dv[2], av[3] * dv[3]);
+          *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), av[4] * dv[4], av[5] * dv[5], av[6] * dv[6], av[7] * dv[7]);
         }
       }
   }
@@ -64,6 +72,7 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_adjoint_kernel(const AdjA
 
   f32x16 acc[NT][MT];
   for (int l = g.L - 1; l >= 0; --l) {
+    if (keep) tile_to_global<T>(ACT, LDA, (T *)(wstash + A.sl.adj_delta[l]) + (size_t)m0 * F, F, BM, F);
     // ACT holds delta_l.  PE-part product (only where the layer reads the encoding): wave -> (p-tile, m-tile)
     if (l == 0 || l == g.skip) {
       const int ptile = wave & 1, mtile = wave >> 1;
@@ -98,6 +107,12 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_adjoint_kernel(const AdjA
             float dv[8];
             ld8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dv);
             const int m = mt * 32 + r;
+            if (keep) {
+              float av[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) av[e] = acc[nt][mt][8 * gp + e];
+              st8((T *)(wstash + A.sl.adj_a[l - 1]) + (size_t)tile * BM * F + native_off8<MT, NT>(wave, nt, mt, gp, lane), av);
+            }
             *(vec4 *)(ACT + (size_t)m * LDA + n0) =
                 to_vec4(T(), acc[nt][mt][8 * gp] * dv[0], acc[nt][mt][8 * gp + 1] * dv[1], acc[nt][mt][8 * gp + 2] * dv[2], acc[nt][mt][8 * gp + 3] * dv[3]);
             *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) =
@@ -137,6 +152,7 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_adjoint_kernel(const AdjA
         gx[0] = gp[0]; gx[1] = gp[1]; gx[2] = gp[2];
       }
       if (A.grad_x) { A.grad_x[gm * 3] = gx[0]; A.grad_x[gm * 3 + 1] = gx[1]; A.grad_x[gm * 3 + 2] = gx[2]; }
+      if (keep) { float *gs = (float *)(wstash + A.sl.gradx) + gm * 4; gs[0] = gx[0]; gs[1] = gx[1]; gs[2] = gx[2]; gs[3] = 0.f; }
       const float inv = -1.f / sqrtf(fmaxf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2], 1.1920928955078125e-07f));
       float *o = A.out + gm * g.C + g.ch_normal_an;
       o[0] = gx[0] * inv; o[1] = gx[1] * inv; o[2] = gx[2] * inv;
@@ -162,14 +178,14 @@ template <typename T, int MT, int NT> static int launch_adj(const AdjArgs &a, in
   return 0;
 }
 
-extern "C" int bn_field_normals(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
-                                const bn_points *pts, const void *stash, float *out, float *grad_x, void *stream) {
+int bn_field_normals_impl(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
+                          const bn_points *pts, const void *stash, float *out, float *grad_x, int keep, void *stream) {
   AdjArgs a;
   if (int e = bn_make_geom(desc, &a.g)) return e;
   BN_REQUIRE(desc->normal_an && a.g.ch_normal_an >= 0, "field_normals: desc.normal_an is not set");
   BN_REQUIRE(desc->act == BN_ACT_SIN || desc->act == BN_ACT_RELU, "field_normals: bad activation");
   BN_REQUIRE(pts && pts->n_points > 0 && packed && stash && out, "field_normals: null argument");
-  a.p = *params; a.packed = packed; a.pts = *pts; a.out = out; a.grad_x = grad_x; a.stash = (const char *)stash;
+  a.p = *params; a.packed = packed; a.pts = *pts; a.out = out; a.grad_x = grad_x; a.stash = (const char *)stash; a.keep = keep;
   bn_make_packed_layout(a.g, &a.pl);
   const bool bf = desc->dtype == BN_BF16;
   const int BM = bf ? 128 : 64;
@@ -178,4 +194,10 @@ extern "C" int bn_field_normals(const bn_field_desc *desc, const bn_field_params
   hipStream_t st = (hipStream_t)stream;
   if (bf) return a.g.NT == 2 ? launch_adj<bf16, 4, 2>(a, tiles, st) : launch_adj<bf16, 4, 1>(a, tiles, st);
   return a.g.NT == 2 ? launch_adj<float, 2, 2>(a, tiles, st) : launch_adj<float, 2, 1>(a, tiles, st);
+}
+
+extern "C" int bn_field_normals(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
+                                const bn_points *pts, const void *stash, float *out, float *grad_x, int32_t keep_for_backward,
+                                void *stream) {
+  return bn_field_normals_impl(desc, params, packed, pts, stash, out, grad_x, keep_for_backward, stream);
 }

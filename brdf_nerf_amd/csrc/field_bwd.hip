@@ -9,6 +9,9 @@
 // Autograd counterpart in the reference: loss.backward() through SpSBRDFNeRF.forward (models/spsbrdfnerf.py:662-757).
 #include "field_kernels.h"
 
+int bn_field_adjoint_backward(const bn_field_desc *desc, const bn_field_params *params, const void *packed, const bn_points *pts,
+                              const float *d_out, void *stash, void *stream);
+
 struct BwdArgs {
   FieldGeom g;
   bn_field_desc d;
@@ -19,6 +22,7 @@ struct BwdArgs {
   int64_t M;
   const float *out, *d_out;
   char *stash;
+  int an;   // analytic normals in the graph: add the adjoint chain's sbar / zbar_l (field_adjbwd.hip)
 };
 
 // sigmoid output y and dL/dy of head `hd`, channel c, recovered from the forward's rescaled output.
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_bwd_kernel(const BwdArgs 
       }
       const float sraw = ((const float *)(A.stash + A.sl.sraw))[gm];
       dpt[0] = dgo[3] * sigmoid_f(sraw);
+      if (A.an) dpt[0] += ((const float *)(A.stash + A.sl.sbar))[gm];
       if (g.ch_normal_lr >= 0) {
         const float *v = (const float *)(A.stash + A.sl.nraw) + gm * 4;
         const float *dn = dgo + g.ch_normal_lr;
@@ -208,8 +213,16 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_bwd_kernel(const BwdArgs 
                 }
               }
             }
-            *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), v[0] * dv[0], v[1] * dv[1], v[2] * dv[2], v[3] * dv[3]);
-            *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), v[4] * dv[4], v[5] * dv[5], v[6] * dv[6], v[7] * dv[7]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= dv[e];
+            if (A.an) {  // + dL/dz_l through D_l of the analytic-normal adjoint chain
+              float zb[8];
+              ld8((const T *)(A.stash + A.sl.adj_zbar[lo]) + (size_t)tile * BM * F + native_off8<MT, NT>(wave, nt, mt, gp, lane), zb);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += zb[e];
+            }
+            *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), v[0], v[1], v[2], v[3]);
+            *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), v[4], v[5], v[6], v[7]);
           }
         }
     }
@@ -550,7 +563,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
                                  const bn_field_grads *G, void *stream) {
   BwdArgs a;
   if (int e = bn_make_geom(desc, &a.g)) return e;
-  BN_REQUIRE(!desc->normal_an, "field_backward: analytic normals not supported by this entry point");
+  a.an = desc->normal_an ? 1 : 0;
   BN_REQUIRE(pts && pts->n_points > 0 && packed && out && d_out && stash && G, "field_backward: null argument");
   const FieldGeom &g = a.g;
   a.d = *desc; a.p = *params; a.packed = packed; a.M = pts->n_points; a.out = out; a.d_out = d_out; a.stash = (char *)stash;
@@ -562,6 +575,10 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   const int64_t tiles = ceil_div64(pts->n_points, BM);
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  if (a.an) {  // double backward of the normals: produces gbar_PE, abar_l, zbar_l, sbar in the stash
+    rc = bn_field_adjoint_backward(desc, params, packed, pts, d_out, stash, stream);
+    if (rc) return rc;
+  }
   if (bf) rc = g.NT == 2 ? launch_bwd<bf16, 4, 2>(a, tiles, st) : launch_bwd<bf16, 4, 1>(a, tiles, st);
   else rc = g.NT == 2 ? launch_bwd<float, 2, 2>(a, tiles, st) : launch_bwd<float, 2, 1>(a, tiles, st);
   if (rc) return rc;
@@ -588,6 +605,16 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     } else add(dZ, F, 0, S + sl.Y[l - 1], F, 0, G->trunk_w[l], F, G->trunk_b[l], F, F);
   }
   add(S + sl.dfeats, F, 0, S + sl.Y[g.L - 1], F, 0, G->feats_w, F, G->feats_b, F, F);
+  if (a.an) {  // dW_l += delta_l^T [gbar_PE ; abar_l]
+    for (int l = 0; l < g.L; ++l) {
+      const void *dl = S + sl.adj_delta[l];
+      if (l == 0) add(dl, F, 0, S + sl.gbar_pe, g.KP, 0, G->trunk_w[l], P0, nullptr, F, P0);
+      else if (l == g.skip) {
+        add(dl, F, 0, S + sl.gbar_pe, g.KP, 0, G->trunk_w[l], F + P0, nullptr, F, P0);
+        add(dl, F, 0, S + sl.adj_abar[l], F, 0, G->trunk_w[l] ? G->trunk_w[l] + P0 : nullptr, F + P0, nullptr, F, F);
+      } else add(dl, F, 0, S + sl.adj_abar[l], F, 0, G->trunk_w[l], F, nullptr, F, F);
+    }
+  }
   for (int hd = 0; hd < g.n_heads; ++hd) {
     const int p = hd / 2, hl = hd % 2;
     add(S + sl.dG[p], g.pass_N[p], hl * g.H2, S + sl.feats, F, 0, G->head_w1[hd], F, G->head_b1[hd], g.H2, F);
@@ -648,6 +675,12 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
       for (int c = 0; c < 3; ++c) { j.out[1 + c] = G->normal_w + (size_t)c * F; j.bias[1 + c] = G->normal_b + c; }
     }
     if (j.out[0]) ++s.n_jobs;
+  }
+  if (a.an && G->sigma_w) {  // dw_sigma += sum_m s'(m) abar_L[m][:]
+    SkinnyJob &j = s.job[s.n_jobs++];
+    j.X = S + sl.adj_abar[g.L]; j.ldx = F; j.x_col0 = 0; j.K = F; j.dpre = (const float *)(S + sl.sprime); j.ldp = 1; j.p_col0 = 0; j.nc = 1;
+    for (int c = 0; c < 4; ++c) { j.out[c] = nullptr; j.bias[c] = nullptr; }
+    j.out[0] = G->sigma_w;
   }
   for (int hd = 0; hd < g.n_heads; ++hd) {
     if (!G->head_w2[hd]) continue;

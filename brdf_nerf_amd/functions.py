@@ -129,9 +129,6 @@ class FieldFunction(torch.autograd.Function):
         out = torch.empty(pts.n_points, spec.out_channels, dtype=torch.float32, device=ref.device)
         need_grad = grad_enabled and any(p.requires_grad for p in params)
         stash = None
-        if need_grad and spec.normal_an:
-            raise NotImplementedError("training through analytic normals needs the double backward of the adjoint chain "
-                                      "(next row, DESIGN.md section 7); run under torch.no_grad() or use --normal learned")
         if need_grad or spec.normal_an:
             nbytes = L.lib().bn_field_stash_bytes(C.byref(spec.desc), pts.n_points)
             stash = torch.empty(nbytes, dtype=torch.uint8, device=ref.device)
@@ -140,8 +137,9 @@ class FieldFunction(torch.autograd.Function):
                                          _stream()), "bn_field_forward")
         if spec.normal_an:
             L.check(L.lib().bn_field_normals(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(stash), _p(out), None,
-                                             _stream()), "bn_field_normals")
-            stash = None
+                                             1 if need_grad else 0, _stream()), "bn_field_normals")
+            if not need_grad:
+                stash = None
         ctx.spec, ctx.packed, ctx.names, ctx.stash = spec, packed, names, stash
         ctx.pts_t = (xyz, rays, z)
         ctx.save_for_backward(out, *params)
@@ -261,6 +259,9 @@ def field_forward_raw(spec, named_params, packed, out, stash, xyz=None, rays=Non
     ps = spec.params_struct(named_params)
     L.check(L.lib().bn_field_forward(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(out), _p(stash), _stream()),
             "bn_field_forward")
+    if spec.normal_an:
+        L.check(L.lib().bn_field_normals(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(stash), _p(out), None, 1,
+                                         _stream()), "bn_field_normals")
     return out
 
 

@@ -119,9 +119,12 @@ int bn_field_forward(const bn_field_desc *desc, const bn_field_params *params, c
                      const bn_points *pts, float *out, void *stash, void *stream);
 /* Analytic normals (calc_normals, models/spsbrdfnerf.py:648-660 and :713-716): fills channels [4,7) of `out` with
  * -l2_normalize(d sigma / d xyz) by the explicit adjoint chain over the stash of a preceding bn_field_forward() call on
- * the same points (desc->normal_an must be 1 in both).  grad_x (nullable) receives the raw gradient [n_points][3]. */
+ * the same points (desc->normal_an must be 1 in both).  grad_x (nullable) receives the raw gradient [n_points][3].
+ * keep_for_backward = 1 also stashes what bn_field_backward needs to differentiate THROUGH the normals (the reference's
+ * create_graph=True double backward). */
 int bn_field_normals(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
-                     const bn_points *pts, const void *stash, float *out, float *grad_x, void *stream);
+                     const bn_points *pts, const void *stash, float *out, float *grad_x, int32_t keep_for_backward,
+                     void *stream);
 /* Parameter gradients from d_out[n_points][out_channels] (autograd of forward, K9 in SURVEY.md).
  * `out` is the forward's output.  grads are accumulated (+=). */
 int bn_field_backward(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
@@ -205,9 +208,10 @@ int bn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
  * bracketed by HIP events on the caller's stream; bn_prof_collect() synchronises them, adds the
  * durations per kernel id (order below) and clears the log.
  * ids: 0 pack, 1 field_fwd(sigma only), 2 field_fwd(full), 3 field_bwd chain, 4 wgrad, 5 skinny
- * wgrad, 6 composite fwd, 7 composite bwd, 8 guided samples, 9 stratified z, 10 adam, 11 brdf, 12 normals adjoint.
+ * wgrad, 6 composite fwd, 7 composite bwd, 8 guided samples, 9 stratified z, 10 adam, 11 brdf, 12 normals adjoint,
+ * 13 normals adjoint backward.
  * ------------------------------------------------------------------------------------------- */
-#define BN_PROF_IDS 13
+#define BN_PROF_IDS 14
 int bn_prof_enable(int on);
 int bn_prof_collect(double *ms_sum, int *count, int n_ids);
 
