@@ -119,7 +119,8 @@ def main():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--guided", type=int, default=64)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--config", default="lambert", choices=["lambert", "rpv_nlr"])
+    ap.add_argument("--config", default="lambert", choices=["lambert", "rpv_nlr", "rpv_nan"],
+                    help="lambert = BASELINE config 2 (headline); rpv_nan = config 3 (RPV + analytic normals); rpv_nlr = learned normals")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -138,8 +139,8 @@ def main():
 
     over = {}
     flags = dict(apply_brdf=False, apply_theta=False, cos_irra_on=False)
-    if a.config == "rpv_nlr":
-        over = dict(funcM=1, funcF=1, funcH=1, normal="learned")
+    if a.config in ("rpv_nlr", "rpv_nan"):
+        over = dict(funcM=1, funcF=1, funcH=1, normal="learned" if a.config == "rpv_nlr" else "analystic")
         flags = dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)
     args = make_args(a.rays, a.samples, a.guided, a.dtype, **over)
     torch.manual_seed(0)
@@ -177,10 +178,16 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    n_heads = 1 + (3 if a.config == "rpv_nlr" else 0)
+    n_heads = 1 + (3 if a.config != "lambert" else 0)
     fpp = flops_per_point(n_heads=n_heads)
+    if a.config == "rpv_nan":       # analytic normals: adjoint chain + its backward (transposed / forward trunk products)
+        F, P, Lh = 512, 60, 8
+        fpp["field_adjoint"] = 2 * ((Lh - 1) * F * F + 2 * P * F)
+        fpp["field_adjoint_bwd"] = 2 * (P * F + (Lh - 2) * F * F + (F + P) * F)
+        fpp["wgrad"] += 2 * (P * F + (Lh - 2) * F * F + (F + P) * F)
     M1, M2 = a.rays * a.samples, a.rays * (a.samples + a.guided)
-    pts = dict(field_fwd_sigma=M1, field_fwd_full=M2, field_bwd_chain=M2, wgrad=M2, skinny_wgrad=M2)
+    pts = dict(field_fwd_sigma=M1, field_fwd_full=M2, field_bwd_chain=M2, wgrad=M2, skinny_wgrad=M2, field_adjoint=M2,
+               field_adjoint_bwd=M2)
     peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
     kernels = {}
     for name, (ms, cnt) in prof.items():
@@ -191,13 +198,13 @@ def main():
         kernels[name] = k
     mfma = {n: k for n, k in kernels.items() if "tflops" in k and n != "skinny_wgrad"}
     dom = max(mfma, key=lambda n: mfma[n]["ms_per_launch"] * mfma[n]["launches_per_step"])
-    flops_step = sum(fpp[n] * pts[n] for n in ("field_fwd_sigma", "field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad"))
+    flops_step = sum(fpp[n] * pts[n] for n in fpp)
     line = {
         "metric": "train rays/sec (+ MFMA% of roofline), spsbrdf-nerf 64 samples/ray, 1/2/4/8 MI355X",
         "value": world * a.rays * a.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
         "data": "synthetic",
-        "config": {"workload": f"BASELINE config 2: Djibouti-shaped synthetic rays, spsbrdf-nerf {a.config} train step "
+        "config": {"workload": f"BASELINE config {3 if a.config == 'rpv_nan' else 2}: Djibouti-shaped synthetic rays, spsbrdf-nerf {a.config} train step "
                                f"(pass1 {a.samples} + guided {a.guided} samples/ray, F=512, 8 Siren layers, PE10, ds_lambda=10), "
                                f"{a.rays} rays/GPU/step", "rays_per_gpu": a.rays, "n_samples": a.samples,
                    "guided_samples": a.guided, "parallelism": f"dp{world}"},

@@ -25,6 +25,7 @@ class FusedTrainer:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
         self.nr_lr = model.normal in ("analystic_learned", "learned")
+        self.nr_an = model.normal in ("analystic_learned", "analystic")
         self._flatten()
         self.steps_a = self.steps_b = 0
         self._bufs = {}
@@ -69,7 +70,7 @@ class FusedTrainer:
         S, G = args.n_samples, args.guided_samples
         R = rays.shape[0]
         dev = rays.device
-        spec = model.spec(apply_brdf, apply_theta, self.nr_lr)
+        spec = model.spec(apply_brdf, apply_theta, self.nr_lr, self.nr_an)
         named = model.named()
         packed = model.repack(spec)
         near, far = rays[:, 6:7], rays[:, 7:8]
