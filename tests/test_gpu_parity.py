@@ -617,3 +617,58 @@ def test_render_rays_train_analytic_normal_golden_fp32(name):
         err = float(np.abs(got - ref).max())
         diag(f"render_{name}_train(an) grad {k}: err {err:.3e} scale {scale:.3e}")
         assert err <= 2e-2 * scale + 1e-9, f"{k}: err {err:.3e} scale {scale:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ fused trainer
+@pytest.mark.parametrize("name,with_depth", [("lambert", False), ("lambert", True), ("rpv111_nlr", True), ("rpv111_nan", False)])
+def test_fused_trainer_matches_autograd_path(name, with_depth):
+    """FusedTrainer.step (the path bench.py times) == render_rays + losses + loss.backward() + torch.optim.Adam, same draws.
+    With depth priors the reference's quirk 7 (target_std == 0) is used, so the ground-truth-guided rows do not depend on
+    their uniform draws (the trainer draws (R,G) instead of (n_valid,G) to avoid a host sync)."""
+    from brdf_nerf_amd import render_rays, losses
+    from brdf_nerf_amd.trainer import FusedTrainer
+    allc = dict(CONFIGS, **CONFIGS_AN)
+    cfg = mini(**allc[name])
+    args = make_args(cfg)
+    g = torch.Generator().manual_seed(3)
+    R, S, G = 96, cfg.n_samples, cfg.guided_samples
+    gold = load_golden("render_lambert_train")
+    rays = torch.from_numpy(gold["rays"])[:R // 2].repeat(2, 1).contiguous().to(DEV)
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    valid = (torch.rand(R, generator=g) < 0.6).float().to(DEV)
+    depths = torch.stack([0.8 + 0.4 * torch.rand(R, generator=g), torch.rand(R, generator=g)], -1).to(DEV)
+    dstd = torch.zeros(R, device=DEV)
+    n_valid = int(valid.sum())
+    draws = [torch.rand(R, S, generator=g), torch.randn(R, S, generator=g), torch.rand(R, G, generator=g)]
+    u_t = torch.rand(R, G, generator=g)
+    draws_ref = list(draws) + ([u_t[:n_valid]] if with_depth else []) + [torch.randn(R, S + G, generator=g)]
+    draws_tr = list(draws) + ([u_t] if with_depth else []) + [draws_ref[-1]]
+    flags = dict(apply_brdf=name != "lambert", apply_theta=True, cos_irra_on=name != "lambert")
+    dk = dict(valid_depth=valid, target_depths=depths, target_std=dstd) if with_depth else {}
+
+    ma = build_model(cfg, 11)
+    opt = torch.optim.Adam(ma.parameters(), lr=5e-4)
+    with Replay(draws_ref):
+        res, _ = render_rays({"coarse": ma}, args, rays, None, mode="train", **flags, **dk)
+    loss_a = losses.snerf_loss(res["rgb_coarse"], rgbs)
+    if with_depth:
+        loss_a = loss_a + losses.depth_loss(res["z_vals_coarse"], res["depth_coarse"], res["weights_coarse"], depths[:, 0],
+                                            depths[:, 1], valid, dstd, 10.0)
+    loss_a.backward()
+    grads_a = {k: v.grad.clone() for k, v in ma.named_parameters() if v.grad is not None}
+    opt.step()
+
+    mb = build_model(cfg, 11)
+    tr = FusedTrainer(mb, args, lr=5e-4, ds_lambda=10.0 if with_depth else 0.0)
+    with Replay(draws_tr):
+        loss_b, _ = tr.step(rays, rgbs, valid_depth=valid if with_depth else None, depths=depths if with_depth else None,
+                            depth_std=dstd if with_depth else None, **flags)
+    assert_close(loss_b, loss_a.detach(), 1e-5, 1e-7, "loss")
+    for k, ga in grads_a.items():
+        gb = tr.grad_views[k]
+        scale = float(ga.abs().max())
+        assert float((gb - ga).abs().max()) <= 1e-4 * scale + 1e-9, f"grad {k}"
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert float((pa - pb).abs().max()) <= 2e-6, f"param {k} after Adam: {float((pa - pb).abs().max()):.3e}"
+    sd = mb.state_dict()                       # flat-buffer views keep the reference's checkpoint contract
+    assert list(sd) == [k for k, _, _ in cfg.param_shapes()]
