@@ -27,6 +27,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3       # fp32-input MFMA
+# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.txt); valid for the
+# default workload only (lambert, 4096 rays, 64+64 samples, bf16), otherwise `traffic` is null
+PMC_TRAFFIC_BYTES = {"field_fwd_full": 10.8e9, "field_bwd_chain": 10.2e9, "wgrad": 14.6e9, "field_fwd_sigma": 0.0}
 
 
 def flops_per_point(F=512, P=60, L=8, n_heads=1):
@@ -209,7 +212,10 @@ def main():
                                f"{a.rays} rays/GPU/step", "rays_per_gpu": a.rays, "n_samples": a.samples,
                    "guided_samples": a.guided, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
-                     "frac": mfma[dom]["tflops"] / peak, "traffic": None},
+                     "frac": mfma[dom]["tflops"] / peak,
+                     "traffic": PMC_TRAFFIC_BYTES.get(dom) if (a.config, a.rays, a.samples, a.guided, a.dtype) ==
+                     ("lambert", 4096, 64, 64, "bf16") else None,
+                     "traffic_unit": "bytes/launch (rocprofv3 PMC, offline pass: profiles/r01_pmc_traffic.txt)"},
         "step_tflops": flops_step / (dt / a.steps) / 1e12, "step_frac_of_peak": flops_step / (dt / a.steps) / 1e12 / peak,
         "kernels": kernels, "final_loss": float(loss),
     }
