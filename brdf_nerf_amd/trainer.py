@@ -16,11 +16,11 @@ from .rendering import shade
 
 class FusedTrainer:
     def __init__(self, model, args, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lambda_rgb=1.0, ds_lambda=0.0,
-                 usealldepth=False, process_group=None, strict_rng=True):
+                 usealldepth=False, process_group=None, strict_rng=True, reuse_coarse=True):
         self.model, self.args = model, args
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.lambda_rgb, self.ds_lambda, self.usealldepth = lambda_rgb, ds_lambda, usealldepth
-        self.pg, self.strict_rng = process_group, strict_rng
+        self.pg, self.strict_rng, self.reuse_coarse = process_group, strict_rng, reuse_coarse
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
@@ -77,12 +77,22 @@ class FusedTrainer:
         rays_d = rays[:, 3:6]
         sun_d = rays[:, 8:11] if args.data == "sat" else torch.ones_like(rays[:, 0:3])
         need_noise = self.strict_rng or args.noise_std != 0
+        C = spec.out_channels
+        S2 = S + G
         with torch.no_grad():
-            # pass 1: sigma only, no stash
             z = Fn.stratified_z(near, far, torch.rand(R, S, device=dev))
             noise1 = torch.randn(R, S, device=dev) if need_noise else None
-            sig = Fn.field_sigma(spec, named, packed, rays=rays, z=z).view(R, S)
-            _, _, w1, d1 = Fn.composite(z, sig, noise1 if args.noise_std != 0 else None, args.noise_std)
+            noise1 = noise1 if args.noise_std != 0 else None
+            if self.reuse_coarse:
+                # pass 1 = FULL forward on the S coarse samples, kept for the backward: the field is a pointwise function
+                # of xyz, so pass 2 only has to evaluate the G new samples (the reference re-evaluates all S+G: same values)
+                out1 = self._buf("out1", (R * S, C))
+                stash1 = self._buf("stash1", (Fn.field_stash_bytes(spec, R * S),), torch.uint8)
+                Fn.field_forward_raw(spec, named, packed, out1, stash1, rays=rays, z=z)
+                _, _, w1, d1, _ = Fn.composite_forward_raw(z, out1.view(R, S, C), noise1, args.noise_std)
+            else:
+                sig = Fn.field_sigma(spec, named, packed, rays=rays, z=z).view(R, S)
+                _, _, w1, d1 = Fn.composite(z, sig, noise1, args.noise_std)
             # depth-guided resampling + merge
             u = torch.rand(R, G, device=dev)
             use_t = tdep = tstd = u_t = trow = None
@@ -98,15 +108,21 @@ class FusedTrainer:
             # the clamp window is the FIRST ray's (near, far) (rendering.py:133); satellite batches share one pair, so
             # callers pass it to avoid a device->host read per step
             near0, far0 = near_far if near_far is not None else (float(rays[0, 6]), float(rays[0, 7]))
-            _, z_all, _ = Fn.guided_samples(z, w1, d1, u, near0, far0, args.std_range, use_t, tdep, tstd, u_t, trow)
-            S2 = S + G
+            z2, z_all, idx = Fn.guided_samples(z, w1, d1, u, near0, far0, args.std_range, use_t, tdep, tstd, u_t, trow)
             noise2 = torch.randn(R, S2, device=dev) if need_noise else None
             noise2 = noise2 if args.noise_std != 0 else None
-            # pass 2: full field with activation stash
-            out = self._buf("out", (R * S2, spec.out_channels))
-            stash = self._buf("stash", (Fn.field_stash_bytes(spec, R * S2),), torch.uint8)
-            Fn.field_forward_raw(spec, named, packed, out, stash, rays=rays, z=z_all)
-            out3 = out.view(R, S2, spec.out_channels)
+            if self.reuse_coarse:
+                out2 = self._buf("out2", (R * G, C))
+                stash2 = self._buf("stash2", (Fn.field_stash_bytes(spec, R * G),), torch.uint8)
+                Fn.field_forward_raw(spec, named, packed, out2, stash2, rays=rays, z=z2)
+                idx_c = idx.unsqueeze(-1).expand(-1, -1, C)
+                out3 = torch.cat([out1.view(R, S, C), out2.view(R, G, C)], 1).gather(1, idx_c)   # depth-sorted order
+            else:
+                # pass 2: full field on all S+G samples with activation stash
+                out = self._buf("out", (R * S2, C))
+                stash = self._buf("stash", (Fn.field_stash_bytes(spec, R * S2),), torch.uint8)
+                Fn.field_forward_raw(spec, named, packed, out, stash, rays=rays, z=z_all)
+                out3 = out.view(R, S2, C)
             alphas, trans, weights, depth, acc = Fn.composite_forward_raw(z_all, out3, noise2, args.noise_std)
         # ray-level loss glue under autograd (leaves: acc, depth, weights)
         acc_l, depth_l, weights_l = acc.requires_grad_(True), depth.requires_grad_(True), weights.requires_grad_(True)
@@ -123,9 +139,15 @@ class FusedTrainer:
                 d_acc[:, 3] = 0
             d_out = Fn.composite_backward_raw(z_all, out3, None if d_weights is None else d_weights.contiguous(),
                                               None if d_depth is None else d_depth.contiguous(), d_acc, noise2, args.noise_std,
-                                              self._buf("d_out", tuple(out3.shape)))
+                                              self._buf("d_out", (R, S2, C)))
             self.flat_grad.zero_()
-            Fn.field_backward_raw(spec, named, self.grad_views, packed, out, d_out.view(R * S2, -1), stash, rays=rays, z=z_all)
+            if self.reuse_coarse:
+                d_cat = self._buf("d_cat", (R, S2, C)).scatter_(1, idx_c, d_out)             # back to [coarse | guided] order
+                d1o, d2o = d_cat[:, :S].contiguous().view(R * S, C), d_cat[:, S:].contiguous().view(R * G, C)
+                Fn.field_backward_raw(spec, named, self.grad_views, packed, out1, d1o, stash1, rays=rays, z=z)
+                Fn.field_backward_raw(spec, named, self.grad_views, packed, out2, d2o, stash2, rays=rays, z=z2)
+            else:
+                Fn.field_backward_raw(spec, named, self.grad_views, packed, out, d_out.view(R * S2, C), stash, rays=rays, z=z_all)
             if self.world > 1:
                 torch.distributed.all_reduce(self.flat_grad, group=self.pg)   # RCCL over xGMI: one ~10 MB buffer
             self._adam(apply_brdf)

@@ -672,3 +672,33 @@ def test_fused_trainer_matches_autograd_path(name, with_depth):
         assert float((pa - pb).abs().max()) <= 2e-6, f"param {k} after Adam: {float((pa - pb).abs().max()):.3e}"
     sd = mb.state_dict()                       # flat-buffer views keep the reference's checkpoint contract
     assert list(sd) == [k for k, _, _ in cfg.param_shapes()]
+
+
+@pytest.mark.parametrize("name", ["lambert", "rpv111_nan"])
+def test_trainer_coarse_reuse_equals_full_reevaluation(name):
+    """reuse_coarse=True (pass-1 evaluation kept, pass 2 only on the guided samples) must give the reference pipeline's
+    result (pass 2 re-evaluates all S+G samples): same loss and gradients, step after step."""
+    from brdf_nerf_amd.trainer import FusedTrainer
+    allc = dict(CONFIGS, **CONFIGS_AN)
+    cfg = mini(**allc[name])
+    args = make_args(cfg)
+    g = torch.Generator().manual_seed(5)
+    R, S, G = 160, cfg.n_samples, cfg.guided_samples
+    rays = torch.from_numpy(load_golden("render_lambert_train")["rays"])[:32].repeat(5, 1).contiguous().to(DEV)
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    flags = dict(apply_brdf=name != "lambert", apply_theta=True, cos_irra_on=name != "lambert")
+    steps = [[torch.rand(R, S, generator=g), torch.randn(R, S, generator=g), torch.rand(R, G, generator=g),
+              torch.randn(R, S + G, generator=g)] for _ in range(2)]
+    out = {}
+    for reuse in (True, False):
+        tr = FusedTrainer(build_model(cfg, 11), args, lr=5e-4, reuse_coarse=reuse)
+        rec = []
+        for draws in steps:
+            with Replay(list(draws)):
+                loss, rgb = tr.step(rays, rgbs, near_far=(0.0, 2.0), **flags)
+            rec.append((float(loss), tr.flat_grad.clone()))
+        out[reuse] = rec
+    for (la, ga), (lb, gb) in zip(out[True], out[False]):
+        assert abs(la - lb) <= 2e-4 * abs(lb) + 1e-7, (la, lb)
+    ga, gb = out[True][0][1], out[False][0][1]
+    assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max()) + 1e-9
