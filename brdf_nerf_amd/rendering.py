@@ -203,8 +203,21 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
     packed = model.repack(spec)
 
     z_vals = get_z_vals(S, rays.device, near, far)
-    res1, _ = inference(model, args, None, z_vals, rays_d=rays_d, sun_d=sun_d, mode=mode, sigma_only=True, _rays=rays,
-                        _packed=packed)
+    C = spec.out_channels
+    noise_on = args.noise_std != 0
+    if gsam_only:
+        # only the guided samples are rendered: pass 1 just guides them (sigma only, no autograd)
+        res1, _ = inference(model, args, None, z_vals, rays_d=rays_d, sun_d=sun_d, mode=mode, sigma_only=True, _rays=rays,
+                            _packed=packed)
+        w1, d1, out1 = res1["weights"], res1["depth"], None
+    else:
+        # The field is a pointwise function of xyz: the S coarse samples are evaluated ONCE, in full, and reused in the
+        # merged pass-2 set (the reference evaluates them twice - sigma only, then again among the S+G samples - with
+        # the same values).  Pass-1 compositing stays detached, as upstream (rendering.py:262).
+        noise1 = torch.randn(R, S, device=rays.device)
+        out1 = model.evaluate(spec, packed, rays=rays, z=z_vals).view(R, S, C)
+        with torch.no_grad():
+            _, _, w1, d1, _ = Fn.composite_forward_raw(z_vals, out1.detach(), noise1 if noise_on else None, args.noise_std)
     # guided samples around the pass-1 depth (or the ground-truth depth prior in training)
     u = torch.rand(R, G, device=rays.device)
     use_t = tdep = tstd = u_t = trow = None
@@ -218,14 +231,18 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
             tstd = target_std.float().reshape(-1).contiguous()
             trow = (torch.cumsum(valid.int(), 0) - 1).clamp_min(0).int().contiguous()
     with torch.no_grad():
-        z2, z_all, idx = Fn.guided_samples(z_vals, res1["weights"], res1["depth"], u, float(near[0, 0]), float(far[0, 0]),
-                                           args.std_range, use_t, tdep, tstd, u_t, trow, merge=not gsam_only)
+        z2, z_all, idx = Fn.guided_samples(z_vals, w1, d1, u, float(near[0, 0]), float(far[0, 0]), args.std_range, use_t, tdep,
+                                           tstd, u_t, trow, merge=not gsam_only)
     if gsam_only:
-        z_unsort, z_all, idx = z2, z2, None
-    else:
-        z_unsort = torch.cat([z_vals, z2], -1)
-    result, brdf_type = inference(model, args, None, z_all, rays_d=rays_d, sun_d=sun_d, z_vals_unsort=z_unsort,
-                                  apply_brdf=apply_brdf, bTestNormal=bTestNormal, sun_res={}, sort_idx=idx, mode=mode,
-                                  apply_theta=apply_theta,
-                                  cos_irra_on=cos_irra_on, _rays=rays, _packed=packed)
+        result, brdf_type = inference(model, args, None, z2, rays_d=rays_d, sun_d=sun_d, z_vals_unsort=z2, apply_brdf=apply_brdf,
+                                      bTestNormal=bTestNormal, sun_res={}, sort_idx=None, mode=mode, apply_theta=apply_theta,
+                                      cos_irra_on=cos_irra_on, _rays=rays, _packed=packed)
+        return {f"{k}_coarse": v for k, v in result.items()}, brdf_type
+    z_unsort = torch.cat([z_vals, z2], -1)
+    out2 = model.evaluate(spec, packed, rays=rays, z=z2).view(R, G, C)
+    out = torch.cat([out1, out2], 1).gather(1, idx.unsqueeze(-1).expand(-1, -1, C))      # depth-sorted order
+    noise2 = torch.randn(R, S + G, device=rays.device)
+    alphas, transparency, weights, depth, acc = Fn.composite(z_all, out, noise2 if noise_on else None, args.noise_std)
+    result, brdf_type = shade(model, args, spec, out, z_all, alphas, transparency, weights, depth, acc, rays_d, sun_d, apply_brdf,
+                              cos_irra_on, idx, z_unsort)
     return {f"{k}_coarse": v for k, v in result.items()}, brdf_type
