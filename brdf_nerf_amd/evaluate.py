@@ -1,0 +1,48 @@
+"""Evaluation-side callers of the path (reference: eval.py:26-105).
+
+  batched_inference  eval.py:56-76   chunked no-grad render_rays, per-chunk dicts concatenated
+  load_ckpt / extract_model_state_dict  eval.py:26-54  Lightning checkpoint -> module state_dict (prefix stripping)
+"""
+from collections import defaultdict
+
+import torch
+
+from .rendering import render_rays
+
+
+@torch.no_grad()
+def batched_inference(models, rays, ts, args, mode="test", apply_brdf=False, apply_theta=False, cos_irra_on=False, **kw):
+    chunk = args.chunk
+    results = defaultdict(list)
+    for i in range(0, rays.shape[0], chunk):
+        out, _ = render_rays(models, args, rays[i:i + chunk], None if ts is None else ts[i:i + chunk], mode=mode,
+                             apply_brdf=apply_brdf, apply_theta=apply_theta, cos_irra_on=cos_irra_on, **kw)
+        for k, v in out.items():
+            results[k].append(v)
+    return {k: torch.cat(v, 0) for k, v in results.items()}
+
+
+def extract_model_state_dict(ckpt_path, model_name="model", prefixes_to_ignore=(), drop_len=-1):
+    """eval.py:26-47: keep the entries whose key starts with `model_name` and drop the first drop_len+1 characters
+    (drop_len = len(model_name) by default; main.py:97-104 passes 'nerf_coarse.<sub>' with drop_len=11 for partial warm starts)."""
+    checkpoint = torch.load(ckpt_path, map_location="cpu")
+    sd = checkpoint["state_dict"] if "state_dict" in checkpoint else checkpoint
+    if drop_len < 0:
+        drop_len = len(model_name)
+    out = {}
+    for k, v in sd.items():
+        if not k.startswith(model_name):
+            continue
+        k2 = k[drop_len + 1:]
+        if any(k2.startswith(p) for p in prefixes_to_ignore):
+            continue
+        out[k2] = v
+    return out
+
+
+def load_ckpt(model, ckpt_path, model_name="model", prefixes_to_ignore=(), drop_len=-1):
+    """eval.py:49-54: partial load (strict=False semantics of updating the model's own state_dict)."""
+    sd = model.state_dict()
+    sd.update(extract_model_state_dict(ckpt_path, model_name, prefixes_to_ignore, drop_len))
+    model.load_state_dict(sd)
+    return model

@@ -315,6 +315,17 @@ def gen_render(ref):
                     arrays[f"grad/{k}"] = p.grad if p.grad is not None else torch.zeros_like(p)
             save(f"render_{name}_{mode}", rays=rays, brdf_type=np.array(brdf_type), param_checksum=csum, param_seed=11,
                  **{f"tgt/{k}": v for k, v in targets.items()}, **arrays)
+    # per-sample BRDF (MultiBRDF=1) and guided-samples-only (gsam_only) variants, test mode
+    # (Hapke + theta with MultiBRDF raises IndexError inside the reference's mu0_eff: not a usable configuration)
+    for tag, extra, gs in (("rpv111_nlr_multibrdf", dict(MultiBRDF=True), False), ("rpv111_nlr_gsamonly", dict(), True)):
+        base = "rpv111_nlr" if tag.startswith("rpv") else "hapke_bct"
+        cfg = mini(**dict(CONFIGS[base], **extra))
+        model, csum = build_ref_model(ref, cfg, seed=11)
+        res, brdf_type, rlog = run_render(ref, cfg, model, rays, "test", dict(apply_brdf=True, apply_theta=True, cos_irra_on=True,
+                                                                               gsam_only=gs))
+        arrays = {f"out/{k}": v for k, v in res.items()}
+        arrays.update({f"rand{i}": t for i, t in enumerate(rlog)})
+        save(f"render_{tag}_test", rays=rays, brdf_type=np.array(brdf_type), param_checksum=csum, param_seed=11, **arrays)
     # full-size network, forward only
     cfg = FieldConfig(**CONFIGS["rpv111_nan"])
     model, csum = build_ref_model(ref, cfg, seed=12)
@@ -368,6 +379,9 @@ def gen_loss(ref):
 if __name__ == "__main__":
     torch.set_num_threads(4)
     ref = import_reference()
+    if "--only-render" in sys.argv:
+        gen_render(ref)
+        sys.exit(0)
     gen_field(ref)
     gen_composite(ref)
     gen_guided(ref)

@@ -178,3 +178,29 @@ def test_gradient_sync_world2_gloo(tmp_path):
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_checkpoint_prefix_round_trip(tmp_path):
+    """Lightning-style checkpoint -> module (eval.py:26-54) and the stage-2 partial warm start (main.py:97-104)."""
+    from brdf_nerf_amd import load_model
+    from brdf_nerf_amd.evaluate import load_ckpt
+    cfg1 = FieldConfig(feat=64)
+    m1 = load_model(make_args(cfg1))
+    ckpt = {"state_dict": {f"nerf_coarse.{k}": v.clone() for k, v in m1.state_dict().items()}, "epoch": 9}
+    path = tmp_path / "epoch=9.ckpt"
+    torch.save(ckpt, path)
+    m2 = load_model(make_args(cfg1))
+    load_ckpt(m2, str(path), model_name="nerf_coarse")
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    # stage 2: RPV heads are new, the Lambertian sub-modules are warm-started by prefix with drop_len=11
+    cfg2 = FieldConfig(feat=64, funcM=1, funcF=1, funcH=1, normal="learned")
+    m3 = load_model(make_args(cfg2))
+    before = {k: v.clone() for k, v in m3.state_dict().items()}
+    for sub in ("fc_net", "sigma_from_xyz", "feats_from_xyz", "rgb_from_xyzdir"):
+        load_ckpt(m3, str(path), model_name=f"nerf_coarse.{sub}", drop_len=11)
+    for k, v in m3.state_dict().items():
+        if k in m1.state_dict():
+            assert torch.equal(v, m1.state_dict()[k]), k
+        else:
+            assert torch.equal(v, before[k]), k

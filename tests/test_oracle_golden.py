@@ -220,3 +220,19 @@ def test_losses():
     (l_rgb + l_ds).backward()
     assert_close(rgb.grad, g["drgb"], 1e-6, 1e-9, "drgb")
     assert_close(depth.grad, g["ddepth"], 1e-6, 1e-9, "ddepth")
+
+
+@pytest.mark.parametrize("tag,extra,gs", [("rpv111_nlr_multibrdf", dict(MultiBRDF=True), False), ("rpv111_nlr_gsamonly", dict(), True)])
+def test_render_variants_multibrdf_gsamonly(tag, extra, gs):
+    g = load_golden(f"render_{tag}_test")
+    cfg = mini(**dict(CONFIGS["rpv111_nlr"], **extra))
+    res, bt = RD.render_rays(tparams(cfg, 11), cfg, torch.from_numpy(g["rays"]), RD.Randoms(replay=replay_list(g)), mode="test",
+                             apply_brdf=True, apply_theta=True, cos_irra_on=True, gsam_only=gs)
+    assert bt == str(g["brdf_type"])
+    ref_keys = {k[4:] for k in g if k.startswith("out/")}
+    assert ref_keys == {k for k in res if not k.startswith("_")}
+    for k in sorted(ref_keys):
+        if k == "sort_idx_coarse":
+            assert np.array_equal(res[k].numpy(), g["out/" + k])
+        else:
+            assert_close(res[k], g["out/" + k], 2e-4, 2e-5, k)
