@@ -9,7 +9,8 @@ struct FieldGeom {
   int F, L, skip, pe_freqs, act;
   int P;        // valid trunk input width: 6*pe_freqs, or 3 without mapping
   int KP;       // P rounded up to 64 (60 -> 64, 3 -> 64): k-extent of the PE operand (4 MFMA k-steps)
-  int NT;       // 32-column tiles per wave in the F-wide phases (F=512: 2, else 1)
+  int NT;       // 32-column tiles per wave in the F-wide phases
+  int BM, waves; // points per workgroup tile, waves per workgroup (tile configuration, bn_tile_config)
   int H2;       // head hidden width F/2
   int n_heads, n_pass;
   int pass_heads[BN_MAX_PASS];  // heads evaluated in pass p (2 or 1)
@@ -19,6 +20,15 @@ struct FieldGeom {
   int C;                        // out channels
   int ch_normal_an, ch_normal_lr;  // channel index or -1
 };
+
+// Tile configuration of the fused chain kernels: 8 waves per workgroup, one workgroup per CU (2 waves per SIMD);
+// 64 points per tile in fp32 (parity mode), 128 in bf16.  A measured alternative - 64 points x 4 waves, two
+// workgroups per CU running out of phase - lost 20 % (r01): each workgroup streams the full weight set from L2, so
+// halving the tile doubles the L2->CU weight traffic per flop, which costs more than the phase overlap wins.
+static inline void bn_tile_config(int dtype, int *BM, int *waves) {
+  *BM = dtype == BN_BF16 ? 128 : 64;
+  *waves = 8;
+}
 
 static inline int bn_make_geom(const bn_field_desc *d, FieldGeom *g) {
   BN_REQUIRE(d->feat >= 64 && d->feat <= 512 && d->feat % 64 == 0 && (d->feat == 512 || d->feat <= 256),
@@ -30,7 +40,11 @@ static inline int bn_make_geom(const bn_field_desc *d, FieldGeom *g) {
   g->F = d->feat; g->L = d->layers; g->skip = d->skip; g->pe_freqs = d->pe_freqs; g->act = d->act;
   g->P = d->pe_freqs > 0 ? 6 * d->pe_freqs : 3;
   g->KP = (g->P + 63) / 64 * 64;
-  g->NT = d->feat == 512 ? 2 : 1;
+  bn_tile_config(d->dtype, &g->BM, &g->waves);
+  {
+    const int per = (d->feat + 32 * g->waves - 1) / (32 * g->waves);   // 32-column tiles each wave must cover
+    g->NT = per <= 1 ? 1 : (per <= 2 ? 2 : 4);
+  }
   g->H2 = d->feat / 2;
   g->n_heads = d->n_heads;
   g->n_pass = (d->n_heads + 1) / 2;
@@ -51,7 +65,7 @@ static inline int bn_make_geom(const bn_field_desc *d, FieldGeom *g) {
   for (int p = 0; p < g->n_pass; ++p) {
     g->pass_heads[p] = (d->n_heads - 2 * p) >= 2 ? 2 : 1;
     g->pass_N[p] = g->pass_heads[p] * g->H2;
-    g->pass_NTW[p] = g->pass_heads[p] == 2 ? g->NT : (g->NT == 2 ? 1 : 1);
+    g->pass_NTW[p] = g->pass_heads[p] == 2 ? g->NT : (g->NT > 1 ? g->NT / 2 : 1);
   }
   return 0;
 }

@@ -24,8 +24,8 @@ struct AdjBwdArgs {
   int prescaled;   // forward packs carry w0/(2 pi) (bf16 Siren): undo it here
 };
 
-template <typename T, int MT, int NT>
-__global__ __launch_bounds__(BN_THREADS, 2) void field_adjbwd_kernel(const AdjBwdArgs A) {
+template <typename T, int MT, int NT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBwdArgs A) {
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
   constexpr int PADE = Elem<T>::kPad;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_adjbwd_kernel(const AdjBw
 
   // ---------------------------------------------------------------- sbar = (w_sigma . abar_L) s'(1-s')
   {
-    constexpr int TPR = BN_THREADS / BM;
+    constexpr int TPR = (WAVES * 64) / BM;
     const int m = tid / TPR, q = tid % TPR;
     float ds = 0.f;
     const T *row = ACT + (size_t)m * LDA;
@@ -155,12 +155,12 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_adjbwd_kernel(const AdjBw
   }
 }
 
-template <typename T, int MT, int NT> static int launch_adjbwd(const AdjBwdArgs &a, int64_t tiles, hipStream_t st) {
+template <typename T, int MT, int NT, int WAVES> static int launch_adjbwd(const AdjBwdArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = ((size_t)BM * (a.g.F + Elem<T>::kPad) + (size_t)BM * (a.g.KP + Elem<T>::kPad)) * sizeof(T);
   static size_t configured = 0;
   if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)field_adjbwd_kernel<T, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)field_adjbwd_kernel<T, MT, NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       bn_set_error("field_adjbwd: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
       return BN_ELAUNCH;
@@ -168,7 +168,7 @@ template <typename T, int MT, int NT> static int launch_adjbwd(const AdjBwdArgs 
     configured = lds;
   }
   BnProfScope prof_(BN_K_ADJBWD, st);
-  field_adjbwd_kernel<T, MT, NT><<<dim3((unsigned)tiles), BN_THREADS, lds, st>>>(a);
+  field_adjbwd_kernel<T, MT, NT, WAVES><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_adjbwd");
   return 0;
 }
@@ -182,10 +182,9 @@ int bn_field_adjoint_backward(const bn_field_desc *desc, const bn_field_params *
   bn_make_packed_layout(a.g, &a.pl);
   const bool bf = desc->dtype == BN_BF16;
   a.prescaled = bf && desc->act == BN_ACT_SIN;
-  const int BM = bf ? 128 : 64;
+  const int BM = a.g.BM;
   bn_make_stash_layout(a.g, pts->n_points, BM, bf ? 2 : 4, &a.sl);
   const int64_t tiles = ceil_div64(pts->n_points, BM);
   hipStream_t st = (hipStream_t)stream;
-  if (bf) return a.g.NT == 2 ? launch_adjbwd<bf16, 4, 2>(a, tiles, st) : launch_adjbwd<bf16, 4, 1>(a, tiles, st);
-  return a.g.NT == 2 ? launch_adjbwd<float, 2, 2>(a, tiles, st) : launch_adjbwd<float, 2, 1>(a, tiles, st);
+  BN_DISPATCH_TILE(desc->dtype, a.g, launch_adjbwd, (a, tiles, st));
 }

@@ -21,8 +21,8 @@ struct AdjArgs {
   int keep;         // 1: training - also stash delta_l (row-major), a_{l+1} (native), sigmoid(s_raw), grad_x
 };
 
-template <typename T, int MT, int NT>
-__global__ __launch_bounds__(BN_THREADS, 2) void field_adjoint_kernel(const AdjArgs A) {
+template <typename T, int MT, int NT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjArgs A) {
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_adjoint_kernel(const AdjA
   const bool wave_on = ncol0 < F;
   const float *sraw = (const float *)(A.stash + A.sl.sraw);
 
-  for (int i = tid; i < BM * P; i += BN_THREADS) GP[i] = 0.f;
+  for (int i = tid; i < BM * P; i += WAVES * 64) GP[i] = 0.f;
   char *wstash = const_cast<char *>(A.stash);
   const bool keep = A.keep != 0;
   if (keep && tid < BM) ((float *)(wstash + A.sl.sprime))[m0 + tid] = sigmoid_f(sraw[m0 + tid]);
@@ -160,12 +160,12 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_adjoint_kernel(const AdjA
   }
 }
 
-template <typename T, int MT, int NT> static int launch_adj(const AdjArgs &a, int64_t tiles, hipStream_t st) {
+template <typename T, int MT, int NT, int WAVES> static int launch_adj(const AdjArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = (size_t)BM * (a.g.F + Elem<T>::kPad) * sizeof(T) + (size_t)BM * a.g.P * sizeof(float);
   static size_t configured = 0;
   if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)field_adjoint_kernel<T, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)field_adjoint_kernel<T, MT, NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       bn_set_error("field_normals: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
       return BN_ELAUNCH;
@@ -173,7 +173,7 @@ template <typename T, int MT, int NT> static int launch_adj(const AdjArgs &a, in
     configured = lds;
   }
   BnProfScope prof_(BN_K_ADJOINT, st);
-  field_adjoint_kernel<T, MT, NT><<<dim3((unsigned)tiles), BN_THREADS, lds, st>>>(a);
+  field_adjoint_kernel<T, MT, NT, WAVES><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_normals");
   return 0;
 }
@@ -188,12 +188,11 @@ int bn_field_normals_impl(const bn_field_desc *desc, const bn_field_params *para
   a.p = *params; a.packed = packed; a.pts = *pts; a.out = out; a.grad_x = grad_x; a.stash = (const char *)stash; a.keep = keep;
   bn_make_packed_layout(a.g, &a.pl);
   const bool bf = desc->dtype == BN_BF16;
-  const int BM = bf ? 128 : 64;
+  const int BM = a.g.BM;
   bn_make_stash_layout(a.g, pts->n_points, BM, bf ? 2 : 4, &a.sl);
   const int64_t tiles = ceil_div64(pts->n_points, BM);
   hipStream_t st = (hipStream_t)stream;
-  if (bf) return a.g.NT == 2 ? launch_adj<bf16, 4, 2>(a, tiles, st) : launch_adj<bf16, 4, 1>(a, tiles, st);
-  return a.g.NT == 2 ? launch_adj<float, 2, 2>(a, tiles, st) : launch_adj<float, 2, 1>(a, tiles, st);
+  BN_DISPATCH_TILE(desc->dtype, a.g, launch_adj, (a, tiles, st));
 }
 
 extern "C" int bn_field_normals(const bn_field_desc *desc, const bn_field_params *params, const void *packed,

@@ -12,6 +12,8 @@
 int bn_field_adjoint_backward(const bn_field_desc *desc, const bn_field_params *params, const void *packed, const bn_points *pts,
                               const float *d_out, void *stash, void *stream);
 
+BN_PH_DEFINE_READER(bn_debug_phase_read_bwd)
+
 struct BwdArgs {
   FieldGeom g;
   bn_field_desc d;
@@ -82,8 +84,8 @@ __device__ __forceinline__ void bwd_head_dG(const BwdArgs &A, int p, T *ACT, con
     }
 }
 
-template <typename T, int MT, int NT>
-__global__ __launch_bounds__(BN_THREADS, 2) void field_bwd_kernel(const BwdArgs A) {
+template <typename T, int MT, int NT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs A) {
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_bwd_kernel(const BwdArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.M;
   const T *packed = (const T *)A.packed;
+  BN_PH_DECL
 
   // ---------------------------------------------------------------- pre-activation gradients of the small outputs
   if (tid < BM) {
@@ -138,21 +141,30 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_bwd_kernel(const BwdArgs 
     for (int i = 0; i < 4; ++i) { DPT[m * 4 + i] = dpt[i]; st[i] = dpt[i]; }
   }
   __syncthreads();
+  BN_PH(0)
 
   const int ncol0 = wave * 32 * NT;
   const bool wave_on = ncol0 < F;
+  const int n_on = F / (32 * NT) < WAVES ? F / (32 * NT) : WAVES;   // waves that own output columns
+  // stash copies ride inside the GEMMs when the shape fits (NT == 2 means F = 512: always, decided at compile time)
+  const bool ride = NT == 2 ? true : tile_copy_exact(F, n_on, WAVES);
   f32x16 acc[NT][MT];
   zero_acc<MT, NT>(acc);
 
   // ---------------------------------------------------------------- heads: dG -> LDS, dFeats += W1^T dG
   for (int p = 0; p < g.n_pass; ++p) {
     if (g.pass_heads[p] == 2) bwd_head_dG<T, MT, NT>(A, p, ACT, DPH, m0, tile);
-    else bwd_head_dG<T, MT, 1>(A, p, ACT, DPH, m0, tile);
+    else bwd_head_dG<T, MT, (NT > 1 ? NT / 2 : 1)>(A, p, ACT, DPH, m0, tile);
+    BN_PH(1)
     __syncthreads();
-    tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dG[p]) + (size_t)m0 * g.pass_N[p], g.pass_N[p], BM, g.pass_N[p]);
+    BN_PH(2)
+    BN_PH(3)
     const int KSp = g.pass_N[p] / 16;
+    tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dG[p]) + (size_t)m0 * g.pass_N[p], g.pass_N[p], BM, g.pass_N[p]);
     if (wave_on) gemm_seg<T, MT, NT>(acc, packed + A.pl.bwd_head[p] + (size_t)(ncol0 / 32) * KSp * 512, KSp, ACT, LDA, lane);
+    BN_PH(4)
     __syncthreads();
+    BN_PH(5)
   }
   // dFeats -> LDS (+ stash below)
   if (wave_on) {
@@ -169,21 +181,47 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_bwd_kernel(const BwdArgs 
         }
       }
   }
+  BN_PH(6)
   __syncthreads();
-  tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dfeats) + (size_t)m0 * F, F, BM, F);
+  BN_PH(7)
+  BN_PH(8)
 
   // ---------------------------------------------------------------- trunk, top layer first
   for (int l = g.L; l >= 1; --l) {
     // l == L: dY_{L-1} = Wf^T dFeats + sigma/normal rank-1 terms; else dY_{l-1} = W_l^T dZ_l
     zero_acc<MT, NT>(acc);
+    const int lo = l - 1;  // layer whose pre-activation gradient is produced
+    // D_lo = d act / d z of that layer, read back in accumulator order.  The loads are issued around the GEMM -
+    // n-tile 0 before it (in flight while the MFMAs run), the others right after its last MFMA, when the weight and
+    // activation fragment registers are free - so the epilogue does not sit on HBM latency.
+    const T *Ds = (const T *)(A.stash + A.sl.D[lo]) + (size_t)tile * BM * F;
+    typename Elem<T>::frag dpre[NT][2][MT];
+    T *zdst = (T *)(A.stash + (l == g.L ? A.sl.dfeats : A.sl.dZ[l])) + (size_t)m0 * F;
+    if (!ride) tile_to_global<T>(ACT, LDA, zdst, F, BM, F);
     if (wave_on) {
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) dpre[0][gp][mt] = stash_load((const typename Elem<T>::frag *)(Ds + native_off8<MT, NT>(wave, 0, mt, gp, lane)));
       const size_t off = (l == g.L ? A.pl.bwd_feats : A.pl.bwd_trunk[l]) + (size_t)(ncol0 / 32) * KSF * 512;
-      gemm_seg<T, MT, NT>(acc, packed + off, KSF, ACT, LDA, lane);
+      // the row-major stash copy of the tile this GEMM reads (dFeats, then dZ_l) rides inside the GEMM
+      if (ride) {
+        TileCopyExact<T> zcopy(ACT, LDA, zdst, F, F, tid, WAVES * 64);
+        gemm_seg<T, MT, NT>(acc, packed + off, KSF, ACT, LDA, lane, zcopy);
+      } else {
+        gemm_seg<T, MT, NT>(acc, packed + off, KSF, ACT, LDA, lane);
+      }
+#pragma unroll
+      for (int nt = 1; nt < NT; ++nt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) dpre[nt][gp][mt] = stash_load((const typename Elem<T>::frag *)(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane)));
     }
+    BN_PH(9)
     __syncthreads();
+    BN_PH(10)
     if (wave_on) {
-      const int lo = l - 1;  // layer whose pre-activation gradient is produced
-      const T *Ds = (const T *)(A.stash + A.sl.D[lo]) + (size_t)tile * BM * F;
       const bool top = l == g.L, nlr = g.ch_normal_lr >= 0;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
@@ -194,9 +232,8 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_bwd_kernel(const BwdArgs 
           for (int mt = 0; mt < MT; ++mt) {
             const int m = mt * 32 + r;
             float dv[8], v[8];
-            ld8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = acc[nt][mt][8 * gp + e];
+            for (int e = 0; e < 8; ++e) { dv[e] = (float)dpre[nt][gp][mt][e]; v[e] = acc[nt][mt][8 * gp + e]; }
             if (top) {  // rank-1 terms of the sigma head and the learned-normal head
               const float ds = DPT[m * 4], a0 = DPT[m * 4 + 1], a1 = DPT[m * 4 + 2], a2 = DPT[m * 4 + 3];
 #pragma unroll
@@ -226,9 +263,13 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_bwd_kernel(const BwdArgs 
           }
         }
     }
+    BN_PH(11)
     __syncthreads();
-    tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dZ[l - 1]) + (size_t)m0 * F, F, BM, F);
+    BN_PH(12)
   }
+  tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dZ[0]) + (size_t)m0 * F, F, BM, F);
+  BN_PH(13)
+  BN_PH_FLUSH
 }
 
 // ------------------------------------------------------------------------------------------ weight gradients
@@ -540,12 +581,12 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
   if (tid < J.nc && J.bias[tid]) atomicAdd(J.bias[tid], red[4 * 512 + tid]);
 }
 
-template <typename T, int MT, int NT> static int launch_bwd(const BwdArgs &a, int64_t tiles, hipStream_t st) {
+template <typename T, int MT, int NT, int WAVES> static int launch_bwd(const BwdArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = (size_t)BM * (a.g.F + Elem<T>::kPad) * sizeof(T) + (size_t)BM * 16 * sizeof(float);
   static size_t configured = 0;
   if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)field_bwd_kernel<T, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)field_bwd_kernel<T, MT, NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       bn_set_error("field_bwd: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
       return BN_ELAUNCH;
@@ -553,7 +594,7 @@ template <typename T, int MT, int NT> static int launch_bwd(const BwdArgs &a, in
     configured = lds;
   }
   BnProfScope prof_(BN_K_BWD_CHAIN, st);
-  field_bwd_kernel<T, MT, NT><<<dim3((unsigned)tiles), BN_THREADS, lds, st>>>(a);
+  field_bwd_kernel<T, MT, NT, WAVES><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_bwd");
   return 0;
 }
@@ -569,7 +610,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   a.d = *desc; a.p = *params; a.packed = packed; a.M = pts->n_points; a.out = out; a.d_out = d_out; a.stash = (char *)stash;
   bn_make_packed_layout(g, &a.pl);
   const bool bf = desc->dtype == BN_BF16;
-  const int BM = bf ? 128 : 64;
+  const int BM = g.BM;
   const size_t esz = bf ? 2 : 4;
   bn_make_stash_layout(g, pts->n_points, BM, esz, &a.sl);
   const int64_t tiles = ceil_div64(pts->n_points, BM);
@@ -579,8 +620,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     rc = bn_field_adjoint_backward(desc, params, packed, pts, d_out, stash, stream);
     if (rc) return rc;
   }
-  if (bf) rc = g.NT == 2 ? launch_bwd<bf16, 4, 2>(a, tiles, st) : launch_bwd<bf16, 4, 1>(a, tiles, st);
-  else rc = g.NT == 2 ? launch_bwd<float, 2, 2>(a, tiles, st) : launch_bwd<float, 2, 1>(a, tiles, st);
+  rc = [&]() -> int { BN_DISPATCH_TILE(desc->dtype, g, launch_bwd, (a, tiles, st)); }();
   if (rc) return rc;
 
   // ---- weight gradients

@@ -22,6 +22,8 @@ struct FwdArgs {
 // w0/(2 pi) (bn_pack_field), so `z` already is the argument of v_sin_f32/v_cos_f32 in revolutions: one transcendental
 // per output, no range-reduction multiplies.  The parity mode keeps z = W x + b and the accurate sincos.
 #define BN_INV_2PI 0.15915494309189535f
+
+BN_PH_DEFINE_READER(bn_debug_phase_read_fwd)
 template <bool FAST, int ACT> __device__ __forceinline__ void act_eval(float z, float w0, float &y, float &d) {
   if (ACT == BN_ACT_SIN) {
     if (FAST) {
@@ -42,8 +44,12 @@ template <bool FAST> __device__ __forceinline__ float act_prescale(int act, floa
 
 // One pass over up to two heads: hidden = act(W1 feats + b1) kept in registers, second layer (<= 3 outputs)
 // as per-lane partial dots reduced through LDS.  NTW = 32-column tiles per wave in this pass.
-template <typename T, int MT, int NTW, bool KEEP>
-__device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT, float *RED, int64_t m0, int64_t tile) {
+template <typename T, int MT, int NTW, int WAVES, bool KEEP>
+__device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT, float *RED, int64_t m0, int64_t tile
+#ifdef BN_PHASE_TIMING
+                                          , unsigned long long (&ph_)[BN_PH_N], unsigned long long &pt_
+#endif
+) {
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
   constexpr bool FAST = Elem<T>::kFastMath;
@@ -61,6 +67,7 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
   zero_acc<MT, NTW>(acc);
   if (on) {
     gemm_seg<T, MT, NTW>(acc, (const T *)A.packed + A.pl.fwd_head[p] + (size_t)(pc0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
+    BN_PH(9)
     const int nout = A.d.head_out[hd];
     const float *b1 = A.p.head_b1[hd];
     const float *w2 = A.p.head_w2[hd];
@@ -96,8 +103,8 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
             const vec4 ya = to_vec4(T(), y[0], y[1], y[2], y[3]), yb = to_vec4(T(), y[4], y[5], y[6], y[7]);
             if (keep) {
               const int m = mt * 32 + r;
-              *(vec4 *)(Gs + (size_t)m * N + n0) = ya;
-              *(vec4 *)(Gs + (size_t)m * N + n0 + 8) = yb;
+              stash_store((vec4 *)(Gs + (size_t)m * N + n0), ya);
+              stash_store((vec4 *)(Gs + (size_t)m * N + n0 + 8), yb);
               st8(DGs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), dd);
             }
             // the second layer sees the stored (rounded) hidden value: fwd and bwd stay consistent
@@ -119,6 +126,7 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
         if (h == 0) RED[(wave * 3 + c) * BM + mt * 32 + r] = v;
       }
   }
+  BN_PH(10)
   __syncthreads();
   if (tid < BM * g.pass_heads[p]) {
     const int m = tid % BM, hl2 = tid / BM, hd2 = 2 * p + hl2;
@@ -150,10 +158,17 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
     }
   }
   __syncthreads();
+  BN_PH(11)
 }
 
-template <typename T, int MT, int NT, bool KEEP>
-__global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs A) {
+#ifdef BN_PHASE_TIMING
+#define BN_PH_ARGS , ph_, pt_
+#else
+#define BN_PH_ARGS
+#endif
+
+template <typename T, int MT, int NT, int WAVES, bool KEEP>
+__global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs A) {
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
   constexpr int PADE = Elem<T>::kPad;
@@ -163,17 +178,18 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
   const int F = g.F, LDA = F + PADE, KP = g.KP, LDP = KP + PADE;
   T *ACT = (T *)smem;
   T *PE = ACT + (size_t)BM * LDA;
-  float *RED = (float *)(PE + (size_t)BM * LDP);  // [8 waves][3][BM]
+  float *RED = (float *)(PE + (size_t)BM * LDP);  // [WAVES][3][BM]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.pts.n_points;
   const T *packed = (const T *)A.packed;
   constexpr bool keep = KEEP;   // compile-time: the inference variant drops every derivative (cos) computation
+  BN_PH_DECL
 
   // ---------------------------------------------------------------- points + positional encoding
   {
-    constexpr int NP = BN_THREADS / BM;
+    constexpr int NP = (WAVES * 64) / BM;
     const int m = tid % BM, part = tid / BM;
     const int64_t gm = m0 + m;
     float x[3] = {0.f, 0.f, 0.f};
@@ -207,6 +223,7 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
   }
   __syncthreads();
   if (keep) tile_to_global<T>(PE, LDP, (T *)(A.stash + A.sl.pe) + (size_t)m0 * KP, KP, BM, KP);
+  BN_PH(0)
 
   const int ncol0 = wave * 32 * NT;        // first feature of this wave in F-wide phases
   const bool wave_on = ncol0 < F;
@@ -214,24 +231,47 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
   f32x16 acc[NT][MT];
 
   // ---------------------------------------------------------------- trunk
+  const int n_on = F / (32 * NT) < WAVES ? F / (32 * NT) : WAVES;   // waves that own output columns
+  // stash copies ride inside the GEMMs when the shape fits (NT == 2 means F = 512: always, decided at compile time)
+  const bool ride = NT == 2 ? true : tile_copy_exact(F, n_on, WAVES);
   for (int l = 0; l < g.L; ++l) {
     zero_acc<MT, NT>(acc);
+    if (keep && !ride && l > 0) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[l - 1]) + (size_t)m0 * F, F, BM, F);
     if (wave_on) {
       const size_t t0 = (size_t)(ncol0 / 32);
-      if (l == 0) {
-        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512, KSP, PE, LDP, lane);
-      } else if (l == g.skip) {
-        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512, KSP, PE, LDP, lane);
-        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][1] + t0 * KSF * 512, KSF, ACT, LDA, lane);
-      } else {
-        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][0] + t0 * KSF * 512, KSF, ACT, LDA, lane);
+      const T *w_pe = packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512;
+      const T *w_h = packed + A.pl.fwd_trunk[l][l == g.skip ? 1 : 0] + t0 * KSF * 512;
+      if (l == 0 || l == g.skip) gemm_seg<T, MT, NT>(acc, w_pe, KSP, PE, LDP, lane);
+      if (l > 0) {
+        // the row-major stash copy of Y_{l-1} (the tile this GEMM reads) rides inside the GEMM when the shape fits
+        if (keep && ride) {
+          TileCopyExact<T> ycopy(ACT, LDA, (T *)(A.stash + A.sl.Y[l - 1]) + (size_t)m0 * F, F, F, tid, WAVES * 64);
+          gemm_seg<T, MT, NT>(acc, w_h, KSF, ACT, LDA, lane, ycopy);
+        } else {
+          gemm_seg<T, MT, NT>(acc, w_h, KSF, ACT, LDA, lane);
+        }
       }
     }
-    __syncthreads();  // every wave has finished reading ACT (in-place update below)
+    // this layer's biases: loaded ahead of the barrier, and ahead of the epilogue's stash stores (a load issued
+    // after a store is not seen before that store has been acknowledged)
+    const float w0 = (l == 0) ? 30.f : 1.f;
+    f32x4 bia[NT][2][2];
     if (wave_on) {
-      const float w0 = (l == 0) ? 30.f : 1.f;
       const float bscale = act_prescale<FAST>(g.act, w0);
       const float *bias = A.p.trunk_b[l];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
+          bia[nt][gp][0] = *(const f32x4 *)(bias + n0) * bscale;
+          bia[nt][gp][1] = *(const f32x4 *)(bias + n0 + 8) * bscale;
+        }
+    }
+    BN_PH(1)
+    __syncthreads();  // every wave has finished reading ACT (in-place update below)
+    BN_PH(2)
+    if (wave_on) {
       T *Ds = keep ? (T *)(A.stash + A.sl.D[l]) + (size_t)tile * BM * F : nullptr;
       auto epilogue = [&](auto act_tag) {
         constexpr int ACTK = decltype(act_tag)::value;
@@ -240,7 +280,7 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
 #pragma unroll
           for (int gp = 0; gp < 2; ++gp) {
             const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
-            const f32x4 ba = *(const f32x4 *)(bias + n0) * bscale, bb = *(const f32x4 *)(bias + n0 + 8) * bscale;
+            const f32x4 ba = bia[nt][gp][0], bb = bia[nt][gp][1];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               float y[8], dd[8];
@@ -259,27 +299,34 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
       if (g.act == BN_ACT_SIN) epilogue(std::integral_constant<int, BN_ACT_SIN>());
       else epilogue(std::integral_constant<int, BN_ACT_RELU>());
     }
+    BN_PH(3)
     __syncthreads();
-    if (keep) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[l]) + (size_t)m0 * F, F, BM, F);
+    BN_PH(4)
   }
 
   // ---------------------------------------------------------------- sigma (+ learned normal): VALU dots over h8
   {
-    constexpr int TPR = BN_THREADS / BM;  // threads per point
+    constexpr int TPR = (WAVES * 64) / BM;  // threads per point
     const int m = tid / TPR, q = tid % TPR;
     const bool nlr = g.ch_normal_lr >= 0;
     float ds = 0.f, dn0 = 0.f, dn1 = 0.f, dn2 = 0.f;
     const T *row = ACT + (size_t)m * LDA;
-    for (int c8 = q; c8 < F / 8; c8 += TPR) {
-      const typename Elem<T>::frag v = lds_frag<T>(row + c8 * 8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float a = (float)v[j];
-        const int k = c8 * 8 + j;
-        ds += a * A.p.sigma_w[k];
-        if (nlr) {
-          dn0 += a * A.p.normal_w[k]; dn1 += a * A.p.normal_w[F + k]; dn2 += a * A.p.normal_w[2 * F + k];
-        }
+    // 16-byte weight loads, all independent of each other (the compiler batches them ahead of the FMAs); the
+    // learned-normal rows get their own loop so the sigma-only loop has no branch in it
+    auto dot8 = [&](const float *w, const typename Elem<T>::frag &v) {
+      const f32x4 wa = *(const f32x4 *)w, wb = *(const f32x4 *)(w + 4);
+      return (float)v[0] * wa[0] + (float)v[1] * wa[1] + (float)v[2] * wa[2] + (float)v[3] * wa[3] + (float)v[4] * wb[0] +
+             (float)v[5] * wb[1] + (float)v[6] * wb[2] + (float)v[7] * wb[3];
+    };
+#pragma unroll 4
+    for (int c8 = q; c8 < F / 8; c8 += TPR) ds += dot8(A.p.sigma_w + c8 * 8, lds_frag<T>(row + c8 * 8));
+    if (nlr) {
+#pragma unroll 2
+      for (int c8 = q; c8 < F / 8; c8 += TPR) {
+        const typename Elem<T>::frag v = lds_frag<T>(row + c8 * 8);
+        dn0 += dot8(A.p.normal_w + c8 * 8, v);
+        dn1 += dot8(A.p.normal_w + F + c8 * 8, v);
+        dn2 += dot8(A.p.normal_w + 2 * F + c8 * 8, v);
       }
     }
 #pragma unroll
@@ -310,11 +357,22 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
       }
     }
   }
-  if (A.sigma_only) return;
+  BN_PH(6)
+  if (A.sigma_only) { BN_PH_FLUSH return; }
 
   // ---------------------------------------------------------------- feats = Wf h8 + bf (linear)
   zero_acc<MT, NT>(acc);
-  if (wave_on) gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_feats + (size_t)(ncol0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
+  if (keep && !ride) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[g.L - 1]) + (size_t)m0 * F, F, BM, F);
+  if (wave_on) {
+    const T *w_f = packed + A.pl.fwd_feats + (size_t)(ncol0 / 32) * KSF * 512;
+    if (keep && ride) {
+      TileCopyExact<T> ycopy(ACT, LDA, (T *)(A.stash + A.sl.Y[g.L - 1]) + (size_t)m0 * F, F, F, tid, WAVES * 64);
+      gemm_seg<T, MT, NT>(acc, w_f, KSF, ACT, LDA, lane, ycopy);
+    } else {
+      gemm_seg<T, MT, NT>(acc, w_f, KSF, ACT, LDA, lane);
+    }
+  }
+  BN_PH(7)
   __syncthreads();
   if (wave_on) {
 #pragma unroll
@@ -333,12 +391,14 @@ __global__ __launch_bounds__(BN_THREADS, 2) void field_fwd_kernel(const FwdArgs 
   }
   __syncthreads();
   if (keep) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.feats) + (size_t)m0 * F, F, BM, F);
+  BN_PH(8)
 
   // ---------------------------------------------------------------- two-layer sigmoid heads, up to 2 per pass
   for (int p = 0; p < g.n_pass; ++p) {
-    if (g.pass_heads[p] == 2) head_pass<T, MT, NT, KEEP>(A, p, ACT, RED, m0, tile);
-    else head_pass<T, MT, 1, KEEP>(A, p, ACT, RED, m0, tile);
+    if (g.pass_heads[p] == 2) head_pass<T, MT, NT, WAVES, KEEP>(A, p, ACT, RED, m0, tile BN_PH_ARGS);
+    else head_pass<T, MT, (NT > 1 ? NT / 2 : 1), WAVES, KEEP>(A, p, ACT, RED, m0, tile BN_PH_ARGS);
   }
+  BN_PH_FLUSH
 }
 
 // ------------------------------------------------------------------------------------------ weight packing
@@ -395,7 +455,7 @@ extern "C" size_t bn_field_stash_bytes(const bn_field_desc *desc, int64_t n_poin
   FieldGeom g;
   if (bn_make_geom(desc, &g)) return 0;
   StashLayout sl;
-  bn_make_stash_layout(g, n_points, desc->dtype == BN_BF16 ? 128 : 64, esize(desc->dtype), &sl);
+  bn_make_stash_layout(g, n_points, g.BM, esize(desc->dtype), &sl);
   return sl.total;
 }
 
@@ -475,17 +535,17 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
   return 0;
 }
 
-template <typename T, int MT, int NT, bool KEEP> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st);
-template <typename T, int MT, int NT> static int launch_fwd(const FwdArgs &a, int64_t tiles, hipStream_t st) {
-  return a.stash ? launch_fwd_k<T, MT, NT, true>(a, tiles, st) : launch_fwd_k<T, MT, NT, false>(a, tiles, st);
+template <typename T, int MT, int NT, int WAVES, bool KEEP> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st);
+template <typename T, int MT, int NT, int WAVES> static int launch_fwd(const FwdArgs &a, int64_t tiles, hipStream_t st) {
+  return a.stash ? launch_fwd_k<T, MT, NT, WAVES, true>(a, tiles, st) : launch_fwd_k<T, MT, NT, WAVES, false>(a, tiles, st);
 }
-template <typename T, int MT, int NT, bool KEEP> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st) {
+template <typename T, int MT, int NT, int WAVES, bool KEEP> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = ((size_t)BM * (a.g.F + Elem<T>::kPad) + (size_t)BM * (a.g.KP + Elem<T>::kPad)) * sizeof(T) +
-                     (size_t)BN_WAVES * 3 * BM * sizeof(float);
+                     (size_t)WAVES * 3 * BM * sizeof(float);
   static size_t configured = 0;
   if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)field_fwd_kernel<T, MT, NT, KEEP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void *)field_fwd_kernel<T, MT, NT, WAVES, KEEP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) {
       bn_set_error("field_fwd: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
@@ -494,7 +554,7 @@ template <typename T, int MT, int NT, bool KEEP> static int launch_fwd_k(const F
     configured = lds;
   }
   BnProfScope prof_(a.sigma_only ? BN_K_FWD_SIGMA : BN_K_FWD_FULL, st);
-  field_fwd_kernel<T, MT, NT, KEEP><<<dim3((unsigned)tiles), BN_THREADS, lds, st>>>(a);
+  field_fwd_kernel<T, MT, NT, WAVES, KEEP><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_fwd");
   return 0;
 }
@@ -510,12 +570,11 @@ int bn_field_forward_impl(const bn_field_desc *desc, const bn_field_params *para
   a.d = *desc; a.p = *params; a.packed = packed; a.pts = *pts; a.out = out; a.stash = (char *)stash;
   a.sigma_only = sigma_only;
   bn_make_packed_layout(a.g, &a.pl);
-  const int BM = desc->dtype == BN_BF16 ? 128 : 64;
+  const int BM = a.g.BM;
   bn_make_stash_layout(a.g, pts->n_points, BM, esize(desc->dtype), &a.sl);
   const int64_t tiles = ceil_div64(pts->n_points, BM);
   hipStream_t st = (hipStream_t)stream;
-  if (desc->dtype == BN_BF16) return a.g.NT == 2 ? launch_fwd<bf16, 4, 2>(a, tiles, st) : launch_fwd<bf16, 4, 1>(a, tiles, st);
-  return a.g.NT == 2 ? launch_fwd<float, 2, 2>(a, tiles, st) : launch_fwd<float, 2, 1>(a, tiles, st);
+  BN_DISPATCH_TILE(desc->dtype, a.g, launch_fwd, (a, tiles, st));
 }
 
 extern "C" int bn_field_sigma(const bn_field_desc *desc, const bn_field_params *params, const void *packed,

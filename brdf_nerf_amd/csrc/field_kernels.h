@@ -1,7 +1,7 @@
 // Device building blocks of the fused field MLP: the activation-stationary tile GEMM and the
 // accumulator-register <-> (point, feature) maps shared by the forward and backward chain kernels.
 //
-// Tiling (one 512-thread workgroup = 8 waves = 2 waves per SIMD):
+// Tiling (one workgroup of WAVES = 8 waves per CU, 2 waves per SIMD):
 //   * a tile of BM points (128 for bf16, 64 for fp32) keeps its activations in LDS as ACT[BM][F+pad]
 //     (row-major, k contiguous) for the whole network;
 //   * products are computed "swapped": D[n][m] = sum_k W[n][k] * ACT[m][k], i.e. the WEIGHTS are the MFMA
@@ -13,8 +13,59 @@
 #pragma once
 #include "field.h"
 
-#define BN_THREADS 512
-#define BN_WAVES 8
+// Phase-cycle instrumentation, compiled only into the diagnostic library built by profiles/phase_timing.py
+// (-DBN_PHASE_TIMING): per-wave shader-clock cycles spent between BN_PH() marks, summed over the grid.
+#ifdef BN_PHASE_TIMING
+#define BN_PH_N 16
+static __device__ unsigned long long bn_phase_clk[BN_PH_N + 1];
+#define BN_PH_DEFINE_READER(NAME)                                                                              \
+  extern "C" int NAME(unsigned long long *out, int reset) {                                                    \
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bn_phase_clk), sizeof(unsigned long long) * (BN_PH_N + 1)) != hipSuccess) return -1; \
+    if (reset) {                                                                                               \
+      unsigned long long z[BN_PH_N + 1] = {0};                                                                 \
+      if (hipMemcpyToSymbol(HIP_SYMBOL(bn_phase_clk), z, sizeof(z)) != hipSuccess) return -1;                  \
+    }                                                                                                          \
+    return 0;                                                                                                  \
+  }
+#define BN_PH_DECL unsigned long long ph_[BN_PH_N] = {0}, pt_ = __builtin_readcyclecounter();
+#define BN_PH(i) { const unsigned long long n_ = __builtin_readcyclecounter(); ph_[i] += n_ - pt_; pt_ = n_; }
+#define BN_PH_FLUSH if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < BN_PH_N; ++i_) atomicAdd(&bn_phase_clk[i_], ph_[i_]); atomicAdd(&bn_phase_clk[BN_PH_N], 1ull); }
+#else
+#define BN_PH_DEFINE_READER(NAME)
+#define BN_PH_DECL
+#define BN_PH(i)
+#define BN_PH_FLUSH
+#endif
+
+// Stash traffic is streaming (written once here, read once by a later kernel) and several times larger than the
+// packed weights every workgroup re-reads from L2: non-temporal stores / loads keep it from evicting the weights.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+template <typename V> __device__ __forceinline__ void stash_store(V *p, const V &v) {
+#ifdef BN_NO_NT_STASH
+  *p = v;
+#else
+  __builtin_nontemporal_store(v, p);
+#endif
+}
+template <typename V> __device__ __forceinline__ V stash_load(const V *p) {
+#ifdef BN_NO_NT_STASH
+  return *p;
+#else
+  return __builtin_nontemporal_load(p);
+#endif
+}
+
+// Instantiate-and-call FN<T, MT, NT, WAVES> ARGS for the tile configuration in geometry G (returns from the caller).
+#define BN_DISPATCH_TILE(DTYPE, G, FN, ARGS)                                                     \
+  do {                                                                                           \
+    if ((DTYPE) == BN_BF16) {                                                                    \
+      if ((G).NT == 2) return FN<bf16, 4, 2, 8> ARGS;                                            \
+      return FN<bf16, 4, 1, 8> ARGS;                                                             \
+    }                                                                                            \
+    if ((G).NT == 2) return FN<float, 2, 2, 8> ARGS;                                             \
+    return FN<float, 2, 1, 8> ARGS;                                                              \
+  } while (0)
+
 
 template <typename T> __device__ __forceinline__ typename Elem<T>::frag lds_frag(const T *p);
 template <> __device__ __forceinline__ bf16x8 lds_frag<bf16>(const bf16 *p) { return *(const bf16x8 *)p; }
@@ -27,58 +78,111 @@ template <typename T> __device__ __forceinline__ typename Elem<T>::frag gld_frag
 
 // acc[nt][mt] += W_packed(this wave's tiles) x B(lds).  `wp` points at the packed block of the wave's first
 // n-tile for this K segment; consecutive n-tiles are KS*512 elements apart.
-template <typename T, int MT, int NTW>
+//
+// Software pipeline: the weight fragments of DEPTH consecutive k-steps are always in flight from L2 (a slot is
+// re-filled right after its MFMAs have issued and is consumed DEPTH k-steps later), and the LDS fragments of k-step
+// s+1 are read while the MFMAs of k-step s run.  sched_barrier pins that order (hipcc otherwise sinks the prefetch
+// loads next to their use).  The weight stream out of L2 is what bounds these kernels: DEPTH
+// sets the bytes in flight per CU (8 waves x DEPTH x NTW KB), and no fragment is fetched twice.
+// Side job of a GEMM segment: at(parity) is called once per k-step after that step's MFMAs have issued; the parity of
+// the k-step is a constant once the k-loop is unrolled (the pipeline depth is even).  A side job must be straight-line code - a branch inside the
+// unrolled k-loop splits its basic block and the waits on the weight stream turn conservative.
+struct NoSide {
+  __device__ __forceinline__ void at(int) const {}
+};
+
+// Row-major stash copy of the workgroup's LDS tile [rows][width] riding inside the NEXT GEMM over the same tile (which
+// only reads it): one 16-byte chunk per thread every second k-step, so the stores drain under the MFMAs and no load
+// the kernel is about to wait for sits behind a burst of them (vmcnt retires loads and stores in issue order).
+// Exact fit only: rows * width / (16 B) == nthr * KS / 2 and nthr % (chunks per row) == 0 (F = 256 or 512 with all
+// eight waves in the GEMM) - other shapes use the stand-alone tile_to_global.
+template <typename T> struct TileCopyExact {
+  static constexpr int EPC = 16 / sizeof(T);
+  const T *lp;
+  T *gp;
+  int lstep, gstep;
+  __device__ __forceinline__ TileCopyExact(const T *lds, int ld, T *g, int gld, int width, int t, int nthr) {
+    const int cpr = width / EPC, row = t / cpr, cc = t % cpr, dr = nthr / cpr;
+    lp = lds + (size_t)row * ld + cc * EPC;
+    gp = g + (size_t)row * gld + cc * EPC;
+    lstep = dr * ld; gstep = dr * gld;
+  }
+  __device__ __forceinline__ void at(int parity) {
+    if (parity == 0) {
+      stash_store((u32x4 *)gp, *(const u32x4 *)lp);
+      lp += lstep; gp += gstep;
+    }
+  }
+};
+__host__ __device__ __forceinline__ bool tile_copy_exact(int F, int n_on, int waves) { return n_on == waves && F % 256 == 0; }
+
+#ifndef BN_DEPTH_BF16
+#define BN_DEPTH_BF16 4
+#endif
+template <typename T> struct PipeDepth { static constexpr int value = 4; };
+template <> struct PipeDepth<bf16> { static constexpr int value = BN_DEPTH_BF16; };
+
+template <typename T, int MT, int NTW, typename Side>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb,
-                                         int lane) {
+                                         int lane, Side &side) {
   typedef typename Elem<T>::frag frag;
-  constexpr int U = Elem<T>::kU;
+  constexpr int DEPTH = PipeDepth<T>::value;
+  static_assert(DEPTH % 2 == 0, "side jobs rely on an even pipeline depth");
   const int r = lane & 31, h = lane >> 5;
   const T *wl = wp + (size_t)lane * 8;
   const T *bl = bsrc + (size_t)r * ldb + 8 * h;
-  frag A0[U][NTW], A1[U][NTW], Bc[MT];
-  // KS is a multiple of U (every K extent is a multiple of 32).  Software pipeline: two weight blocks (U k-steps
-  // each) are always in flight from L2 - a block is re-filled right after its last MFMA has issued and consumed one
-  // whole block later - and the LDS fragments of k-step s+1 are read while the MFMAs of k-step s run.
-  // sched_barrier pins that order (hipcc otherwise sinks the prefetch loads next to their use).
-  const int nb = KS / U;
-  auto loadA = [&](frag(&A)[U][NTW], int blk) {
+  frag A[DEPTH][NTW], Bc[MT];
+  auto loadA = [&](frag(&a)[NTW], int ks) {
+#ifdef BN_GUARD_LOADS
+    if (ks < KS)
+#else
+    ks = ks < KS ? ks : KS - 1;
+#endif
+    {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) A[u][nt] = gld_frag<T>(wl + ((size_t)nt * KS + blk * U + u) * 512);
+      for (int nt = 0; nt < NTW; ++nt) a[nt] = gld_frag<T>(wl + ((size_t)nt * KS + ks) * 512);
+    }
   };
   auto loadB = [&](frag(&B)[MT], int ks) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) B[mt] = lds_frag<T>(bl + (size_t)mt * 32 * ldb + ks * 16);
   };
-  auto compute = [&](frag(&A)[U][NTW], int blk) {   // consumes Bc (fragments of k-step blk*U), leaves the next ones in Bc
+  auto step = [&](frag(&a)[NTW], int ks) {   // consumes Bc (fragments of k-step ks), leaves those of ks+1 in Bc
+    frag Bn[MT];
+    loadB(Bn, ks + 1 < KS ? ks + 1 : 0);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      frag Bn[MT];
-      const int nxt = blk * U + u + 1;
-      loadB(Bn, nxt < KS ? nxt : 0);
+    for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)
+      for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], a[nt], Bc[mt]);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], A[u][nt], Bc[mt]);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) Bc[mt] = Bn[mt];
-    }
+    for (int mt = 0; mt < MT; ++mt) Bc[mt] = Bn[mt];
   };
-  loadA(A0, 0);
-  loadA(A1, nb > 1 ? 1 : 0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) loadA(A[d], d);
   loadB(Bc, 0);
   __builtin_amdgcn_sched_barrier(0);
-  int b = 0;
-  for (; b + 2 <= nb; b += 2) {
-    compute(A0, b);
-    loadA(A0, b + 2 < nb ? b + 2 : nb - 1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(A1, b + 1);
-    loadA(A1, b + 3 < nb ? b + 3 : nb - 1);
-    __builtin_amdgcn_sched_barrier(0);
+  int ks = 0;
+  for (; ks + DEPTH <= KS; ks += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      step(A[d], ks + d);
+      loadA(A[d], ks + d + DEPTH);
+      side.at(d & 1);   // constant after unrolling
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
-  if (b < nb) compute(A0, b);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (ks + d < KS) {
+      step(A[d], ks + d);
+      side.at(d & 1);
+    }
+}
+template <typename T, int MT, int NTW>
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb,
+                                         int lane) {
+  NoSide none;
+  gemm_seg<T, MT, NTW, NoSide>(acc, wp, KS, bsrc, ldb, lane, none);
 }
 
 template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NTW][MT]) {
@@ -100,19 +204,19 @@ __device__ __forceinline__ void st8(bf16 *p, const float (&v)[8]) {
   bf16x8 o;
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
-  *(bf16x8 *)p = o;
+  stash_store((bf16x8 *)p, o);
 }
 __device__ __forceinline__ void st8(float *p, const float (&v)[8]) {
-  *(f32x4 *)p = f32x4{v[0], v[1], v[2], v[3]};
-  *(f32x4 *)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  stash_store((f32x4 *)p, f32x4{v[0], v[1], v[2], v[3]});
+  stash_store((f32x4 *)(p + 4), f32x4{v[4], v[5], v[6], v[7]});
 }
 __device__ __forceinline__ void ld8(const bf16 *p, float (&v)[8]) {
-  const bf16x8 o = *(const bf16x8 *)p;
+  const bf16x8 o = stash_load((const bf16x8 *)p);
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = (float)o[i];
 }
 __device__ __forceinline__ void ld8(const float *p, float (&v)[8]) {
-  const f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
+  const f32x4 a = stash_load((const f32x4 *)p), b = stash_load((const f32x4 *)(p + 4));
 #pragma unroll
   for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
 }
@@ -122,9 +226,13 @@ __device__ __forceinline__ void ld8(const float *p, float (&v)[8]) {
 // fragments the accumulator layout would give.
 template <typename T> __device__ __forceinline__ void tile_to_global(const T *lds, int ld, T *g, int gld, int rows, int width) {
   constexpr int EPC = 16 / sizeof(T);
-  const int cpr = width / EPC;
-  for (int c = threadIdx.x; c < rows * cpr; c += BN_THREADS) {
-    const int row = c / cpr, cc = (c % cpr) * EPC;
-    *(uint4 *)(g + (size_t)row * gld + cc) = *(const uint4 *)(lds + (size_t)row * ld + cc);
+  const int cpr = width / EPC, nthr = blockDim.x;
+  // chunk c = row * cpr + cc, walked with stride nthr: one division per call, not one per chunk
+  int row = threadIdx.x / cpr, cc = threadIdx.x % cpr;
+  const int dr = nthr / cpr, dc = nthr % cpr;
+  while (row < rows) {
+    stash_store((u32x4 *)(g + (size_t)row * gld + cc * EPC), *(const u32x4 *)(lds + (size_t)row * ld + cc * EPC));
+    row += dr; cc += dc;
+    if (cc >= cpr) { cc -= cpr; ++row; }
   }
 }
