@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbrdfnerf_hip.so")
+# BRDFNERF_HIP_LIB selects another build of the same library (variant builds for A/B measurements, brdf_nerf_amd.build -D...)
+LIB_PATH = os.environ.get("BRDFNERF_HIP_LIB") or os.path.join(HERE, "libbrdfnerf_hip.so")
 
 BN_MAX_LAYERS = 12
 BN_MAX_HEADS = 4

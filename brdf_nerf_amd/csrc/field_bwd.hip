@@ -269,7 +269,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   }
   tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dZ[0]) + (size_t)m0 * F, F, BM, F);
   BN_PH(13)
+#ifndef BN_PHASE_TIMING_WGRAD
   BN_PH_FLUSH
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ weight gradients
@@ -411,7 +413,8 @@ template <typename T> __global__ __launch_bounds__(256) void wgrad_kernel(const 
 // ds_read_b64_tr_b16 fragment reads.  Each wave owns 64(n) x 128(k): 2 x 4 accumulator tiles.  Blocks that share an
 // (job, point-split) - i.e. the same A rows - get consecutive ids on ONE XCD so the second read of a tile hits L2.
 #define W2_LD (256 + 32)       // 576-byte rows: the 4 rows of a tr-read block fall on disjoint bank groups
-#define W2_STAGE (WG_BK * W2_LD)
+#define W2_BK 64               // points per stage (one barrier per stage; 2 stages x 2 operands = 144 KB of LDS)
+#define W2_STAGE (W2_BK * W2_LD)
 __device__ __forceinline__ bf16x8 w2_frag(const bf16 *tile, int mm, int col0, int lane) {
   const int h = lane >> 5, grp = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
   const bf16 *a = tile + (size_t)(mm + 8 * h + q) * W2_LD + col0 + 16 * grp + 4 * p;
@@ -423,9 +426,25 @@ __device__ __forceinline__ bf16x8 w2_frag(const bf16 *tile, int mm, int col0, in
   return u.b;
 }
 
-__global__ __launch_bounds__(512, 2) void wgrad256_kernel(const WgradArgs A, int n_split, int n_blocks) {
+#if defined(BN_PHASE_TIMING) && defined(BN_PHASE_TIMING_WGRAD)
+#define WG_PH_DECL BN_PH_DECL
+#define WG_PH(i) BN_PH(i)
+#define WG_PH_FLUSH BN_PH_FLUSH
+#else
+#define WG_PH_DECL
+#define WG_PH(i)
+#define WG_PH_FLUSH
+#endif
+// W2_WAVES = 8: wave tile 64(n) x 128(k), 2 waves per SIMD.  W2_WAVES = 4 (wave tile 128 x 128, accumulators in the
+// AGPR half of the register file, a third fewer LDS fragment bytes per MFMA) compiles but spills in the k-loop and
+// measured 5.7x slower (profiles/r01_ablation.txt): kept only as an experiment switch.
+#ifndef W2_WAVES
+#define W2_WAVES 8
+#endif
+#define W2_RA (256 / ((W2_WAVES / 2) * 32))   // 32-row accumulator tiles per wave along n
+__global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256_kernel(const WgradArgs A, int n_split, int n_blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem_w[];
-  bf16 *sA = (bf16 *)smem_w;                 // [2][32][W2_LD]
+  bf16 *sA = (bf16 *)smem_w;                 // [2][W2_BK][W2_LD]
   bf16 *sB = sA + 2 * W2_STAGE;
   // XCD-aware id: hardware deals consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous range
   const int per = n_blocks / 8;              // n_blocks is a multiple of 8
@@ -445,75 +464,131 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const WgradArgs A, int
   if (mb >= me) return;
   const bf16 *gA = (const bf16 *)J.A + J.a_col0 + n0;
   const bf16 *gB = (const bf16 *)J.B + J.b_col0 + k0;
-  // 32 rows x 32 chunks (16 B) per operand = 1024 chunks: 2 per thread
-  const int row0 = tid >> 5, cc = (tid & 31) * 8;            // rows row0 and row0 + 16
+  // W2_BK rows x 32 chunks (16 B) per operand: NC per thread
+  constexpr int RPP = W2_WAVES * 2;                          // rows per pass of the workgroup
+  constexpr int NC = W2_BK / RPP;
+  const int row0 = tid >> 5, cc = (tid & 31) * 8;            // rows row0 + RPP c
   const bool a_ok = n0 + cc < J.N, b_ok = k0 + cc < J.K;
-  uint4 ra[2], rb[2];
+  // Stage pipeline with ONE register set: after the barrier that opens stage s, the registers (stage s+1, loaded
+  // during stage s-1's MFMAs) are written to the other LDS buffer, re-filled at once with stage s+2, and stage s
+  // is multiplied - every global load has a whole stage of MFMAs to arrive, every LDS buffer one barrier between
+  // its last read and its next write.
+  u32x4 ra[NC], rb[NC];
+  int64_t m_dbg = mb;   // diagnostic variants only
   auto gload = [&](int64_t m) {
+    if (m >= me) return;
+#ifdef W2_SKIP_GLOAD   // diagnostic variant (profiles/ab_bench.sh): compute side only
+    if (m > mb + W2_BK) return;
+#endif
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int64_t row = m + row0 + 16 * c;
-      ra[c] = a_ok ? *(const uint4 *)(gA + row * J.lda + cc) : uint4{0, 0, 0, 0};
-      rb[c] = b_ok ? *(const uint4 *)(gB + row * J.ldb + cc) : uint4{0, 0, 0, 0};
+    for (int c = 0; c < NC; ++c) {
+      const int64_t row = m + row0 + RPP * c;
+      ra[c] = a_ok ? *(const u32x4 *)(gA + row * J.lda + cc) : u32x4{0, 0, 0, 0};
+      rb[c] = b_ok ? *(const u32x4 *)(gB + row * J.ldb + cc) : u32x4{0, 0, 0, 0};
     }
   };
   auto sstore = [&](int buf) {
+#ifdef W2_SKIP_SSTORE
+    if (m_dbg > mb) return;
+#endif
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      *(uint4 *)(sA + buf * W2_STAGE + (row0 + 16 * c) * W2_LD + cc) = ra[c];
-      *(uint4 *)(sB + buf * W2_STAGE + (row0 + 16 * c) * W2_LD + cc) = rb[c];
+    for (int c = 0; c < NC; ++c) {
+      *(u32x4 *)(sA + buf * W2_STAGE + (row0 + RPP * c) * W2_LD + cc) = ra[c];
+      *(u32x4 *)(sB + buf * W2_STAGE + (row0 + RPP * c) * W2_LD + cc) = rb[c];
     }
   };
-  f32x16 acc[2][4];
+  f32x16 acc[W2_RA][4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < W2_RA; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-  float bsum = 0.f;
-  const bool do_bias = J.bias != nullptr && k0 == 0 && tid < 256;
+  // bias gradient = column sums of A: the waves that own output columns k0 .. k0+127 of the first k-block add up the
+  // A fragments they already hold (lane (r, h): row n = r, points 8h .. 8h+7 of the step)
+  const bool do_bias = J.bias != nullptr && k0 == 0 && wc == 0;
+  float bsum[W2_RA];
+#pragma unroll
+  for (int a = 0; a < W2_RA; ++a) bsum[a] = 0.f;
+  WG_PH_DECL
+  // fragments of 16-point step i+1 are read while the MFMAs of step i run (two fragment sets; sched_barrier keeps
+  // hipcc from sinking the reads below the MFMAs)
+  auto compute = [&](int buf) {
+    const bf16 *cA = sA + buf * W2_STAGE, *cB = sB + buf * W2_STAGE;
+    bf16x8 fa[2][W2_RA], fb[2][4];
+    auto frags = [&](int set, int mm) {
+#pragma unroll
+      for (int a = 0; a < W2_RA; ++a) fa[set][a] = w2_frag(cA, mm, wr * (W2_RA * 32) + a * 32, lane);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fb[set][b] = w2_frag(cB, mm, wc * 128 + b * 32, lane);
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int i = 0; i < W2_BK / 16; ++i) {
+      const int cur = i & 1;
+#ifdef W2_SKIP_FRAGS
+      if (m_dbg == mb)
+#endif
+      if (i + 1 < W2_BK / 16) frags(cur ^ 1, (i + 1) * 16);
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef W2_SKIP_MFMA    // diagnostic variant: memory side only (one MFMA keeps the fragment reads alive)
+      mma32(acc[0][0], fa[cur][0] + fa[cur][1], fb[cur][0] + fb[cur][1] + fb[cur][2] + fb[cur][3]);
+#else
+#pragma unroll
+      for (int a = 0; a < W2_RA; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) mma32(acc[a][b], fa[cur][a], fb[cur][b]);
+#endif
+      if (do_bias) {
+#pragma unroll
+        for (int a = 0; a < W2_RA; ++a)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[a] += (float)fa[cur][a][j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   gload(mb);
   sstore(0);
-  __syncthreads();
+  gload(mb + W2_BK);
+  WG_PH(14)
   int buf = 0;
-  for (int64_t m = mb; m < me; m += WG_BK) {
-    const bool more = m + WG_BK < me;
-    if (more) gload(m + WG_BK);
-    const bf16 *cA = sA + buf * W2_STAGE, *cB = sB + buf * W2_STAGE;
-#pragma unroll
-    for (int mm = 0; mm < WG_BK; mm += 16) {
-      bf16x8 fa[2], fb[4];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) fa[a] = w2_frag(cA, mm, wr * 64 + a * 32, lane);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) fb[b] = w2_frag(cB, mm, wc * 128 + b * 32, lane);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) mma32(acc[a][b], fa[a], fb[b]);
-    }
-    if (do_bias) {
-#pragma unroll 8
-      for (int row = 0; row < WG_BK; ++row) bsum += (float)cA[row * W2_LD + tid];
-    }
-    if (more) sstore(buf ^ 1);
+  for (int64_t m = mb; m < me; m += W2_BK) {
+    m_dbg = m;
+#ifdef W2_SKIP_BARRIER
+    if (m == mb)
+#endif
     __syncthreads();
+    WG_PH(3)
+    if (m + W2_BK < me) sstore(buf ^ 1);
+    gload(m + 2 * W2_BK);
+    WG_PH(2)
+    compute(buf);
+    WG_PH(0)
     buf ^= 1;
   }
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < W2_RA; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int k = k0 + wc * 128 + b * 32 + r;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int n = n0 + wr * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int n = n0 + wr * (W2_RA * 32) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
         if (n < J.N && k < J.K) atomicAdd(J.C + (size_t)n * J.ldc + k, acc[a][b][i]);
       }
     }
-  if (do_bias && n0 + tid < J.N) atomicAdd(J.bias + n0 + tid, bsum);
+  if (do_bias) {
+#pragma unroll
+    for (int a = 0; a < W2_RA; ++a) {
+      const float v = bsum[a] + __shfl_xor(bsum[a], 32);
+      const int n = n0 + wr * (W2_RA * 32) + a * 32 + r;
+      if (h == 0 && n < J.N) atomicAdd(J.bias + n, v);
+    }
+  }
+  WG_PH(4)
+  WG_PH_FLUSH
 }
 
 struct SkinnyJob {
@@ -665,9 +740,12 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     for (int j = 0; j < w.n_jobs; ++j)
       w.tile0[j + 1] = w.tile0[j] + ((w.job[j].N + 255) / 256) * ((w.job[j].K + 255) / 256);
     const int tiles = w.tile0[w.n_jobs];
-    int64_t n_split = 1024 / tiles;
+#ifndef W2_BLOCKS
+#define W2_BLOCKS 1024
+#endif
+    int64_t n_split = W2_BLOCKS / tiles;
     if (n_split < 1) n_split = 1;
-    int64_t mpb2 = ceil_div64(ceil_div64(sl.Mpad, n_split), WG_BK) * WG_BK;
+    int64_t mpb2 = ceil_div64(ceil_div64(sl.Mpad, n_split), W2_BK) * W2_BK;
     if (mpb2 < 512) mpb2 = 512;
     n_split = ceil_div64(sl.Mpad, mpb2);
     w.m_per_block = (int)mpb2;
@@ -684,7 +762,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     }
     {
       BnProfScope prof_(BN_K_WGRAD, st);
-      wgrad256_kernel<<<dim3((unsigned)n_blocks), 512, lds, st>>>(w, (int)n_split, n_blocks);
+      wgrad256_kernel<<<dim3((unsigned)n_blocks), W2_WAVES * 64, lds, st>>>(w, (int)n_split, n_blocks);
       BN_LAUNCH_CHECK("wgrad256");
     }
     w.n_jobs = 0;  // done

@@ -133,11 +133,10 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__rest
   const T *bl = bsrc + (size_t)r * ldb + 8 * h;
   frag A[DEPTH][NTW], Bc[MT];
   auto loadA = [&](frag(&a)[NTW], int ks) {
-#ifdef BN_GUARD_LOADS
-    if (ks < KS)
-#else
-    ks = ks < KS ? ks : KS - 1;
+#ifdef BN_SKIP_A       // diagnostic variant (profiles/ab_bench.sh): no weight stream after the prologue
+    if (ks >= DEPTH) return;
 #endif
+    ks = ks < KS ? ks : KS - 1;
     {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) a[nt] = gld_frag<T>(wl + ((size_t)nt * KS + ks) * 512);
@@ -149,7 +148,12 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__rest
   };
   auto step = [&](frag(&a)[NTW], int ks) {   // consumes Bc (fragments of k-step ks), leaves those of ks+1 in Bc
     frag Bn[MT];
+#ifdef BN_SKIP_B       // diagnostic variant: no LDS fragment reads after the first
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) Bn[mt] = Bc[mt];
+#else
     loadB(Bn, ks + 1 < KS ? ks + 1 : 0);
+#endif
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll

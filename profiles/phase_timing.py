@@ -70,7 +70,8 @@ if __name__ == "__main__":
         tot = sum(buf[i] for i in range(16))
         print(tag, "waves", waves, "cycles/wave", tot // waves)
         for i, n in enumerate(names):
-            print(f"   {i:2d} {n:16s} {buf[i] / waves:10.0f}  {100.0 * buf[i] / max(1, tot):5.1f} %")
+            if n:
+                print(f"   {i:2d} {n:16s} {buf[i] / waves:10.0f}  {100.0 * buf[i] / max(1, tot):5.1f} %")
 
     report("sigma-only (inference)", lambda: Fn.field_sigma(spec, model.named(), packed, rays=b["rays"], z=z),
            L.bn_debug_phase_read_fwd, FWD)
@@ -81,5 +82,7 @@ if __name__ == "__main__":
            L.bn_debug_phase_read_fwd, FWD)
     d_out = torch.randn_like(out)
     grads = {k: torch.zeros_like(v) for k, v in model.named().items()}
-    report("backward chain", lambda: Fn.field_backward_raw(spec, model.named(), grads, packed, out, d_out, stash, rays=b["rays"], z=z),
+    if "BN_PHASE_TIMING_WGRAD" in defines:
+        BWD = ["mfma", "bias", "lds_store(wait gld)", "barrier", "atomics"] + [""] * 9 + ["prologue"]
+    report("backward: wgrad256" if "BN_PHASE_TIMING_WGRAD" in defines else "backward chain", lambda: Fn.field_backward_raw(spec, model.named(), grads, packed, out, d_out, stash, rays=b["rays"], z=z),
            L.bn_debug_phase_read_bwd, BWD)
