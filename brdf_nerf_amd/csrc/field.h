@@ -117,7 +117,7 @@ struct StashLayout {
   size_t Y[BN_MAX_LAYERS];        // T [Mpad][F]  output of trunk layer l
   size_t D[BN_MAX_LAYERS];        // T native     d act / d z of trunk layer l
   size_t feats;                   // T [Mpad][F]
-  size_t G[BN_MAX_PASS];          // T [Mpad][pass_N]  head hidden activations
+  size_t G[BN_MAX_PASS];          // T native     head hidden activations
   size_t DG[BN_MAX_PASS];         // T native
   size_t dZ[BN_MAX_LAYERS];       // T [Mpad][F]                                          (bwd-produced)
   size_t dfeats;                  // T [Mpad][F]                                          (bwd-produced)
@@ -151,8 +151,8 @@ static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, in
   for (int p = 0; p < BN_MAX_PASS; ++p) {
     s->G[p] = s->DG[p] = s->dG[p] = 0;
     if (p < g.n_pass) {
-      s->G[p] = take((size_t)Mpad * g.pass_N[p] * esz);
-      s->DG[p] = take((size_t)Mpad * g.F * esz);  // native image sized for a full-width phase
+      s->G[p] = take((size_t)Mpad * g.F * esz);   // native images sized for a full-width phase
+      s->DG[p] = take((size_t)Mpad * g.F * esz);
     }
   }
   for (int l = 0; l < g.L; ++l) s->dZ[l] = take((size_t)Mpad * g.F * esz);

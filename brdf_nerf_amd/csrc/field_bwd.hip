@@ -592,9 +592,11 @@ __global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256
 }
 
 struct SkinnyJob {
-  const void *X;       // [Mpad][ldx] T
+  const void *X;       // [Mpad][ldx] T, or (native != 0) accumulator-order tile images: see native_off8
   const float *dpre;   // [Mpad][ldp] fp32
   int ldx, x_col0, K, ldp, p_col0, nc;
+  int native;          // 0: row-major X.  else: tiles of `bm` points, `ntw` 32-column tiles per wave, tile stride `tstride`
+  int bm, ntw, tstride;
   float *out[4];       // row c of the gradient: out[c][k], k < K
   float *bias[4];      // scalar bias gradient of row c (nullable)
 };
@@ -610,8 +612,66 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
   const SkinnyJob &J = A.job[blockIdx.y];
   const int64_t mb = (int64_t)blockIdx.x * A.m_per_block;
   const int64_t me = mb + A.m_per_block < A.Mpad ? mb + A.m_per_block : A.Mpad;
-  const T *X = (const T *)J.X + J.x_col0;
   const int tid = threadIdx.x;
+  __shared__ float red[4 * 512 + 4];
+  for (int i = tid; i < 4 * 512 + 4; i += 256) red[i] = 0.f;
+  __syncthreads();
+  if (J.native) {
+    // X in accumulator order: one wave instruction reads one 1 KB image block = 32 points x 16 columns (lane (r, h)
+    // holds columns 16 gp + 4 h + {0..3} and + 8 of point r).  Wave w of the block takes the 32-column blocks
+    // cb = w, w + 4, ... of the head; a lane accumulates its 8 columns x nc outputs over the points, then the 32 lanes
+    // of a column set meet in LDS.
+    const int lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int mt_n = J.bm / 32, ncb = J.K / 32;
+    const T *X = (const T *)J.X;
+    float bs[4] = {0, 0, 0, 0};
+    for (int cb = wv; cb < ncb; cb += 4) {
+      const int cbp = J.x_col0 / 32 + cb, wave_n = cbp / J.ntw, nt = cbp % J.ntw;
+      float s[2][4][8];
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s[gp][c][e] = 0.f;
+      for (int64_t m0 = mb; m0 < me; m0 += 32) {
+        const int64_t tile = m0 / J.bm;
+        const int mt = (int)(m0 % J.bm) / 32;
+        const float *dp = J.dpre + (m0 + r) * J.ldp + J.p_col0;
+        float d[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = c < J.nc ? dp[c] : 0.f;
+        if (cb == 0 && h == 0) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) bs[c] += d[c];
+        }
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          float x[8];
+          ld8(X + (size_t)tile * J.tstride + ((((size_t)(wave_n * J.ntw + nt) * mt_n + mt) * 2 + gp) * 64 + lane) * 8, x);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[gp][c][e] += d[c] * x[e];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < J.nc) {
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              atomicAdd(&red[c * 512 + cb * 32 + 16 * gp + 4 * h + (e & 3) + 8 * (e >> 2)], s[gp][c][e]);   // LDS, 32-way
+        }
+    }
+    if (wv == 0 && h == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < J.nc) atomicAdd(&red[4 * 512 + c], bs[c]);
+    }
+  } else {
+  const T *X = (const T *)J.X + J.x_col0;
   // thread = (row group rg, 8-column group cg): every wave instruction reads whole 16-byte chunks of consecutive
   // rows (K <= 512 columns -> K/8 <= 64 column groups, 256/(K/8) rows in flight per block)
   const int ncg = J.K / 8, nrg = 256 / ncg;
@@ -636,18 +696,19 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
         }
     }
   }
-  // reduce the row groups through LDS, then ONE atomic per output element per block (same-address atomics
-  // from thousands of adders serialise at the memory side)
-  __shared__ float red[4 * 512 + 4];
-  for (int i = tid; i < 4 * 512 + 4; i += 256) red[i] = 0.f;
-  __syncthreads();
+  // row groups meet in LDS (nrg-way LDS atomics)
   if (rg < nrg) {
-    for (int c = 0; c < J.nc; ++c) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) atomicAdd(&red[c * 512 + cg * 8 + e], s[c][e]);   // LDS atomic, nrg-way
-      if (cg == 0) atomicAdd(&red[4 * 512 + c], bs[c]);
-    }
+    for (int c = 0; c < 4; ++c)
+      if (c < J.nc) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&red[c * 512 + cg * 8 + e], s[c][e]);
+        if (cg == 0) atomicAdd(&red[4 * 512 + c], bs[c]);
+      }
   }
+  }
+  // ONE global atomic per output element per block (same-address atomics from thousands of adders serialise at the
+  // memory side)
   __syncthreads();
   for (int i = tid; i < J.nc * J.K; i += 256) {
     const int c = i / J.K, k = i % J.K;
@@ -785,7 +846,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   {
     SkinnyJob &j = s.job[s.n_jobs];
     j.X = S + sl.Y[g.L - 1]; j.ldx = F; j.x_col0 = 0; j.K = F; j.dpre = (const float *)(S + sl.dpre_trunk); j.ldp = 4; j.p_col0 = 0;
-    j.nc = g.ch_normal_lr >= 0 ? 4 : 1;
+    j.nc = g.ch_normal_lr >= 0 ? 4 : 1; j.native = 0;
     for (int c = 0; c < 4; ++c) { j.out[c] = nullptr; j.bias[c] = nullptr; }
     j.out[0] = G->sigma_w; j.bias[0] = G->sigma_b;
     if (g.ch_normal_lr >= 0) {
@@ -796,7 +857,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   }
   if (a.an && G->sigma_w) {  // dw_sigma += sum_m s'(m) abar_L[m][:]
     SkinnyJob &j = s.job[s.n_jobs++];
-    j.X = S + sl.adj_abar[g.L]; j.ldx = F; j.x_col0 = 0; j.K = F; j.dpre = (const float *)(S + sl.sprime); j.ldp = 1; j.p_col0 = 0; j.nc = 1;
+    j.X = S + sl.adj_abar[g.L]; j.ldx = F; j.x_col0 = 0; j.K = F; j.dpre = (const float *)(S + sl.sprime); j.ldp = 1; j.p_col0 = 0; j.nc = 1; j.native = 0;
     for (int c = 0; c < 4; ++c) { j.out[c] = nullptr; j.bias[c] = nullptr; }
     j.out[0] = G->sigma_w;
   }
@@ -804,14 +865,14 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     if (!G->head_w2[hd]) continue;
     const int p = hd / 2, hl = hd % 2;
     SkinnyJob &j = s.job[s.n_jobs++];
-    j.X = S + sl.G[p]; j.ldx = g.pass_N[p]; j.x_col0 = hl * g.H2; j.K = g.H2;
+    j.X = S + sl.G[p]; j.ldx = 0; j.x_col0 = hl * g.H2; j.K = g.H2;
+    j.native = 1; j.bm = BM; j.ntw = g.pass_NTW[p]; j.tstride = BM * F;
     j.dpre = (const float *)(S + sl.dpre_head); j.ldp = 12; j.p_col0 = hd * 3; j.nc = desc->head_out[hd];
     for (int c = 0; c < 4; ++c) { j.out[c] = nullptr; j.bias[c] = nullptr; }
     for (int c = 0; c < j.nc; ++c) { j.out[c] = G->head_w2[hd] + (size_t)c * g.H2; j.bias[c] = G->head_b2[hd] ? G->head_b2[hd] + c : nullptr; }
   }
   if (s.n_jobs > 0) {
-    int64_t smpb = ceil_div64(sl.Mpad, 512);
-    if (smpb < 64) smpb = 64;
+    int64_t smpb = ceil_div64(ceil_div64(sl.Mpad, 512), BM) * BM;   // whole tiles per block (native jobs walk tile images)
     s.m_per_block = (int)smpb;
     dim3 grid((unsigned)ceil_div64(sl.Mpad, smpb), (unsigned)s.n_jobs);
     BnProfScope prof_(BN_K_SKINNY, st);

@@ -44,8 +44,11 @@ template <bool FAST> __device__ __forceinline__ float act_prescale(int act, floa
 
 // One pass over up to two heads: hidden = act(W1 feats + b1) kept in registers, second layer (<= 3 outputs)
 // as per-lane partial dots reduced through LDS.  NTW = 32-column tiles per wave in this pass.
+// The pass's first-layer biases and second-layer weights are staged in LDS (PRM, the positional-encoding buffer,
+// free by now) ahead of the GEMM: the epilogue then reads them without queueing behind its own stash stores.
+// The hidden activations G are stashed in accumulator order like DG (one coalesced 16-byte store per lane).
 template <typename T, int MT, int NTW, int WAVES, bool KEEP>
-__device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT, float *RED, int64_t m0, int64_t tile
+__device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT, float *PRM, float *RED, int64_t m0, int64_t tile
 #ifdef BN_PHASE_TIMING
                                           , unsigned long long (&ph_)[BN_PH_N], unsigned long long &pt_
 #endif
@@ -62,21 +65,25 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
   const int pc0 = wave * 32 * NTW;                // first column of this wave in the pass
   const bool on = pc0 < N;
   const int hl = pc0 / g.H2;                      // head inside the pass (0/1)
-  const int hd = 2 * p + hl;
+  // PRM[0][n] = b1 (pre-scaled for the fast sine), PRM[1 + c][n] = w2[c] (0 beyond the head's outputs), n < N
+  for (int n = tid; n < N; n += WAVES * 64) {
+    const int hn = n / g.H2, nl = n - hn * g.H2, hdn = 2 * p + hn;
+    const int nout = A.d.head_out[hdn];
+    PRM[n] = A.p.head_b1[hdn][nl] * act_prescale<FAST>(g.act, 1.f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) PRM[(1 + c) * N + n] = c < nout ? A.p.head_w2[hdn][(size_t)c * g.H2 + nl] : 0.f;
+  }
   f32x16 acc[NTW][MT];
   zero_acc<MT, NTW>(acc);
+  if (on) gemm_seg<T, MT, NTW>(acc, (const T *)A.packed + A.pl.fwd_head[p] + (size_t)(pc0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
+  BN_PH(9)
+  __syncthreads();   // PRM filled
   if (on) {
-    gemm_seg<T, MT, NTW>(acc, (const T *)A.packed + A.pl.fwd_head[p] + (size_t)(pc0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
-    BN_PH(9)
-    const int nout = A.d.head_out[hd];
-    const float *b1 = A.p.head_b1[hd];
-    const float *w2 = A.p.head_w2[hd];
-    T *Gs = keep ? (T *)(A.stash + A.sl.G[p]) + (size_t)m0 * N : nullptr;
+    T *Gs = keep ? (T *)(A.stash + A.sl.G[p]) + (size_t)tile * BM * F : nullptr;
     T *DGs = keep ? (T *)(A.stash + A.sl.DG[p]) + (size_t)tile * BM * F : nullptr;
     float part[MT][3];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) part[mt][0] = part[mt][1] = part[mt][2] = 0.f;
-    const float bscale = act_prescale<FAST>(g.act, 1.f);
     auto epilogue = [&](auto act_tag) {
       constexpr int ACTK = decltype(act_tag)::value;
 #pragma unroll
@@ -84,13 +91,12 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
           const int n0 = pc0 + nt * 32 + 16 * gp + 4 * h;   // column in the pass of the first run (second: +8)
-          const int nl = n0 - hl * g.H2;                     // column inside the head
-          const f32x4 ba = *(const f32x4 *)(b1 + nl) * bscale, bb = *(const f32x4 *)(b1 + nl + 8) * bscale;
+          const f32x4 ba = *(const f32x4 *)(PRM + n0), bb = *(const f32x4 *)(PRM + n0 + 8);
           f32x4 wa[3], wb[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            wa[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl) : f32x4{0, 0, 0, 0};
-            wb[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl + 8) : f32x4{0, 0, 0, 0};
+            wa[c] = *(const f32x4 *)(PRM + (1 + c) * N + n0);
+            wb[c] = *(const f32x4 *)(PRM + (1 + c) * N + n0 + 8);
           }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
@@ -100,18 +106,17 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
               act_eval<FAST, ACTK>(acc[nt][mt][8 * gp + e] + ba[e], 1.f, y[e], dd[e]);
               act_eval<FAST, ACTK>(acc[nt][mt][8 * gp + 4 + e] + bb[e], 1.f, y[4 + e], dd[4 + e]);
             }
-            const vec4 ya = to_vec4(T(), y[0], y[1], y[2], y[3]), yb = to_vec4(T(), y[4], y[5], y[6], y[7]);
+            // the second layer sees the stored (rounded) hidden value: fwd and bwd stay consistent
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = (float)(T)y[e];
             if (keep) {
-              const int m = mt * 32 + r;
-              stash_store((vec4 *)(Gs + (size_t)m * N + n0), ya);
-              stash_store((vec4 *)(Gs + (size_t)m * N + n0 + 8), yb);
+              st8(Gs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), y);
               st8(DGs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), dd);
             }
-            // the second layer sees the stored (rounded) hidden value: fwd and bwd stay consistent
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) part[mt][c] += (float)ya[e] * wa[c][e] + (float)yb[e] * wb[c][e];
+              for (int e = 0; e < 4; ++e) part[mt][c] += y[e] * wa[c][e] + y[4 + e] * wb[c][e];
           }
         }
     };
@@ -395,8 +400,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
 
   // ---------------------------------------------------------------- two-layer sigmoid heads, up to 2 per pass
   for (int p = 0; p < g.n_pass; ++p) {
-    if (g.pass_heads[p] == 2) head_pass<T, MT, NT, WAVES, KEEP>(A, p, ACT, RED, m0, tile BN_PH_ARGS);
-    else head_pass<T, MT, (NT > 1 ? NT / 2 : 1), WAVES, KEEP>(A, p, ACT, RED, m0, tile BN_PH_ARGS);
+    if (g.pass_heads[p] == 2) head_pass<T, MT, NT, WAVES, KEEP>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
+    else head_pass<T, MT, (NT > 1 ? NT / 2 : 1), WAVES, KEEP>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
   }
   BN_PH_FLUSH
 }
