@@ -226,6 +226,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
       for (int k = 0; k < KP; ++k) row[k] = (T)(k < 3 ? x[k] : 0.f);
     }
   }
+  if (tid < 8) ((int *)RED)[tid] = 0;   // ping-pong counters (RED is not used before the head passes)
   __syncthreads();
   if (keep) tile_to_global<T>(PE, LDP, (T *)(A.stash + A.sl.pe) + (size_t)m0 * KP, KP, BM, KP);
   BN_PH(0)
@@ -239,6 +240,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
   const int n_on = F / (32 * NT) < WAVES ? F / (32 * NT) : WAVES;   // waves that own output columns
   // stash copies ride inside the GEMMs when the shape fits (NT == 2 means F = 512: always, decided at compile time)
   const bool ride = NT == 2 ? true : tile_copy_exact(F, n_on, WAVES);
+  // Two-group ping-pong (F = 512: NT == 2, all eight waves own columns; bf16 mode).  Waves 0-3 (group 0) own output
+  // columns 0-255, waves 4-7 (group 1) columns 256-511; each SIMD hosts one wave of either group.  There is no
+  // workgroup barrier inside the trunk.  Every wave multiplies over input-column half 0, then half 1; group 1 is
+  // held one half-GEMM behind group 0, so group 0's (VALU) epilogue runs under group 1's second half-GEMM and group
+  // 1's epilogue under group 0's first half-GEMM of the next layer: the matrix pipe always has a wave to serve.
+  // Counters in LDS (they only grow, 4 per layer each):  WR[g] waves of group g past epilogue l;
+  // RD[h][g] waves of group g done reading column half h in layer l.
+  //   phase 1 (half 0) needs WR[0] (and, for group 1, RD[0][0]: the enforced lag); phase 2 needs WR[1];
+  //   the epilogue of group g rewrites half g: needs RD[g][0] and RD[g][1].
+#ifndef BN_NO_PINGPONG
+  constexpr bool PING = NT == 2 && WAVES == 8 && FAST;   // bf16 throughput mode only: the fp32 parity mode keeps k in order
+#else
+  constexpr bool PING = false;
+#endif
+  int *WR = (int *)RED, *RD = WR + 2;   // RD[2 * h + g]
+  const int grp = wave >> 2;
   for (int l = 0; l < g.L; ++l) {
     zero_acc<MT, NT>(acc);
     if (keep && !ride && l > 0) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[l - 1]) + (size_t)m0 * F, F, BM, F);
@@ -248,8 +265,33 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
       const T *w_h = packed + A.pl.fwd_trunk[l][l == g.skip ? 1 : 0] + t0 * KSF * 512;
       if (l == 0 || l == g.skip) gemm_seg<T, MT, NT>(acc, w_pe, KSP, PE, LDP, lane);
       if (l > 0) {
-        // the row-major stash copy of Y_{l-1} (the tile this GEMM reads) rides inside the GEMM when the shape fits
-        if (keep && ride) {
+        if (PING) {
+          const int half = KSF / 2;
+          T *ydst = (T *)(A.stash + A.sl.Y[l - 1]) + (size_t)m0 * F;
+          NoSide none;
+          BN_PH(1)
+          pp_wait(WR + 0, 4 * l);                       // half 0 of Y_{l-1} is written
+          if (grp == 1) pp_wait(RD + 0, 4 * l);         // group 0 is done with its phase 1 of this layer: the lag
+          BN_PH(12)
+          if (keep && grp == 0) {                       // a group's half of the stash copy rides in the phase that reads it
+            TileCopyHalf<T> ycopy(ACT, LDA, ydst, F, 0, F / 2, tid & 255);
+            gemm_range<T, MT, NT>(acc, w_h, KSF, 0, half, ACT, LDA, lane, ycopy);
+          } else {
+            gemm_range<T, MT, NT>(acc, w_h, KSF, 0, half, ACT, LDA, lane, none);
+          }
+          BN_PH(1)
+          pp_signal(RD + 0 + grp, lane);
+          pp_wait(WR + 1, 4 * l);                       // half 1
+          BN_PH(13)
+          if (keep && grp == 1) {
+            TileCopyHalf<T> ycopy(ACT, LDA, ydst, F, F / 2, F / 2, tid & 255);
+            gemm_range<T, MT, NT>(acc, w_h, KSF, half, half, ACT, LDA, lane, ycopy);
+          } else {
+            gemm_range<T, MT, NT>(acc, w_h, KSF, half, half, ACT, LDA, lane, none);
+          }
+          pp_signal(RD + 2 + grp, lane);
+        } else if (keep && ride) {
+          // the row-major stash copy of Y_{l-1} (the tile this GEMM reads) rides inside the GEMM when the shape fits
           TileCopyExact<T> ycopy(ACT, LDA, (T *)(A.stash + A.sl.Y[l - 1]) + (size_t)m0 * F, F, F, tid, WAVES * 64);
           gemm_seg<T, MT, NT>(acc, w_h, KSF, ACT, LDA, lane, ycopy);
         } else {
@@ -274,7 +316,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
         }
     }
     BN_PH(1)
-    __syncthreads();  // every wave has finished reading ACT (in-place update below)
+    if (PING) {
+      if (l > 0) {   // all eight waves have read this group's columns of Y_{l-1}
+        pp_wait(RD + 2 * grp + 0, 4 * l);
+        pp_wait(RD + 2 * grp + 1, 4 * l);
+      }
+    } else {
+      __syncthreads();  // every wave has finished reading ACT (in-place update below)
+    }
     BN_PH(2)
     if (wave_on) {
       T *Ds = keep ? (T *)(A.stash + A.sl.D[l]) + (size_t)tile * BM * F : nullptr;
@@ -305,9 +354,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
       else epilogue(std::integral_constant<int, BN_ACT_RELU>());
     }
     BN_PH(3)
-    __syncthreads();
+    if (PING) pp_signal(WR + grp, lane);
+    else __syncthreads();
     BN_PH(4)
   }
+  if (PING) __syncthreads();   // both halves of the last layer are in LDS (every wave signalled before arriving here)
 
   // ---------------------------------------------------------------- sigma (+ learned normal): VALU dots over h8
   {

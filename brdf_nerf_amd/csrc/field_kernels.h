@@ -116,6 +116,41 @@ template <typename T> struct TileCopyExact {
 };
 __host__ __device__ __forceinline__ bool tile_copy_exact(int F, int n_on, int waves) { return n_on == waves && F % 256 == 0; }
 
+// Ping-pong form (F = 512, 8 waves in two groups of four): a group copies ITS half (halfw columns from col0) of the
+// tile, one chunk per thread at every k-step of its 16-step own-half segment (256 threads x 16 chunks = the half tile
+// for both element types: 128 rows x 512 B in bf16, 64 rows x 1 KB in fp32).
+template <typename T> struct TileCopyHalf {
+  static constexpr int EPC = 16 / sizeof(T);
+  const T *lp;
+  T *gp;
+  int lstep, gstep;
+  __device__ __forceinline__ TileCopyHalf(const T *lds, int ld, T *g, int gld, int col0, int halfw, int tg) {
+    const int cph = halfw / EPC, row = tg / cph, col = col0 + (tg % cph) * EPC, rstep = 256 / cph;
+    lp = lds + (size_t)row * ld + col;
+    gp = g + (size_t)row * gld + col;
+    lstep = rstep * ld; gstep = rstep * gld;
+  }
+  __device__ __forceinline__ void at(int) {
+    stash_store((u32x4 *)gp, *(const u32x4 *)lp);
+    lp += lstep; gp += gstep;
+  }
+};
+
+// Flags of the two-group ping-pong (LDS ints, zeroed before first use): counters only grow; a waiter spins with
+// s_sleep until the count is reached.  LDS executes one wave's operations in issue order, so data written before a
+// signal is visible to whoever sees the signal.  The spin is bounded (a count that is never reached in a correct run):
+// every wave reaches its exit even if a signal were lost.
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ void pp_wait(int *flag, int target) {
+  volatile lds_int *f = (volatile lds_int *)flag;
+  for (int spin = 0; *f < target && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void pp_signal(int *flag, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add((lds_int *)flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 #ifndef BN_DEPTH_BF16
 #define BN_DEPTH_BF16 4
 #endif
@@ -123,20 +158,22 @@ template <typename T> struct PipeDepth { static constexpr int value = 4; };
 template <> struct PipeDepth<bf16> { static constexpr int value = BN_DEPTH_BF16; };
 
 template <typename T, int MT, int NTW, typename Side>
-__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb,
-                                         int lane, Side &side) {
+__device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, int ks0, int nks, const T *bsrc,
+                                           int ldb, int lane, Side &side) {
+  // k-steps [ks0, ks0 + nks) of a packed matrix whose n-tiles are KS k-steps apart
   typedef typename Elem<T>::frag frag;
   constexpr int DEPTH = PipeDepth<T>::value;
   static_assert(DEPTH % 2 == 0, "side jobs rely on an even pipeline depth");
   const int r = lane & 31, h = lane >> 5;
   const T *wl = wp + (size_t)lane * 8;
   const T *bl = bsrc + (size_t)r * ldb + 8 * h;
+  const int kend = ks0 + nks;
   frag A[DEPTH][NTW], Bc[MT];
   auto loadA = [&](frag(&a)[NTW], int ks) {
 #ifdef BN_SKIP_A       // diagnostic variant (profiles/ab_bench.sh): no weight stream after the prologue
-    if (ks >= DEPTH) return;
+    if (ks >= ks0 + DEPTH) return;
 #endif
-    ks = ks < KS ? ks : KS - 1;
+    ks = ks < kend ? ks : kend - 1;
     {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) a[nt] = gld_frag<T>(wl + ((size_t)nt * KS + ks) * 512);
@@ -152,7 +189,7 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__rest
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) Bn[mt] = Bc[mt];
 #else
-    loadB(Bn, ks + 1 < KS ? ks + 1 : 0);
+    loadB(Bn, ks + 1 < kend ? ks + 1 : ks0);
 #endif
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
@@ -162,11 +199,11 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__rest
     for (int mt = 0; mt < MT; ++mt) Bc[mt] = Bn[mt];
   };
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) loadA(A[d], d);
-  loadB(Bc, 0);
+  for (int d = 0; d < DEPTH; ++d) loadA(A[d], ks0 + d);
+  loadB(Bc, ks0);
   __builtin_amdgcn_sched_barrier(0);
-  int ks = 0;
-  for (; ks + DEPTH <= KS; ks += DEPTH) {
+  int ks = ks0;
+  for (; ks + DEPTH <= kend; ks += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       step(A[d], ks + d);
@@ -177,16 +214,21 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__rest
   }
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
-    if (ks + d < KS) {
+    if (ks + d < kend) {
       step(A[d], ks + d);
       side.at(d & 1);
     }
+}
+template <typename T, int MT, int NTW, typename Side>
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb,
+                                         int lane, Side &side) {
+  gemm_range<T, MT, NTW, Side>(acc, wp, KS, 0, KS, bsrc, ldb, lane, side);
 }
 template <typename T, int MT, int NTW>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb,
                                          int lane) {
   NoSide none;
-  gemm_seg<T, MT, NTW, NoSide>(acc, wp, KS, bsrc, ldb, lane, none);
+  gemm_range<T, MT, NTW, NoSide>(acc, wp, KS, 0, KS, bsrc, ldb, lane, none);
 }
 
 template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NTW][MT]) {

@@ -53,7 +53,7 @@ if __name__ == "__main__":
     b = bench.synthetic_batch(4096, 1, dev)
     z = torch.sort(torch.rand(4096, 128, device=dev) * 2, -1)[0]
     FWD = ["pe", "gemm", "bar_gemm", "epilogue", "bar_epi", "stash", "sigma", "feats_gemm", "feats_epi+stash", "head_gemm",
-           "head_epi", "head_reduce"]
+           "head_epi", "head_reduce", "pp_wait_h0", "pp_wait_h1"]
     BWD = ["seed", "head_dG", "bar", "dG_stash", "head_gemm", "bar", "dfeats_epi", "bar", "dfeats_stash", "gemm", "bar_gemm",
            "epilogue", "bar_epi", "dZ_stash"]
     buf = (ctypes.c_ulonglong * 17)()
