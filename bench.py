@@ -29,7 +29,9 @@ PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3       # fp32-input MFMA
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.txt); valid for the
 # default workload only (lambert, 4096 rays, 64+64 samples, bf16), otherwise `traffic` is null
-PMC_TRAFFIC_BYTES = {"field_fwd_full": 10.8e9 / 2, "field_bwd_chain": 10.2e9 / 2, "wgrad": 14.6e9 / 2}   # two launches per step
+# HBM-side bytes per launch of the default workload (262,144 points per launch, two launches per step), from rocprofv3
+# PMC passes over profiles/prof_step.py: 2 x FETCH_SIZE + WRITE_SIZE (profiles/r01_pmc_traffic.txt)
+PMC_TRAFFIC_BYTES = {"field_fwd_full": 5.15e9, "field_bwd_chain": 5.07e9, "wgrad": 7.42e9}
 
 
 def flops_per_point(F=512, P=60, L=8, n_heads=1):

@@ -13,7 +13,7 @@ spec = model.spec(False, False, False)
 packed = model.repack(spec)
 b = bench.synthetic_batch(4096, 1, dev)
 z = torch.sort(torch.rand(4096, 128, device=dev) * 2, -1)[0]
-for i in range(4):
+for i in range(30):
     Fn.field_sigma(spec, model.named(), packed, rays=b["rays"], z=z)
 torch.cuda.synchronize()
 print("done")
