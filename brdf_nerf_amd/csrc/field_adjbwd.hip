@@ -84,17 +84,25 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
   const bool wave_on = ncol0 < F;
   const int KSP = KP / 16, KSF = F / 16;
   f32x16 acc[NT][MT];
+  const int n_on = F / (32 * NT) < WAVES ? F / (32 * NT) : WAVES;
+  // the row-major stash copy of abar_l (the tile layer l's GEMM reads) rides inside that GEMM when the shape fits
+  const bool ride = NT == 2 ? true : tile_copy_exact(F, n_on, WAVES);
   for (int l = 0; l < g.L; ++l) {
     zero_acc<MT, NT>(acc);
+    T *adst = (T *)(A.stash + A.sl.adj_abar[l]) + (size_t)m0 * F;   // abar_l, l >= 1
+    if (!ride && l > 0) tile_to_global<T>(ACT, LDA, adst, F, BM, F);
     if (wave_on) {
       const size_t t0 = (size_t)(ncol0 / 32);
-      if (l == 0) {
-        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512, KSP, PE, LDP, lane);
-      } else if (l == g.skip) {
-        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512, KSP, PE, LDP, lane);
-        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][1] + t0 * KSF * 512, KSF, ACT, LDA, lane);
-      } else {
-        gemm_seg<T, MT, NT>(acc, packed + A.pl.fwd_trunk[l][0] + t0 * KSF * 512, KSF, ACT, LDA, lane);
+      const T *w_pe = packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512;
+      const T *w_h = packed + A.pl.fwd_trunk[l][l == g.skip ? 1 : 0] + t0 * KSF * 512;
+      if (l == 0 || l == g.skip) gemm_seg<T, MT, NT>(acc, w_pe, KSP, PE, LDP, lane);
+      if (l > 0) {
+        if (ride) {
+          TileCopyExact<T> acopy(ACT, LDA, adst, F, F, tid, WAVES * 64);
+          gemm_seg<T, MT, NT>(acc, w_h, KSF, ACT, LDA, lane, acopy);
+        } else {
+          gemm_seg<T, MT, NT>(acc, w_h, KSF, ACT, LDA, lane);
+        }
       }
     }
     __syncthreads();
@@ -132,8 +140,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
         }
     }
     __syncthreads();
-    tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.adj_abar[l + 1]) + (size_t)m0 * F, F, BM, F);
   }
+  // abar_L (the tile the loop leaves in LDS) has no later GEMM to ride in
+  tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.adj_abar[g.L]) + (size_t)m0 * F, F, BM, F);
 
   // ---------------------------------------------------------------- sbar = (w_sigma . abar_L) s'(1-s')
   {

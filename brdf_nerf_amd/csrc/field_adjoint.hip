@@ -21,7 +21,7 @@ struct AdjArgs {
   int keep;         // 1: training - also stash delta_l (row-major), a_{l+1} (native), sigmoid(s_raw), grad_x
 };
 
-template <typename T, int MT, int NT, int WAVES>
+template <typename T, int MT, int NT, int WAVES, bool KEEP>
 __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjArgs A) {
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
 
   for (int i = tid; i < BM * P; i += WAVES * 64) GP[i] = 0.f;
   char *wstash = const_cast<char *>(A.stash);
-  const bool keep = A.keep != 0;
+  constexpr bool keep = KEEP;   // training: stash delta_l / a_l for the backward of this chain
   if (keep && tid < BM) ((float *)(wstash + A.sl.sprime))[m0 + tid] = sigmoid_f(sraw[m0 + tid]);
 
   // delta_{L-1} = (sigmoid(s_raw) w_sigma) (.) D_{L-1}
@@ -71,8 +71,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
   __syncthreads();
 
   f32x16 acc[NT][MT];
+  const int n_on = F / (32 * NT) < WAVES ? F / (32 * NT) : WAVES;
+  // the row-major stash copy of delta_l (the tile the trunk GEMM reads) rides inside that GEMM when the shape fits
+  const bool ride = NT == 2 ? true : tile_copy_exact(F, n_on, WAVES);
   for (int l = g.L - 1; l >= 0; --l) {
-    if (keep) tile_to_global<T>(ACT, LDA, (T *)(wstash + A.sl.adj_delta[l]) + (size_t)m0 * F, F, BM, F);
+    T *ddst = (T *)(wstash + A.sl.adj_delta[l]) + (size_t)m0 * F;
+    if (keep && (!ride || l == 0)) tile_to_global<T>(ACT, LDA, ddst, F, BM, F);
     // ACT holds delta_l.  PE-part product (only where the layer reads the encoding): wave -> (p-tile, m-tile)
     if (l == 0 || l == g.skip) {
       const int ptile = wave & 1, mtile = wave >> 1;
@@ -93,10 +97,30 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
     }
     if (l == 0) break;
     zero_acc<MT, NT>(acc);
-    if (wave_on) gemm_seg<T, MT, NT>(acc, packed + A.pl.bwd_trunk[l] + (size_t)(ncol0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
+    // D_{l-1} in accumulator order, prefetched around the GEMM (n-tile 0 before it, the rest after its last MFMA)
+    const T *Ds = (const T *)(A.stash + A.sl.D[l - 1]) + (size_t)tile * BM * F;
+    typename Elem<T>::frag dpre[NT][2][MT];
+    if (wave_on) {
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) dpre[0][gp][mt] = stash_load((const typename Elem<T>::frag *)(Ds + native_off8<MT, NT>(wave, 0, mt, gp, lane)));
+      const T *w_t = packed + A.pl.bwd_trunk[l] + (size_t)(ncol0 / 32) * KSF * 512;
+      if (keep && ride) {
+        TileCopyExact<T> dcopy(ACT, LDA, ddst, F, F, tid, WAVES * 64);
+        gemm_seg<T, MT, NT>(acc, w_t, KSF, ACT, LDA, lane, dcopy);
+      } else {
+        gemm_seg<T, MT, NT>(acc, w_t, KSF, ACT, LDA, lane);
+      }
+#pragma unroll
+      for (int nt = 1; nt < NT; ++nt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) dpre[nt][gp][mt] = stash_load((const typename Elem<T>::frag *)(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane)));
+    }
     __syncthreads();
     if (wave_on) {
-      const T *Ds = (const T *)(A.stash + A.sl.D[l - 1]) + (size_t)tile * BM * F;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -105,7 +129,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             float dv[8];
-            ld8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dv[e] = (float)dpre[nt][gp][mt][e];
             const int m = mt * 32 + r;
             if (keep) {
               float av[8];
@@ -160,12 +185,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
   }
 }
 
+template <typename T, int MT, int NT, int WAVES, bool KEEP> static int launch_adj_k(const AdjArgs &a, int64_t tiles, hipStream_t st);
 template <typename T, int MT, int NT, int WAVES> static int launch_adj(const AdjArgs &a, int64_t tiles, hipStream_t st) {
+  return a.keep ? launch_adj_k<T, MT, NT, WAVES, true>(a, tiles, st) : launch_adj_k<T, MT, NT, WAVES, false>(a, tiles, st);
+}
+template <typename T, int MT, int NT, int WAVES, bool KEEP> static int launch_adj_k(const AdjArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = (size_t)BM * (a.g.F + Elem<T>::kPad) * sizeof(T) + (size_t)BM * a.g.P * sizeof(float);
   static size_t configured = 0;
   if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)field_adjoint_kernel<T, MT, NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)field_adjoint_kernel<T, MT, NT, WAVES, KEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       bn_set_error("field_normals: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
       return BN_ELAUNCH;
@@ -173,7 +202,7 @@ template <typename T, int MT, int NT, int WAVES> static int launch_adj(const Adj
     configured = lds;
   }
   BnProfScope prof_(BN_K_ADJOINT, st);
-  field_adjoint_kernel<T, MT, NT, WAVES><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
+  field_adjoint_kernel<T, MT, NT, WAVES, KEEP><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_normals");
   return 0;
 }
