@@ -16,8 +16,13 @@ from .rendering import shade
 
 class FusedTrainer:
     def __init__(self, model, args, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lambda_rgb=1.0, ds_lambda=0.0,
-                 usealldepth=False, process_group=None, strict_rng=True, reuse_coarse=True):
+                 usealldepth=False, process_group=None, strict_rng=True, reuse_coarse=True, nr_reg_an_lambda=0.0,
+                 nr_reg_lr_lambda=0.0, hs_lambda=0.0, nr_spv_lambda=0.0):
+        """The regulariser lambdas are the reference's --nr_reg_an_lambda / --nr_reg_lr_lambda / --hs_lambda /
+        --nr_spv_lambda (opt.py:232-246, all 0 by default); WHEN they act (train_steps > nrrg_on, epoch > 2, main.py:271-327)
+        is the caller's schedule: pass regularisers=False to step() until then."""
         self.model, self.args = model, args
+        self.reg = dict(nr_an=nr_reg_an_lambda, nr_lr=nr_reg_lr_lambda, hs=hs_lambda, nr_spv=nr_spv_lambda)
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.lambda_rgb, self.ds_lambda, self.usealldepth = lambda_rgb, ds_lambda, usealldepth
         self.pg, self.strict_rng, self.reuse_coarse = process_group, strict_rng, reuse_coarse
@@ -65,7 +70,7 @@ class FusedTrainer:
 
     # ------------------------------------------------------------------ one step
     def step(self, rays, rgbs, valid_depth=None, depths=None, depth_std=None, apply_brdf=False, apply_theta=False,
-             cos_irra_on=False, depth_loss_on=True, near_far=None):
+             cos_irra_on=False, depth_loss_on=True, near_far=None, regularisers=True):
         model, args = self.model, self.args
         S, G = args.n_samples, args.guided_samples
         R = rays.shape[0]
@@ -124,7 +129,8 @@ class FusedTrainer:
                 Fn.field_forward_raw(spec, named, packed, out, stash, rays=rays, z=z_all)
                 out3 = out.view(R, S2, C)
             alphas, trans, weights, depth, acc = Fn.composite_forward_raw(z_all, out3, noise2, args.noise_std)
-        # ray-level loss glue under autograd (leaves: acc, depth, weights)
+        # ray-level loss glue under autograd (leaves: acc, depth, weights; the per-sample normals too when a regulariser
+        # reads them)
         acc_l, depth_l, weights_l = acc.requires_grad_(True), depth.requires_grad_(True), weights.requires_grad_(True)
         res, _ = shade(model, args, spec, out3, z_all, alphas, trans, weights_l, depth_l, acc_l, rays_d, sun_d, apply_brdf,
                        cos_irra_on)
@@ -132,7 +138,24 @@ class FusedTrainer:
         if self.ds_lambda > 0 and depth_loss_on and valid_depth is not None:
             loss = loss + losses.depth_loss(z_all, depth_l, weights_l, depths[:, 0], depths[:, 1], valid_depth, depth_std,
                                             self.ds_lambda, self.usealldepth)
-        d_acc, d_depth, d_weights = torch.autograd.grad(loss, [acc_l, depth_l, weights_l], allow_unused=True)
+        reg = self.reg if regularisers else {}
+        n_leaf = {}                                   # channel offset -> per-sample normal leaf
+        def normal_leaf(key):
+            c0 = spec.ch_normal_an if key == "normal_an" else spec.ch_normal_lr
+            if c0 not in n_leaf:
+                n_leaf[c0] = out3[..., c0:c0 + 3].detach().clone().requires_grad_(True)
+            return n_leaf[c0]
+        if reg.get("nr_an", 0) > 0 and spec.normal_an:
+            loss = loss + losses.normal_reg_loss(normal_leaf("normal_an"), weights_l, -rays_d, reg["nr_an"])[0]
+        if reg.get("nr_lr", 0) > 0 and spec.normal_lr:
+            loss = loss + losses.normal_reg_loss(normal_leaf("normal_lr"), weights_l, -rays_d, reg["nr_lr"])[0]
+        if reg.get("hs", 0) > 0:
+            loss = loss + losses.hard_surface_loss(z_all, depth_l, weights_l, reg["hs"])
+        if abs(reg.get("nr_spv", 0)) > 1e-5 and spec.normal_an and spec.normal_lr:   # nr_spv_type 1 (main.py:297-303)
+            loss = loss + losses.normal_loss(weights_l, normal_leaf("normal_an"), normal_leaf("normal_lr"), reg["nr_spv"])
+        leaves = [acc_l, depth_l, weights_l] + list(n_leaf.values())
+        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        d_acc, d_depth, d_weights = grads[:3]
         with torch.no_grad():
             if d_acc is not None:
                 d_acc = d_acc.contiguous()
@@ -140,6 +163,9 @@ class FusedTrainer:
             d_out = Fn.composite_backward_raw(z_all, out3, None if d_weights is None else d_weights.contiguous(),
                                               None if d_depth is None else d_depth.contiguous(), d_acc, noise2, args.noise_std,
                                               self._buf("d_out", (R, S2, C)))
+            for c0, dn in zip(n_leaf.keys(), grads[3:]):
+                if dn is not None:
+                    d_out[..., c0:c0 + 3] += dn          # regulariser gradients on the per-sample normals
             self.flat_grad.zero_()
             if self.reuse_coarse:
                 d_cat = self._buf("d_cat", (R, S2, C)).scatter_(1, idx_c, d_out)             # back to [coarse | guided] order

@@ -376,9 +376,43 @@ def gen_loss(ref):
          dweights=w.grad if w.grad is not None else torch.zeros_like(w), psnr=torch.as_tensor(psnr[0]))
 
 
+def gen_regularisers(ref):
+    """NormalRegLoss, HardSurfaceLoss, NormalLoss (metrics.py:179-290) on seeded per-sample tensors, with gradients."""
+    R, S = 48, 24
+    g = torch.Generator().manual_seed(77)
+    z = torch.sort(torch.rand(R, S, generator=g) * 2, -1)[0]
+    w = torch.softmax(torch.randn(R, S, generator=g) * 2, -1).requires_grad_(True)
+    depth = (w * z).sum(-1).detach().clone().requires_grad_(True)
+    unit = lambda t: t / t.norm(dim=-1, keepdim=True)
+    n_an = unit(torch.randn(R, S, 3, generator=g)).requires_grad_(True)
+    n_lr = unit(torch.randn(R, S, 3, generator=g)).requires_grad_(True)
+    view = unit(torch.randn(R, 3, generator=g) * 0.3 + torch.tensor([0.0, 0.0, 1.0]))
+    n_gt = unit(torch.randn(R, 3, generator=g) * 0.3 + torch.tensor([0.0, 0.0, 1.0]))
+    valid = (torch.rand(R, generator=g) < 0.7).float()
+    tw = torch.rand(R, generator=g)
+    inputs = {"normal_an_coarse": n_an, "normal_lr_coarse": n_lr, "weights_coarse": w, "rays_d_coarse": view,
+              "z_vals_coarse": z, "depth_coarse": depth}
+    m = ref["metrics"]
+    l_an, _, perc_an = quiet(m.NormalRegLoss(lambda_nr_reg=0.1, keyword="normal_an"), inputs)
+    l_lr, _, perc_lr = quiet(m.NormalRegLoss(lambda_nr_reg=0.05, keyword="normal_lr"), inputs)
+    l_hs, _ = quiet(m.HardSurfaceLoss(lambda_hs=0.5), inputs)
+    nl = m.NormalLoss(lambda_nr_spv=0.01)
+    l_n1, _ = quiet(nl, w, n_an, n_lr, keyword="an_lr")
+    l_n3, _ = quiet(nl, w, n_gt, n_an, target_weight=tw, target_valid_depth=valid, keyword="an")
+    total = l_an + l_lr + l_hs + l_n1 + l_n3
+    total.backward()
+    save("loss_regularisers", z=z, weights=w, depth=depth, normal_an=n_an, normal_lr=n_lr, view=view, normal_gt=n_gt,
+         valid_depth=valid, target_weight=tw, l_nr_an=l_an, l_nr_lr=l_lr, perc_an=torch.as_tensor(float(perc_an)),
+         perc_lr=torch.as_tensor(float(perc_lr)), l_hs=l_hs, l_n1=l_n1, l_n3=l_n3, d_weights=w.grad, d_depth=depth.grad,
+         d_normal_an=n_an.grad, d_normal_lr=n_lr.grad)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     ref = import_reference()
+    if "--only-regularisers" in sys.argv:
+        gen_regularisers(ref)
+        sys.exit(0)
     if "--only-render" in sys.argv:
         gen_render(ref)
         sys.exit(0)
@@ -388,3 +422,4 @@ if __name__ == "__main__":
     gen_brdf(ref)
     gen_render(ref)
     gen_loss(ref)
+    gen_regularisers(ref)

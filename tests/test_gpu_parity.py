@@ -716,6 +716,47 @@ def test_fused_trainer_matches_autograd_path(name, with_depth):
     assert list(sd) == [k for k, _, _ in cfg.param_shapes()]
 
 
+@pytest.mark.parametrize("name", ["rpv111_nlr", "rpv111_nan"])
+def test_fused_trainer_regularisers_match_autograd_path(name):
+    """NormalRegLoss + HardSurfaceLoss (metrics.py:179-290) inside the fused step: the per-sample normals become extra
+    leaves of the loss glue and their gradients join d_out; compared with autograd through render_rays."""
+    from brdf_nerf_amd import render_rays, losses
+    from brdf_nerf_amd.trainer import FusedTrainer
+    allc = dict(CONFIGS, **CONFIGS_AN)
+    cfg = mini(**allc[name])
+    args = make_args(cfg)
+    g = torch.Generator().manual_seed(8)
+    R, S, G = 64, cfg.n_samples, cfg.guided_samples
+    gold = load_golden("render_lambert_train")
+    rays = torch.from_numpy(gold["rays"])[:R // 2].repeat(2, 1).contiguous().to(DEV)
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    draws = [torch.rand(R, S, generator=g), torch.randn(R, S, generator=g), torch.rand(R, G, generator=g),
+             torch.randn(R, S + G, generator=g)]
+    flags = dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)
+    key = "normal_an" if cfg.normal == "analystic" else "normal_lr"
+    lam = dict(nr_reg_an_lambda=0.3) if key == "normal_an" else dict(nr_reg_lr_lambda=0.3)
+
+    ma = build_model(cfg, 5)
+    with Replay(list(draws)):
+        res, _ = render_rays({"coarse": ma}, args, rays, None, mode="train", **flags)
+    loss_a = losses.snerf_loss(res["rgb_coarse"], rgbs)
+    loss_a = loss_a + losses.normal_reg_loss(res[f"{key}_coarse"], res["weights_coarse"], res["rays_d_coarse"].squeeze(1), 0.3)[0]
+    loss_a = loss_a + losses.hard_surface_loss(res["z_vals_coarse"], res["depth_coarse"], res["weights_coarse"], 0.5)
+    loss_a.backward()
+
+    mb = build_model(cfg, 5)
+    tr = FusedTrainer(mb, args, lr=5e-4, hs_lambda=0.5, **lam)
+    with Replay(list(draws)):
+        loss_b, _ = tr.step(rays, rgbs, **flags)
+    assert_close(loss_b, loss_a.detach(), 1e-5, 1e-7, "loss")
+    for k, v in ma.named_parameters():
+        if v.grad is None:
+            continue
+        gb = tr.grad_views[k]
+        scale = float(v.grad.abs().max())
+        assert float((gb - v.grad).abs().max()) <= 2e-4 * scale + 1e-9, f"grad {k}"
+
+
 @pytest.mark.parametrize("name", ["lambert", "rpv111_nan"])
 def test_trainer_coarse_reuse_equals_full_reevaluation(name):
     """reuse_coarse=True (pass-1 evaluation kept, pass 2 only on the guided samples) must give the reference pipeline's

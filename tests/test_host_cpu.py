@@ -134,6 +134,28 @@ def test_losses_match_golden():
     assert_close(losses.psnr(t["rgb"], t["tgt"]), g["psnr"], 1e-6, 1e-6, "psnr")
 
 
+def test_regulariser_losses_match_golden():
+    """NormalRegLoss / HardSurfaceLoss / NormalLoss in their mask (sync-free) form against the reference's values and
+    gradients (tests/golden/loss_regularisers.npz)."""
+    from brdf_nerf_amd import losses
+    g = load_golden("loss_regularisers")
+    t = {k: torch.from_numpy(v) for k, v in g.items()}
+    w, depth, n_an, n_lr = [t[k].clone().requires_grad_(True) for k in ("weights", "depth", "normal_an", "normal_lr")]
+    l_an, perc_an = losses.normal_reg_loss(n_an, w, t["view"], 0.1)
+    l_lr, perc_lr = losses.normal_reg_loss(n_lr, w, t["view"], 0.05)
+    l_hs = losses.hard_surface_loss(t["z"], depth, w, 0.5)
+    l_n1 = losses.normal_loss(w, n_an, n_lr, 0.01, "an_lr")
+    l_n3 = losses.normal_loss(w, t["normal_gt"], n_an, 0.01, "an", target_weight=t["target_weight"], valid_depth=t["valid_depth"])
+    for name, got in (("l_nr_an", l_an), ("l_nr_lr", l_lr), ("l_hs", l_hs), ("l_n1", l_n1), ("l_n3", l_n3)):
+        assert_close(got, g[name], 1e-5, 1e-9, name)
+    assert abs(float(perc_an) - float(g["perc_an"])) < 1e-3 and abs(float(perc_lr) - float(g["perc_lr"])) < 1e-3
+    (l_an + l_lr + l_hs + l_n1 + l_n3).backward()
+    assert_close(w.grad, g["d_weights"], 1e-5, 1e-9, "d_weights")
+    assert_close(depth.grad, g["d_depth"], 1e-5, 1e-9, "d_depth")
+    assert_close(n_an.grad, g["d_normal_an"], 1e-5, 1e-10, "d_normal_an")
+    assert_close(n_lr.grad, g["d_normal_lr"], 1e-5, 1e-10, "d_normal_lr")
+
+
 def test_shard_bounds_cover_rows():
     from brdf_nerf_amd.distributed import shard_bounds
     for n, w in ((4096, 8), (1000, 3), (7, 8), (0, 2)):

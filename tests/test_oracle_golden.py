@@ -236,3 +236,24 @@ def test_render_variants_multibrdf_gsamonly(tag, extra, gs):
             assert np.array_equal(res[k].numpy(), g["out/" + k])
         else:
             assert_close(res[k], g["out/" + k], 2e-4, 2e-5, k)
+
+
+def test_regulariser_losses():
+    g = load_golden("loss_regularisers")
+    t = {k: torch.from_numpy(v) for k, v in g.items()}
+    w, depth, n_an, n_lr = [t[k].clone().requires_grad_(True) for k in ("weights", "depth", "normal_an", "normal_lr")]
+    res = {"normal_an_coarse": n_an, "normal_lr_coarse": n_lr, "weights_coarse": w, "rays_d_coarse": t["view"],
+           "z_vals_coarse": t["z"], "depth_coarse": depth}
+    l_an, perc_an = L.normal_reg_loss(res, "normal_an", 0.1)
+    l_lr, perc_lr = L.normal_reg_loss(res, "normal_lr", 0.05)
+    l_hs = L.hard_surface_loss(res, 0.5)
+    l_n1 = L.normal_loss(w, n_an, n_lr, 0.01, "an_lr")
+    l_n3 = L.normal_loss(w, t["normal_gt"], n_an, 0.01, "an", target_weight=t["target_weight"], valid_depth=t["valid_depth"])
+    for name, got in (("l_nr_an", l_an), ("l_nr_lr", l_lr), ("l_hs", l_hs), ("l_n1", l_n1), ("l_n3", l_n3)):
+        assert_close(got, g[name], 1e-5, 1e-9, name)
+    assert abs(perc_an - float(g["perc_an"])) < 1e-3 and abs(perc_lr - float(g["perc_lr"])) < 1e-3
+    (l_an + l_lr + l_hs + l_n1 + l_n3).backward()
+    assert_close(w.grad, g["d_weights"], 1e-5, 1e-9, "d_weights")
+    assert_close(depth.grad, g["d_depth"], 1e-5, 1e-9, "d_depth")
+    assert_close(n_an.grad, g["d_normal_an"], 1e-5, 1e-10, "d_normal_an")
+    assert_close(n_lr.grad, g["d_normal_lr"], 1e-5, 1e-10, "d_normal_lr")
