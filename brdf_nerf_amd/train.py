@@ -1,0 +1,112 @@
+"""Training loop around the fused step, without Lightning (reference main.py:31-118,
+194-353, 694-736): stage schedule, on-device ray table, StepLR(0.9 / epoch), checkpoints in the reference's layout
+(`{"state_dict": {"nerf_coarse.<name>": tensor}, "epoch", "global_step"}` so eval.py:26-54 / main.py:97-104 can load
+them, plus the optimiser and schedule state this loop needs to resume), `opts.json` beside them.
+
+    loop = TrainLoop(args, table)            # args: the reference's argparse namespace
+    loop.run(n_steps)                        # or loop.step() one at a time
+"""
+import json
+import os
+
+import torch
+
+from .distributed import world_info
+from .evaluate import load_ckpt
+from .field import load_model
+from .losses import psnr
+from .schedule import StageSchedule
+from .trainer import FusedTrainer
+
+
+class TrainLoop:
+    def __init__(self, args, table, device=None, compute_dtype=None, process_group=None, near_far=None):
+        """near_far: the (near, far) pair the guided-sampling clamp uses (rendering.py:133 reads row 0 of the batch;
+        satellite batches share one pair per image) - pass it to keep the step free of device->host reads."""
+        self.args, self.table, self.near_far = args, table, near_far
+        self.rank, self.world = world_info()
+        dev = torch.device(device) if device is not None else table.device
+        self.model = load_model(args, compute_dtype).to(dev)
+        in_ckpts = getattr(args, "in_ckpts", "none")
+        if in_ckpts != "none":                              # stage-2 warm start of the shared sub-modules (main.py:97-104)
+            subs = ["fc_net", "sigma_from_xyz", "feats_from_xyz"] + ([] if args.b == True else ["rgb_from_xyzdir"])  # noqa: E712
+            for sub in subs:
+                load_ckpt(self.model, in_ckpts, model_name=f"nerf_coarse.{sub}", drop_len=11)
+        g = lambda k, d=0.0: getattr(args, k, d)
+        self.trainer = FusedTrainer(self.model, args, lr=args.lr, lambda_rgb=g("lambda_rgb", 1.0), ds_lambda=g("ds_lambda"),
+                                    usealldepth=bool(g("usealldepth", False)), process_group=process_group, strict_rng=False,
+                                    nr_reg_an_lambda=g("nr_reg_an_lambda"), nr_reg_lr_lambda=g("nr_reg_lr_lambda"),
+                                    hs_lambda=g("hs_lambda"), nr_spv_lambda=g("nr_spv_lambda") if g("nr_spv_type", 1) == 1 else 0.0)
+        self.schedule = StageSchedule(args, len(table), self.world)
+        self.global_step = 0
+        self.last = {}
+
+    # ------------------------------------------------------------------ one optimisation step
+    def step(self):
+        a, tr, sch = self.args, self.trainer, self.schedule
+        flags = sch.begin_step()
+        tr.lr = sch.lr(self.global_step)
+        b = self.table.next_batch(a.batch_size * self.world, self.rank, self.world)
+        if flags["gsam_only"]:
+            raise NotImplementedError("gsam_only training (pass 2 on the guided samples only) is not wired into the fused step")
+        has_depth = "depths" in b
+        depths = b.get("depths")
+        if has_depth and getattr(a, "ds_noweights", False):
+            depths = depths.clone()
+            depths[:, 1] = 1.0
+        reg = dict(tr.reg)
+        if not flags["nr_reg_on"]:
+            reg["nr_an"] = reg["nr_lr"] = 0.0
+        if not flags["hs_on"]:
+            reg["hs"] = 0.0
+        saved, tr.reg = tr.reg, reg
+        try:
+            loss, rgb = tr.step(b["rays"], b["rgbs"], valid_depth=b.get("valid_depth"), depths=depths,
+                                depth_std=b.get("depth_std"), apply_brdf=flags["apply_brdf"], apply_theta=flags["apply_theta"],
+                                cos_irra_on=flags["cos_irra_on"], depth_loss_on=flags["depth_loss_on"], near_far=self.near_far)
+        finally:
+            tr.reg = saved
+        sch.end_step()
+        self.global_step += 1
+        self.last = {"loss": loss, "psnr": psnr(rgb, b["rgbs"]), "lr": tr.lr, **flags}
+        return self.last
+
+    def run(self, n_steps=None, log_every=0):
+        n = self.schedule.max_steps - self.global_step if n_steps is None else n_steps
+        for i in range(n):
+            out = self.step()
+            if log_every and (i + 1) % log_every == 0 and self.rank == 0:
+                print(f"step {self.global_step} epoch {out['epoch']} loss {float(out['loss']):.5f} "
+                      f"psnr {float(out['psnr']):.2f} lr {out['lr']:.2e}", flush=True)
+        return self.last
+
+    # ------------------------------------------------------------------ checkpoints
+    def save(self, ckpts_dir, logs_dir=None):
+        """`<ckpts_dir>/epoch=<e>.ckpt` in the reference's layout + resume state; `opts.json` in logs_dir (opt.py)."""
+        os.makedirs(ckpts_dir, exist_ok=True)
+        tr = self.trainer
+        ckpt = {"state_dict": {f"nerf_coarse.{k}": v.detach().clone() for k, v in self.model.state_dict().items()},
+                "epoch": self.schedule.epoch, "global_step": self.global_step,
+                "fused_trainer": {"exp_avg": tr.exp_avg.clone(), "exp_avg_sq": tr.exp_avg_sq.clone(),
+                                  "steps_a": tr.steps_a, "steps_b": tr.steps_b},
+                "schedule": self.schedule.state_dict(), "ray_table": self.table.state_dict()}
+        path = os.path.join(ckpts_dir, f"epoch={self.schedule.epoch}.ckpt")
+        torch.save(ckpt, path)
+        if logs_dir is not None:
+            os.makedirs(logs_dir, exist_ok=True)
+            with open(os.path.join(logs_dir, "opts.json"), "w") as f:
+                json.dump({k: v for k, v in sorted(vars(self.args).items()) if isinstance(v, (int, float, str, bool, type(None)))},
+                          f, indent=2)
+        return path
+
+    def resume(self, path):
+        ckpt = torch.load(path, map_location=self.trainer.flat_param.device, weights_only=False)
+        load_ckpt(self.model, path, model_name="nerf_coarse")
+        tr = self.trainer
+        ft = ckpt["fused_trainer"]
+        tr.exp_avg.copy_(ft["exp_avg"]); tr.exp_avg_sq.copy_(ft["exp_avg_sq"])
+        tr.steps_a, tr.steps_b = ft["steps_a"], ft["steps_b"]
+        self.schedule.load_state_dict(ckpt["schedule"])
+        self.table.load_state_dict(ckpt["ray_table"])
+        self.global_step = int(ckpt["global_step"])
+        return ckpt

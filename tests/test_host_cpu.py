@@ -156,6 +156,59 @@ def test_regulariser_losses_match_golden():
     assert_close(n_lr.grad, g["d_normal_lr"], 1e-5, 1e-10, "d_normal_lr")
 
 
+def test_stage_schedule_follows_reference_thresholds():
+    """main.py:56-76,194-246: thresholds = round(fraction * max_train_steps), `>` switches a stage on, train_steps advance
+    by the GPU count, epoch = train_steps // (n_rays // batch_size), StepLR(0.9) per loader pass, noise_std *= 0.9 per step."""
+    import argparse
+    from brdf_nerf_amd.schedule import StageSchedule
+    a = argparse.Namespace(max_train_steps=100, brdf_on=0.2, nrrg_on=0.1, gsam_only_on=1.0, cos_irra_on=0.25, ds_drop=0.5,
+                           ds_lambda=10.0, batch_size=8, lr=5e-4, noise_std=1.0)
+    s = StageSchedule(a, n_train_rays=83, world=1)          # 10 steps per epoch
+    assert (s.brdf_on, s.nrrg_on, s.cos_irra_on, s.ds_drop, s.steps_per_epoch, s.max_steps) == (20, 10, 25, 50, 10, 100)
+    seen = {}
+    for i in range(1, 61):
+        f = s.begin_step()
+        s.end_step()
+        seen[i] = f
+    assert not seen[20]["apply_brdf"] and seen[21]["apply_brdf"]
+    assert not seen[40]["apply_theta"] and seen[41]["apply_theta"]
+    assert not seen[25]["cos_irra_on"] and seen[26]["cos_irra_on"]
+    assert seen[49]["depth_loss_on"] and not seen[50]["depth_loss_on"]
+    assert not seen[10]["nr_reg_on"] and seen[11]["nr_reg_on"]
+    assert seen[29]["epoch"] == 2 and not seen[29]["hs_on"] and seen[30]["epoch"] == 3 and seen[30]["hs_on"]
+    assert not any(f["gsam_only"] for f in seen.values())
+    assert abs(a.noise_std - 0.9 ** 60) < 1e-12
+    assert abs(s.lr(0) - 5e-4) < 1e-15 and abs(s.lr(10) - 4.5e-4) < 1e-12 and abs(s.lr(25) - 5e-4 * 0.81) < 1e-12
+    s4 = StageSchedule(argparse.Namespace(**dict(vars(a), noise_std=0.0)), 83, world=4)
+    f = [s4.begin_step() for _ in range(6)]
+    assert s4.train_steps == 24 and s4.max_steps == 25 and not f[4]["apply_brdf"] and f[5]["apply_brdf"]
+
+
+def test_ray_table_epochs_and_shards():
+    from brdf_nerf_amd.raytable import synthetic_table
+    t = synthetic_table(50, device="cpu", seed=3)
+    assert t.data["rays"].shape == (50, 11) and abs(float(t.data["rays"][:, 3:6].norm(dim=-1).mean()) - 1) < 1e-5
+    tag = torch.arange(50.0)
+    t.data["rgbs"][:, 0] = tag                                   # tag the rows to follow them through the sampler
+    got = [t.next_batch(16) for _ in range(4)]
+    assert [b["rays"].shape[0] for b in got] == [16, 16, 16, 2]  # last batch of the epoch is short (drop_last=False)
+    ids = torch.cat([b["rgbs"][:, 0] for b in got]).long()
+    assert sorted(ids.tolist()) == list(range(50))               # every row exactly once per epoch
+    b5 = t.next_batch(16)
+    assert t.epoch == 1 and b5["rays"].shape[0] == 16
+    # data parallel: same seed on every rank, contiguous shares of each global batch
+    ta, tb = synthetic_table(50, device="cpu", seed=3), synthetic_table(50, device="cpu", seed=3)
+    for tt in (ta, tb):
+        tt.data["rgbs"][:, 0] = tag
+    a0, b1 = ta.next_batch(16, 0, 2), tb.next_batch(16, 1, 2)
+    assert a0["rays"].shape[0] == 8 and b1["rays"].shape[0] == 8
+    assert torch.equal(torch.cat([a0["rgbs"][:, 0], b1["rgbs"][:, 0]]), got[0]["rgbs"][:, 0])
+    sd = ta.state_dict()
+    nxt = ta.next_batch(16)["rgbs"][:, 0].clone()
+    ta.load_state_dict(sd)
+    assert torch.equal(ta.next_batch(16)["rgbs"][:, 0], nxt)
+
+
 def test_shard_bounds_cover_rows():
     from brdf_nerf_amd.distributed import shard_bounds
     for n, w in ((4096, 8), (1000, 3), (7, 8), (0, 2)):
