@@ -46,3 +46,32 @@ def load_ckpt(model, ckpt_path, model_name="model", prefixes_to_ignore=(), drop_
     sd.update(extract_model_state_dict(ckpt_path, model_name, prefixes_to_ignore, drop_len))
     model.load_state_dict(sd)
     return model
+
+
+@torch.no_grad()
+def render_image(models, args, rays, rgbs=None, keys=("rgb", "depth"), chunk=None, apply_brdf=False, apply_theta=False,
+                 cos_irra_on=False, group=None, **kw):
+    """Full-image evaluation (eval.py:56-76, 379-507; metrics.py:292-325): the H*W rays of one image rendered in chunks,
+    keeping ONLY the requested ray-level / per-sample entries of each chunk (an image at S+G = 128 samples would
+    otherwise hold ~40 per-sample tensors), and the PSNR against `rgbs` when given.  Under data parallelism every rank
+    renders its contiguous share of the rays and the rows are all-gathered (the only exchange).
+    Returns a dict with `keys` (suffix-free) and `psnr`."""
+    from .distributed import gather_rows, shard_bounds, world_info
+    from .losses import psnr
+    rank, world = world_info(group)
+    lo, hi = shard_bounds(rays.shape[0], rank, world)
+    mine = rays[lo:hi]
+    chunk = chunk or args.chunk
+    parts = {k: [] for k in keys}
+    for i in range(0, mine.shape[0], chunk):
+        out, _ = render_rays(models, args, mine[i:i + chunk], None, mode="test", apply_brdf=apply_brdf, apply_theta=apply_theta,
+                             cos_irra_on=cos_irra_on, **kw)
+        for k in keys:
+            parts[k].append(out[f"{k}_coarse"])
+    res = {}
+    for k in keys:
+        v = torch.cat(parts[k], 0) if parts[k] else rays.new_zeros((0,))
+        res[k] = gather_rows(v, group) if world > 1 else v
+    if rgbs is not None and "rgb" in res:
+        res["psnr"] = psnr(res["rgb"], rgbs)
+    return res

@@ -825,6 +825,27 @@ def test_batched_inference_chunks_concatenate():
     assert not res["rgb_coarse"].requires_grad
 
 
+def test_render_image_keeps_requested_keys_and_psnr():
+    """evaluate.render_image: full-image chunked render returning only rgb/depth (+ on-demand entries) and the PSNR."""
+    from brdf_nerf_amd.evaluate import batched_inference, render_image
+    from brdf_nerf_amd import losses
+    cfg = mini(**CONFIGS["rpv111_nlr"])
+    model = build_model(cfg, 11)
+    args = make_args(cfg)
+    args.chunk = 24
+    rays = torch.from_numpy(load_golden("render_lambert_test")["rays"]).to(DEV)
+    tgt = torch.rand(rays.shape[0], 3, generator=torch.Generator().manual_seed(1)).to(DEV)
+    torch.manual_seed(0)
+    full = batched_inference({"coarse": model}, rays, None, args, apply_brdf=True, apply_theta=True, cos_irra_on=True)
+    torch.manual_seed(0)
+    img = render_image({"coarse": model}, args, rays, tgt, keys=("rgb", "depth", "normal_lr"), apply_brdf=True,
+                       apply_theta=True, cos_irra_on=True)
+    assert set(img) == {"rgb", "depth", "normal_lr", "psnr"}
+    assert torch.equal(img["rgb"], full["rgb_coarse"]) and torch.equal(img["depth"], full["depth_coarse"])
+    assert torch.equal(img["normal_lr"], full["normal_lr_coarse"])
+    assert_close(img["psnr"], losses.psnr(full["rgb_coarse"], tgt), 1e-6, 1e-6, "psnr")
+
+
 def test_train_loop_runs_saves_and_resumes(tmp_path):
     """TrainLoop (schedule + on-device ray table + fused step + checkpoints): the loss goes down on a small synthetic
     table, the BRDF stage switches on at its threshold, and a resumed loop continues where the saved one does."""
