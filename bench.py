@@ -132,10 +132,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal hooks for a one-GPU box (the N > 1 path end to end on the real kernels): BN_BENCH_SHARE_GPU=1 puts every
+    # rank on cuda:0, BN_BENCH_BACKEND=gloo replaces RCCL (which wants one GPU per rank).  Never set by the driver.
+    if os.environ.get("BN_BENCH_SHARE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("BN_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.distributed.init_process_group(backend)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
