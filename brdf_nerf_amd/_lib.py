@@ -66,6 +66,8 @@ _SIGS = {
                                        C.c_int32, fptr, fptr, fptr, fptr, fptr, fptr]),
     "bn_composite_backward": (C.c_int, [fptr, fptr, C.c_int64, fptr, C.c_float, fptr, C.c_int64, C.c_int32, C.c_int64,
                                         C.c_int32, fptr, fptr, fptr, fptr, C.c_int64, fptr, C.c_int64, fptr]),
+    "bn_lambert_loss": (C.c_int, [fptr, C.c_int32, fptr, fptr, C.c_int32, fptr, fptr, fptr, fptr, fptr, fptr, C.c_float, C.c_float,
+                                  C.c_float, C.c_int32, C.c_int64, fptr, fptr, fptr, fptr, fptr, fptr]),
     "bn_stratified_z": (C.c_int, [fptr, fptr, C.c_int64, fptr, C.c_int64, C.c_int32, fptr, fptr]),
     "bn_guided_samples": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                     C.c_float, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr]),

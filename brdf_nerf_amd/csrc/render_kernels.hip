@@ -226,6 +226,81 @@ extern "C" int bn_composite_backward(const float *z, const float *sigma, int64_t
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------ Lambertian loss glue
+// Ray-level tail of a Lambertian training step in one launch: shade (models/spsbrdfnerf.py:270-282: rgb =
+// clamp(sum_s w (albedo (1+2p) - p), 0, 1)), SNerfLoss (metrics.py:39-61, lambda_sc = 0) and DepthLoss
+// (metrics.py:82-161, subset rule as a mask), and their gradients w.r.t. the composited sums, the depth and the weights -
+// what ~60 small ATen launches (forward + autograd) compute otherwise.  One wavefront per ray.
+struct LossArgs {
+  const float *acc, *weights, *z, *depth, *rgbs, *valid, *tdepth, *tweight, *tstd;
+  float *ray_loss, *rgb, *d_acc, *d_depth, *d_weights;
+  int64_t R;
+  int C, S, usealldepth;
+  float pad, lambda_rgb, lambda_ds;
+};
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void lambert_loss_kernel(const LossArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (ray >= A.R) return;
+  const float d = A.depth[ray];
+  float wsum = 0.f, var = 0.f;
+  for (int s = lane; s < A.S; s += 64) {
+    const float w = A.weights[ray * A.S + s], dz = A.z[ray * A.S + s] - d;
+    wsum += w;
+    var += dz * dz * w;
+  }
+  wsum = wave_sum(wsum);
+  var = wave_sum(var);
+  const float invn = 1.f / (3.f * (float)A.R);
+  float loss = 0.f, dws = 0.f, dacc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float x = A.acc[ray * A.C + c] * (1.f + 2.f * A.pad) - A.pad * wsum;
+    const float y = fminf(fmaxf(x, 0.f), 1.f);
+    const float e = y - A.rgbs[ray * 3 + c];
+    loss += A.lambda_rgb * e * e * invn;
+    const float dy = (x >= 0.f && x <= 1.f) ? A.lambda_rgb * 2.f * e * invn : 0.f;   // clamp passes the gradient on [0, 1]
+    dacc[c] = dy * (1.f + 2.f * A.pad);
+    dws -= dy * A.pad;
+    if (lane == 0) A.rgb[ray * 3 + c] = y;
+  }
+  float dd = 0.f;
+  if (A.tdepth && A.valid[ray] > 0.f) {
+    const float td = A.tdepth[ray], tw = A.tweight[ray], ts = A.tstd[ray];
+    const bool apply = A.usealldepth || (fabsf(d - td) - ts > 0.f) || (ts < sqrtf(var));
+    if (apply) {
+      const float k = A.lambda_ds / 3.f / (float)A.R;
+      loss += k * tw * (d - td) * (d - td);
+      dd = k * 2.f * tw * (d - td);
+    }
+  }
+  if (lane == 0) {
+    A.ray_loss[ray] = loss;
+    A.d_depth[ray] = dd;
+  }
+  for (int c = lane; c < A.C; c += 64) A.d_acc[ray * A.C + c] = c < 3 ? dacc[c] : 0.f;
+  for (int s = lane; s < A.S; s += 64) A.d_weights[ray * A.S + s] = dws;
+}
+
+extern "C" int bn_lambert_loss(const float *acc, int32_t C, const float *weights, const float *z, int32_t S, const float *depth,
+                               const float *rgbs, const float *valid_depth, const float *target_depth,
+                               const float *target_weight, const float *target_std, float rgb_padding, float lambda_rgb,
+                               float lambda_ds, int32_t usealldepth, int64_t R, float *ray_loss, float *rgb, float *d_acc,
+                               float *d_depth, float *d_weights, void *stream) {
+  BN_REQUIRE(acc && weights && z && depth && rgbs && ray_loss && rgb && d_acc && d_depth && d_weights && R > 0 && S >= 1 && C >= 3,
+             "lambert_loss: bad arguments");
+  BN_REQUIRE(!target_depth || (valid_depth && target_weight && target_std), "lambert_loss: incomplete depth prior");
+  LossArgs a;
+  a.acc = acc; a.weights = weights; a.z = z; a.depth = depth; a.rgbs = rgbs; a.valid = valid_depth; a.tdepth = target_depth;
+  a.tweight = target_weight; a.tstd = target_std; a.ray_loss = ray_loss; a.rgb = rgb; a.d_acc = d_acc; a.d_depth = d_depth;
+  a.d_weights = d_weights; a.R = R; a.C = C; a.S = S; a.usealldepth = usealldepth; a.pad = rgb_padding;
+  a.lambda_rgb = lambda_rgb; a.lambda_ds = lambda_ds;
+  lambert_loss_kernel<<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
+  BN_LAUNCH_CHECK("lambert_loss");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ guided resampling
 #define BN_MAX_G 256
 #define BN_MAX_SG 512

@@ -276,6 +276,30 @@ def field_stash_bytes(spec, n_points):
     return L.lib().bn_field_stash_bytes(C.byref(spec.desc), int(n_points))
 
 
+def lambert_loss(acc, weights, z, depth, rgbs, rgb_padding, lambda_rgb, valid_depth=None, target_depth=None,
+                 target_weight=None, target_std=None, lambda_ds=0.0, usealldepth=False):
+    """Shading + SNerfLoss + DepthLoss of a Lambertian step and their gradients in one launch (bn_lambert_loss).
+    Returns (loss 0-d, rgb (R,3), d_acc (R,C), d_depth (R), d_weights (R,S))."""
+    R, S = weights.shape
+    Cc = acc.shape[1]
+    dev = acc.device
+    ray_loss = torch.empty(R, dtype=torch.float32, device=dev)
+    rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    d_acc = torch.empty(R, Cc, dtype=torch.float32, device=dev)
+    d_depth = torch.empty(R, dtype=torch.float32, device=dev)
+    d_weights = torch.empty(R, S, dtype=torch.float32, device=dev)
+    use = target_depth is not None and lambda_ds > 0
+    f = lambda t: _f32(t).contiguous() if (use and t is not None) else None
+    # every converted / compacted input stays referenced until the launch has been issued (a temporary freed earlier could
+    # be handed to the next conversion by the caching allocator)
+    acc, weights, z, depth, rgbs = _f32(acc), _f32(weights), _f32(z), _f32(depth), _f32(rgbs)
+    vd, td, tw, ts = f(valid_depth), f(target_depth), f(target_weight), f(target_std)
+    L.check(L.lib().bn_lambert_loss(_p(acc), Cc, _p(weights), _p(z), S, _p(depth), _p(rgbs), _p(vd), _p(td), _p(tw), _p(ts),
+                                    float(rgb_padding), float(lambda_rgb), float(lambda_ds), int(bool(usealldepth)), R,
+                                    _p(ray_loss), _p(rgb), _p(d_acc), _p(d_depth), _p(d_weights), _stream()), "bn_lambert_loss")
+    return ray_loss.sum(), rgb, d_acc, d_depth, d_weights
+
+
 # ----------------------------------------------------------------------------------------- sampling
 def stratified_z(near, far, u):
     """near, far: (R,1) (any stride along R), u: (R,S) -> z (R,S)."""
@@ -327,7 +351,8 @@ class RPVFunction(torch.autograd.Function):
         N = n.shape[0]
         mk = lambda on: torch.empty(N, 3, dtype=torch.float32, device=n.device) if on else None
         d_n, d_w, d_k, d_t, d_r = mk(True), mk(True), mk(hk), mk(ht), mk(hr)
-        L.check(L.lib().bn_brdf_rpv_backward(_p(l), _p(v), _p(n), _p(w), _p(k), _p(theta), _p(rhoc), _p(_f32(d_brdf)), N,
+        d_brdf = _f32(d_brdf)      # referenced until the launch is issued
+        L.check(L.lib().bn_brdf_rpv_backward(_p(l), _p(v), _p(n), _p(w), _p(k), _p(theta), _p(rhoc), _p(d_brdf), N,
                                              _p(d_n), _p(d_w), _p(d_k), _p(d_t), _p(d_r), _stream()), "bn_brdf_rpv_backward")
         return None, None, d_n, d_w, d_k, d_t, d_r
 
@@ -356,8 +381,9 @@ class HapkeFunction(torch.autograd.Function):
         mk = lambda on: torch.empty(N, 3, dtype=torch.float32, device=n.device) if on else None
         d_n, d_w, d_b, d_c = mk(True), mk(True), mk(hb), mk(hc)
         d_t = torch.empty(N, dtype=torch.float32, device=n.device) if ht else None
+        d_brdf = _f32(d_brdf)      # referenced until the launch is issued
         L.check(L.lib().bn_brdf_hapke_backward(_p(l), _p(v), _p(n), _p(w), _p(b), _p(c), _p(theta), ctx.hpk_scl, ctx.shell,
-                                               _p(_f32(d_brdf)), N, _p(d_n), _p(d_w), _p(d_b), _p(d_c), _p(d_t), _stream()),
+                                               _p(d_brdf), N, _p(d_n), _p(d_w), _p(d_b), _p(d_c), _p(d_t), _stream()),
                 "bn_brdf_hapke_backward")
         return None, None, d_n, d_w, d_b, d_c, d_t, None, None
 
@@ -384,7 +410,8 @@ class MicrofacetFunction(torch.autograd.Function):
         d_n = torch.empty(N, 3, dtype=torch.float32, device=n.device)
         d_a = torch.empty_like(d_n)
         d_r = torch.empty(N, dtype=torch.float32, device=n.device)
-        L.check(L.lib().bn_brdf_microfacet_backward(_p(l), _p(v), _p(n), _p(albedo), _p(rough), ctx.f0, _p(_f32(d_brdf)), N,
+        d_brdf = _f32(d_brdf)      # referenced until the launch is issued
+        L.check(L.lib().bn_brdf_microfacet_backward(_p(l), _p(v), _p(n), _p(albedo), _p(rough), ctx.f0, _p(d_brdf), N,
                                                     _p(d_n), _p(d_a), _p(d_r), _stream()), "bn_brdf_microfacet_backward")
         return None, None, d_n, d_a, d_r.reshape(ctx.rough_shape), None
 

@@ -23,6 +23,7 @@ class FusedTrainer:
         is the caller's schedule: pass regularisers=False to step() until then."""
         self.model, self.args = model, args
         self.reg = dict(nr_an=nr_reg_an_lambda, nr_lr=nr_reg_lr_lambda, hs=hs_lambda, nr_spv=nr_spv_lambda)
+        self.fused_glue = True      # Lambertian steps: one launch for shading + losses + their gradients
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.lambda_rgb, self.ds_lambda, self.usealldepth = lambda_rgb, ds_lambda, usealldepth
         self.pg, self.strict_rng, self.reuse_coarse = process_group, strict_rng, reuse_coarse
@@ -129,33 +130,45 @@ class FusedTrainer:
                 Fn.field_forward_raw(spec, named, packed, out, stash, rays=rays, z=z_all)
                 out3 = out.view(R, S2, C)
             alphas, trans, weights, depth, acc = Fn.composite_forward_raw(z_all, out3, noise2, args.noise_std)
-        # ray-level loss glue under autograd (leaves: acc, depth, weights; the per-sample normals too when a regulariser
-        # reads them)
-        acc_l, depth_l, weights_l = acc.requires_grad_(True), depth.requires_grad_(True), weights.requires_grad_(True)
-        res, _ = shade(model, args, spec, out3, z_all, alphas, trans, weights_l, depth_l, acc_l, rays_d, sun_d, apply_brdf,
-                       cos_irra_on)
-        loss = losses.snerf_loss(res["rgb"], rgbs, self.lambda_rgb)
-        if self.ds_lambda > 0 and depth_loss_on and valid_depth is not None:
-            loss = loss + losses.depth_loss(z_all, depth_l, weights_l, depths[:, 0], depths[:, 1], valid_depth, depth_std,
-                                            self.ds_lambda, self.usealldepth)
         reg = self.reg if regularisers else {}
+        lambertian = (len(spec.heads) == 1 and not spec.normal_an and not spec.normal_lr and reg.get("hs", 0) <= 0)
         n_leaf = {}                                   # channel offset -> per-sample normal leaf
-        def normal_leaf(key):
-            c0 = spec.ch_normal_an if key == "normal_an" else spec.ch_normal_lr
-            if c0 not in n_leaf:
-                n_leaf[c0] = out3[..., c0:c0 + 3].detach().clone().requires_grad_(True)
-            return n_leaf[c0]
-        if reg.get("nr_an", 0) > 0 and spec.normal_an:
-            loss = loss + losses.normal_reg_loss(normal_leaf("normal_an"), weights_l, -rays_d, reg["nr_an"])[0]
-        if reg.get("nr_lr", 0) > 0 and spec.normal_lr:
-            loss = loss + losses.normal_reg_loss(normal_leaf("normal_lr"), weights_l, -rays_d, reg["nr_lr"])[0]
-        if reg.get("hs", 0) > 0:
-            loss = loss + losses.hard_surface_loss(z_all, depth_l, weights_l, reg["hs"])
-        if abs(reg.get("nr_spv", 0)) > 1e-5 and spec.normal_an and spec.normal_lr:   # nr_spv_type 1 (main.py:297-303)
-            loss = loss + losses.normal_loss(weights_l, normal_leaf("normal_an"), normal_leaf("normal_lr"), reg["nr_spv"])
-        leaves = [acc_l, depth_l, weights_l] + list(n_leaf.values())
-        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
-        d_acc, d_depth, d_weights = grads[:3]
+        grads = ()
+        if lambertian and self.fused_glue:
+            # Lambertian step: shading + SNerfLoss + DepthLoss + their gradients in ONE launch (bn_lambert_loss)
+            use_ds = self.ds_lambda > 0 and depth_loss_on and valid_depth is not None
+            with torch.no_grad():
+                loss, rgb_out, d_acc, d_depth, d_weights = Fn.lambert_loss(
+                    acc, weights, z_all, depth, rgbs, model.rgb_padding, self.lambda_rgb,
+                    valid_depth if use_ds else None, depths[:, 0] if use_ds else None, depths[:, 1] if use_ds else None,
+                    depth_std if use_ds else None, self.ds_lambda if use_ds else 0.0, self.usealldepth)
+            res = {"rgb": rgb_out}
+        else:
+            # ray-level loss glue under autograd (leaves: acc, depth, weights; the per-sample normals too when a regulariser
+            # reads them)
+            acc_l, depth_l, weights_l = acc.requires_grad_(True), depth.requires_grad_(True), weights.requires_grad_(True)
+            res, _ = shade(model, args, spec, out3, z_all, alphas, trans, weights_l, depth_l, acc_l, rays_d, sun_d, apply_brdf,
+                           cos_irra_on)
+            loss = losses.snerf_loss(res["rgb"], rgbs, self.lambda_rgb)
+            if self.ds_lambda > 0 and depth_loss_on and valid_depth is not None:
+                loss = loss + losses.depth_loss(z_all, depth_l, weights_l, depths[:, 0], depths[:, 1], valid_depth, depth_std,
+                                                self.ds_lambda, self.usealldepth)
+            def normal_leaf(key):
+                c0 = spec.ch_normal_an if key == "normal_an" else spec.ch_normal_lr
+                if c0 not in n_leaf:
+                    n_leaf[c0] = out3[..., c0:c0 + 3].detach().clone().requires_grad_(True)
+                return n_leaf[c0]
+            if reg.get("nr_an", 0) > 0 and spec.normal_an:
+                loss = loss + losses.normal_reg_loss(normal_leaf("normal_an"), weights_l, -rays_d, reg["nr_an"])[0]
+            if reg.get("nr_lr", 0) > 0 and spec.normal_lr:
+                loss = loss + losses.normal_reg_loss(normal_leaf("normal_lr"), weights_l, -rays_d, reg["nr_lr"])[0]
+            if reg.get("hs", 0) > 0:
+                loss = loss + losses.hard_surface_loss(z_all, depth_l, weights_l, reg["hs"])
+            if abs(reg.get("nr_spv", 0)) > 1e-5 and spec.normal_an and spec.normal_lr:   # nr_spv_type 1 (main.py:297-303)
+                loss = loss + losses.normal_loss(weights_l, normal_leaf("normal_an"), normal_leaf("normal_lr"), reg["nr_spv"])
+            leaves = [acc_l, depth_l, weights_l] + list(n_leaf.values())
+            grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+            d_acc, d_depth, d_weights = grads[:3]
         with torch.no_grad():
             if d_acc is not None:
                 d_acc = d_acc.contiguous()

@@ -149,6 +149,18 @@ int bn_composite_backward(const float *z, const float *sigma, int64_t sigma_stri
                           int64_t d_sigma_stride, float *d_chan, int64_t d_chan_stride, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Ray-level tail of a Lambertian training step in one launch: shading of the composited sums
+ * (models/spsbrdfnerf.py:270-282, rgb = clamp(sum_s w (albedo (1+2p) - p), 0, 1)), SNerfLoss
+ * (metrics.py:39-61, lambda_sc = 0) and DepthLoss (metrics.py:82-161, subset=True, GNLL=False; the
+ * np.where row selection as a mask), with the gradients autograd would return for acc [R][C], depth [R] and
+ * weights [R][S].  target_depth == NULL: no depth term.  ray_loss [R] sums to the step's loss.
+ * ------------------------------------------------------------------------------------------- */
+int bn_lambert_loss(const float *acc, int32_t C, const float *weights, const float *z, int32_t S, const float *depth,
+                    const float *rgbs, const float *valid_depth, const float *target_depth, const float *target_weight,
+                    const float *target_std, float rgb_padding, float lambda_rgb, float lambda_ds, int32_t usealldepth,
+                    int64_t R, float *ray_loss, float *rgb, float *d_acc, float *d_depth, float *d_weights, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Stratified depths (get_z_vals, rendering.py:149-166, perturb=1): z[R][S] from near/far taken
  * from rays[:,6], rays[:,7] (or explicit near/far arrays) and uniforms u[R][S].
  * ------------------------------------------------------------------------------------------- */

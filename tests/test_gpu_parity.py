@@ -825,6 +825,37 @@ def test_batched_inference_chunks_concatenate():
     assert not res["rgb_coarse"].requires_grad
 
 
+@pytest.mark.parametrize("with_depth", [False, True])
+def test_lambert_loss_kernel_matches_autograd(with_depth):
+    """bn_lambert_loss (shading + SNerfLoss + DepthLoss + gradients in one launch) against the torch glue it replaces;
+    inputs straddle both clamp edges and both branches of the depth-subset rule."""
+    from brdf_nerf_amd import functions as Fn, losses
+    g = torch.Generator().manual_seed(21)
+    R, S, C, pad = 300, 96, 4, 0.001
+    z = torch.sort(torch.rand(R, S, generator=g) * 2, -1)[0].to(DEV)
+    w = torch.softmax(torch.randn(R, S, generator=g) * 2, -1).to(DEV)
+    acc = (torch.rand(R, C, generator=g) * 1.4 - 0.2).to(DEV)          # some composited albedos outside [0, 1]
+    depth = (w * z).sum(-1)
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    valid = (torch.rand(R, generator=g) < 0.7).float().to(DEV)
+    tdep = (0.8 + 0.4 * torch.rand(R, generator=g)).to(DEV)
+    tw = torch.rand(R, generator=g).to(DEV)
+    tstd = (0.3 * torch.rand(R, generator=g)).to(DEV)
+    a_l, d_l, w_l = acc.clone().requires_grad_(True), depth.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    rgb = (a_l[:, :3] * (1 + 2 * pad) - pad * w_l.sum(-1, keepdim=True)).clamp(0.0, 1.0)
+    loss = losses.snerf_loss(rgb, rgbs, 1.0)
+    if with_depth:
+        loss = loss + losses.depth_loss(z, d_l, w_l, tdep, tw, valid, tstd, 10.0)
+    ga, gd, gw = torch.autograd.grad(loss, [a_l, d_l, w_l], allow_unused=True)
+    kw = dict(valid_depth=valid, target_depth=tdep, target_weight=tw, target_std=tstd, lambda_ds=10.0) if with_depth else {}
+    l2, rgb2, da, dd, dw = Fn.lambert_loss(acc, w, z, depth, rgbs, pad, 1.0, **kw)
+    assert_close(l2, loss.detach(), 1e-5, 1e-8, "loss")
+    assert_close(rgb2, rgb.detach(), 1e-6, 1e-7, "rgb")
+    assert_close(da, ga, 1e-5, 1e-10, "d_acc")
+    assert_close(dw, gw, 1e-5, 1e-10, "d_weights")
+    assert_close(dd, gd if gd is not None else torch.zeros_like(dd), 1e-5, 1e-10, "d_depth")
+
+
 def test_render_image_keeps_requested_keys_and_psnr():
     """evaluate.render_image: full-image chunked render returning only rgb/depth (+ on-demand entries) and the PSNR."""
     from brdf_nerf_amd.evaluate import batched_inference, render_image
