@@ -51,8 +51,8 @@ class SpSBRDFNeRF(nn.Module):
         super().__init__()
         if beta:
             raise NotImplementedError(_UNSUPPORTED + "--beta (transient embedding; reference README recommends it off)")
-        if sun_v != "none":
-            raise NotImplementedError(_UNSUPPORTED + f"--sun_v {sun_v} (reference quirks 2 and 3: crashes upstream)")
+        if sun_v not in ("none", "analystic"):      # 'analystic' adds no parameters: the sun pass lives in render_rays
+            raise NotImplementedError(_UNSUPPORTED + f"--sun_v {sun_v} (reference quirk 3: NameError upstream)")
         if indirect_light:
             raise NotImplementedError(_UNSUPPORTED + "--indirect_light (needs sun_v)")
         if getattr(args, "input_viewdir", 0):

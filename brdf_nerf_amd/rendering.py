@@ -74,17 +74,22 @@ def inference(model, args, rays_xyz, z_vals, rays_d=None, sun_d=None, rays_t=Non
         raise NotImplementedError("single-sample pass 2 is undefined in the reference (SURVEY quirk 4)")
     alphas, transparency, weights, depth, acc = Fn.composite(z_vals, out, noise_arg, args.noise_std)
     return shade(model, args, spec, out, z_vals, alphas, transparency, weights, depth, acc, rays_d, sun_d, apply_brdf,
-                 cos_irra_on, sort_idx, z_vals_unsort)
+                 cos_irra_on, sort_idx, z_vals_unsort, sun_res)
 
 
 def shade(model, args, spec, out, z_vals, alphas, transparency, weights, depth, acc, rays_d, sun_d, apply_brdf,
-          cos_irra_on, sort_idx=None, z_vals_unsort=None):
+          cos_irra_on, sort_idx=None, z_vals_unsort=None, sun_res=None):
     """Ray-level part of inference() (models/spsbrdfnerf.py:198-416) from the composited sums `acc` = sum_s w * out."""
     R, S = z_vals.shape
     nr_lr = spec.normal_lr
     albedo, sigmas = out[..., :3], out[..., 3]
     result = {"sigmas": sigmas.unsqueeze(-1), "albedo": albedo, "albedo_accu": acc[:, :3].clamp(0.0, 1.0), "depth": depth,
               "alphas": alphas, "weights": weights, "transparency": transparency, "z_vals": z_vals}
+    sun_v = None                                 # per-sample sun visibility (R,S,1) of the sun pass (:148-151, :211-219)
+    if sun_res and "sun" in sun_res:
+        result["sun"], result["weights_sc"] = sun_res["sun"], sun_res["weights_sc"]
+        if model.sun_v == "analystic":
+            sun_v = sun_res["sun"]
     if sort_idx is not None:
         result["sort_idx"] = sort_idx
     if z_vals_unsort is not None:
@@ -108,18 +113,25 @@ def shade(model, args, spec, out, z_vals, alphas, transparency, weights, depth, 
     irr_ray = None
     if cos_irra_on and normal is not None:
         irr_ray = sun_d[:, 2:3].abs()                            # upward normal (0,0,1): irradiance = |sun_z| (:260-264)
+        sun_v = None                                             # the cosine branch wins (:260-266)
     rgb = albedo_s if irr_ray is None else albedo_s * irr_ray
+    if sun_v is not None:                                        # per-sample irradiance: no composited shortcut (:265-273)
+        rgb = (weights.unsqueeze(-1) * (albedo * (1 + 2 * pad) - pad) * sun_v).sum(-2)
     result["rgb"] = rgb.clamp(0.0, 1.0)
     heads = {}
     for (name, n_out, kind), (c0, wdt) in zip(spec.heads[1:], spec.head_cols[1:]):
         heads[name] = out[..., c0:c0 + wdt]
     if normal is None and not heads:
         return result, "Lambertian"
+    if sun_v is not None:
+        irr_ray = sun_v[:, -1, :]                                # per-ray BRDF: irradiance of the LAST sample (:354)
 
     brdf_type = "Lambertian"
     extra = {}
     view = -rays_d
     irr = torch.ones_like(albedo) if irr_ray is None else irr_ray[:, None, :].expand(R, S, 3)
+    if sun_v is not None:
+        irr = sun_v.expand(R, S, 3)
     shell = getattr(args, "shell_hapke", 0)
     kind = None
     if model.roughness and apply_brdf:
@@ -183,8 +195,8 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
         raise ValueError("brdf_nerf_amd.render_rays serves --model spsbrdf-nerf only")
     if args.n_importance > 0:
         raise NotImplementedError("fine pass (n_importance > 0) is an optional extension (SURVEY.md section 8f rank 4)")
-    if bTestSun_v or rows is not None or cols is not None:
-        raise NotImplementedError("bTestSun_v / ref_sphere visualisation are out of the hot-path scope")
+    if rows is not None or cols is not None:
+        raise NotImplementedError("ref_sphere visualisation is out of the hot-path scope")
     model = models["coarse"]
     G, S = args.guided_samples, args.n_samples
     if G <= 0:
@@ -218,6 +230,21 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
         out1 = model.evaluate(spec, packed, rays=rays, z=z_vals).view(R, S, C)
         with torch.no_grad():
             _, _, w1, d1, _ = Fn.composite_forward_raw(z_vals, out1.detach(), noise1 if noise_on else None, args.noise_std)
+    sun_res = {}
+    if (model.sun_v == "analystic" and apply_brdf) or bTestSun_v:
+        # Sun-visibility pass (rendering.py:244-259): transparency along the sun direction from the pass-1 surface
+        # point, sigma only, detached.  far_sun is scaled with ROW 0's directions, as upstream (:247-248).
+        if not gsam_only:
+            raise NotImplementedError("--sun_v analystic needs gsam_only=True: with the merged S+G sample set the reference "
+                                      "raises a shape error in pass 2 (SURVEY quirk 2)")
+        with torch.no_grad():
+            far_sun = d1.clone().unsqueeze(-1)
+            if abs(float(sun_d[0, 2])) > 0.00001:
+                far_sun = abs(float(rays_d[0, 2]) / float(sun_d[0, 2])) * far_sun
+            z_sun = get_z_vals(G, rays.device, far_sun * 0.01, far_sun)
+            sun_rays = torch.cat([rays[:, 0:3] + rays_d * d1.unsqueeze(-1), sun_d], -1).contiguous()
+            rs, _ = inference(model, args, None, z_sun, rays_d=sun_d, mode=mode, sigma_only=True, _rays=sun_rays, _packed=packed)
+        sun_res = {"sun": rs["transparency"].unsqueeze(-1).detach(), "weights_sc": rs["weights"].detach()}
     # guided samples around the pass-1 depth (or the ground-truth depth prior in training)
     u = torch.rand(R, G, device=rays.device)
     use_t = tdep = tstd = u_t = trow = None
@@ -235,7 +262,7 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
                                            tstd, u_t, trow, merge=not gsam_only)
     if gsam_only:
         result, brdf_type = inference(model, args, None, z2, rays_d=rays_d, sun_d=sun_d, z_vals_unsort=z2, apply_brdf=apply_brdf,
-                                      bTestNormal=bTestNormal, sun_res={}, sort_idx=None, mode=mode, apply_theta=apply_theta,
+                                      bTestNormal=bTestNormal, sun_res=sun_res, sort_idx=None, mode=mode, apply_theta=apply_theta,
                                       cos_irra_on=cos_irra_on, _rays=rays, _packed=packed)
         return {f"{k}_coarse": v for k, v in result.items()}, brdf_type
     z_unsort = torch.cat([z_vals, z2], -1)

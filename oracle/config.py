@@ -38,6 +38,7 @@ class FieldConfig:
     std_range: float = 3.0
     noise_std: float = 0.0
     data: str = "sat"
+    sun_v: str = "none"                # none | analystic (sun-visibility pass, rendering.py:244-259; no parameters)
 
     @property
     def RPV(self):

@@ -127,8 +127,8 @@ def guided_samples(depth, weights, z, n_guided, near0, far0, rnd, d_range=3.0, m
 
 
 def inference(params, cfg, xyz, z, rays_d, sun_d, rnd, sigma_only=False, apply_brdf=False,
-              apply_theta=False, cos_irra_on=False, sort_idx=None, z_unsort=None, bTestNormal=False):
-    """inference (spsbrdfnerf.py:71-416) for sun_v='none', beta=False.  Returns (dict, brdf_type)."""
+              apply_theta=False, cos_irra_on=False, sort_idx=None, z_unsort=None, bTestNormal=False, sun_res=None):
+    """inference (spsbrdfnerf.py:71-416) for sun_v in ('none', 'analystic'), beta=False.  Returns (dict, brdf_type)."""
     R, S = z.shape
     pts = xyz.reshape(-1, 3)
     nr_an = cfg.normal in ("analystic", "analystic_learned") or bTestNormal
@@ -163,6 +163,11 @@ def inference(params, cfg, xyz, z, rays_d, sun_d, rnd, sigma_only=False, apply_b
     result = {"sigmas": sig.unsqueeze(-1), "albedo": albedo,
               "albedo_accu": (wx * albedo).sum(-2).clamp(0.0, 1.0), "depth": depth, "alphas": a,
               "weights": w, "transparency": T, "z_vals": z}
+    sun_v = None
+    if sun_res and "sun" in sun_res:            # :148-151, :211-219 (both branches store the same two entries)
+        result["sun"], result["weights_sc"] = sun_res["sun"], sun_res["weights_sc"]
+        if cfg.sun_v == "analystic":
+            sun_v = sun_res["sun"]
     if sort_idx is not None:
         result["sort_idx"] = sort_idx
     if z_unsort is not None:
@@ -177,6 +182,8 @@ def inference(params, cfg, xyz, z, rays_d, sun_d, rnd, sigma_only=False, apply_b
     irr = torch.ones_like(albedo)
     if cos_irra_on and normal is not None:
         irr = irr * sun_d[:, None, 2:3].abs()                   # upward normal (0,0,1): :260-264
+    elif sun_v is not None:
+        irr = sun_v.expand(-1, -1, 3)                           # per-sample sun visibility (:265-266)
     pad = cfg.rgb_padding
     albedo_p = albedo * (1 + 2 * pad) - pad
     result["rgb"] = (wx * albedo_p * irr).sum(-2).clamp(0.0, 1.0)
@@ -261,8 +268,9 @@ def inference(params, cfg, xyz, z, rays_d, sun_d, rnd, sigma_only=False, apply_b
 
 
 def render_rays(params, cfg, rays, rnd, mode="test", valid_depth=None, target_depths=None, target_std=None,
-                apply_brdf=False, apply_theta=False, cos_irra_on=False, gsam_only=False, bTestNormal=False):
-    """render_rays, spsbrdf-nerf branch (rendering.py:168-291), guided_samples>0, sun_v='none'."""
+                apply_brdf=False, apply_theta=False, cos_irra_on=False, gsam_only=False, bTestNormal=False,
+                bTestSun_v=False):
+    """render_rays, spsbrdf-nerf branch (rendering.py:168-291), guided_samples>0, sun_v in ('none', 'analystic')."""
     o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
     S, G = cfg.n_samples, cfg.guided_samples
     assert G > 0, "guided_samples<=0 returns an un-suffixed dict in the reference (SURVEY quirk 1)"
@@ -274,6 +282,21 @@ def render_rays(params, cfg, rays, rnd, mode="test", valid_depth=None, target_de
     d_range, g_r = cfg.std_range, G
     if G == 2:
         d_range, g_r = 0.0001, 1
+    sun_res = {}
+    if (cfg.sun_v == "analystic" and apply_brdf) or bTestSun_v:
+        # sun-visibility pass (rendering.py:244-259): transparency along the sun direction from the pass-1 surface point.
+        # The reference's pass 2 only accepts it with gsam_only; far_sun uses ROW 0's directions.
+        assert gsam_only, "sun_v analystic with gsam_only=False raises in the reference (SURVEY quirk 2)"
+        pt_surf = o + d * res1["depth"].unsqueeze(-1)
+        far_sun = res1["depth"].clone().unsqueeze(-1)
+        if abs(float(sun_d[0, 2])) > 0.00001:
+            far_sun = torch.abs(d[0, 2] / sun_d[0, 2]) * far_sun
+        n1 = g_r
+        z_sun = get_z_vals(n1, far_sun * 0.01, far_sun, rnd.rand((rays.shape[0], n1), rays.dtype))
+        xyz_sun = pt_surf.unsqueeze(1) + sun_d.unsqueeze(1) * z_sun.unsqueeze(2)
+        with torch.no_grad():
+            rs, _ = inference(params, cfg, xyz_sun, z_sun, sun_d, None, rnd, sigma_only=True)
+        sun_res = {"sun": rs["transparency"].unsqueeze(-1).detach(), "weights_sc": rs["weights"].detach()}
     z2, inds, inds_gt = guided_samples(res1["depth"], res1["weights"], z, G, near[0, 0], far[0, 0], rnd, d_range,
                                        mode, valid_depth, target_depths, target_std)
     z2 = torch.sort(z2.detach(), -1)[0]
@@ -287,7 +310,7 @@ def render_rays(params, cfg, rays, rnd, mode="test", valid_depth=None, target_de
     xyz = o.unsqueeze(1) + d.unsqueeze(1) * z_all.unsqueeze(2)
     res, brdf_type = inference(params, cfg, xyz, z_all, d, sun_d, rnd, apply_brdf=apply_brdf,
                                apply_theta=apply_theta, cos_irra_on=cos_irra_on, sort_idx=idx,
-                               z_unsort=z_unsort, bTestNormal=bTestNormal)
+                               z_unsort=z_unsort, bTestNormal=bTestNormal, sun_res=sun_res)
     out = {f"{k}_coarse": v for k, v in res.items()}
     out["_pass1"] = res1
     out["_guided_inds"] = inds

@@ -48,7 +48,7 @@ def ref_args(cfg: FieldConfig):
     return argparse.Namespace(
         model="spsbrdf-nerf", fc_layers=cfg.layers, fc_feat=cfg.feat, mapping=cfg.mapping, siren=int(cfg.siren),
         t_embbeding_tau=4, beta=False, roughness=cfg.roughness, normal=cfg.normal, indirect_light=False,
-        glossy_scale=1.0, sun_v="none", MultiBRDF=int(cfg.MultiBRDF), dim_RPV=cfg.dim_RPV, input_viewdir=0,
+        glossy_scale=1.0, sun_v=cfg.sun_v, MultiBRDF=int(cfg.MultiBRDF), dim_RPV=cfg.dim_RPV, input_viewdir=0,
         funcM=cfg.funcM, funcF=cfg.funcF, funcH=cfg.funcH, b=cfg.b, c=cfg.c, theta=cfg.theta, B0=0, h=0,
         shell_hapke=cfg.shell_hapke, hpk_scl=cfg.hpk_scl, guided_samples=cfg.guided_samples,
         n_samples=cfg.n_samples, n_importance=0, std_range=cfg.std_range, data=cfg.data, sc_lambda=0.0,
@@ -326,6 +326,7 @@ def gen_render(ref):
         arrays = {f"out/{k}": v for k, v in res.items()}
         arrays.update({f"rand{i}": t for i, t in enumerate(rlog)})
         save(f"render_{tag}_test", rays=rays, brdf_type=np.array(brdf_type), param_checksum=csum, param_seed=11, **arrays)
+    gen_render_sunv(ref, rays, targets)
     # full-size network, forward only
     cfg = FieldConfig(**CONFIGS["rpv111_nan"])
     model, csum = build_ref_model(ref, cfg, seed=12)
@@ -351,6 +352,33 @@ def gen_render(ref):
     arrays.update({f"rand{i}": t for i, t in enumerate(rlog)})
     save("render_lambert_blender", rays=raysb, brdf_type=np.array(brdf_type), param_checksum=csum, param_seed=11,
          **arrays)
+
+
+def gen_render_sunv(ref, rays=None, targets=None):
+    """Sun-visibility pass (--sun_v analystic, rendering.py:244-259) with gsam_only=True - the only combination the
+    reference's pass 2 accepts - and cos_irra_on=False so the visibility IS the irradiance."""
+    R = 64
+    if rays is None:
+        rays = sat_rays(R, 1)
+        g = torch.Generator().manual_seed(4)
+        targets = dict(rgbs=torch.rand(R, 3, generator=g), valid_depth=(torch.rand(R, generator=g) < 0.7).float(),
+                       depths=torch.stack([0.8 + 0.4 * torch.rand(R, generator=g), torch.rand(R, generator=g)], -1),
+                       depth_std=0.02 + 0.05 * torch.rand(R, generator=g))
+    for base in ("rpv111_nlr", "lambert"):
+        cfg = mini(**dict(CONFIGS[base], sun_v="analystic"))
+        for mode in ("train", "test"):
+            model, csum = build_ref_model(ref, cfg, seed=11)
+            res, brdf_type, rlog = run_render(ref, cfg, model, rays, mode,
+                                              dict(apply_brdf=True, apply_theta=True, cos_irra_on=False, gsam_only=True), targets)
+            arrays = {f"out/{k}": v for k, v in res.items()}
+            arrays.update({f"rand{i}": t for i, t in enumerate(rlog)})
+            if mode == "train":
+                loss = ((res["rgb_coarse"] - targets["rgbs"]) ** 2).mean()
+                loss.backward()
+                for k, p_ in model.named_parameters():
+                    arrays[f"grad/{k}"] = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+            save(f"render_{base}_sunv_{mode}", rays=rays, brdf_type=np.array(brdf_type), param_checksum=csum, param_seed=11,
+                 **{f"tgt/{k}": v for k, v in targets.items()}, **arrays)
 
 
 def gen_loss(ref):
@@ -410,6 +438,9 @@ def gen_regularisers(ref):
 if __name__ == "__main__":
     torch.set_num_threads(4)
     ref = import_reference()
+    if "--only-sunv" in sys.argv:
+        gen_render_sunv(ref)
+        sys.exit(0)
     if "--only-regularisers" in sys.argv:
         gen_regularisers(ref)
         sys.exit(0)

@@ -33,7 +33,7 @@ def make_args(cfg, compute_dtype="fp32"):
     return argparse.Namespace(
         model="spsbrdf-nerf", fc_layers=cfg.layers, fc_feat=cfg.feat, mapping=cfg.mapping, siren=int(cfg.siren),
         t_embbeding_tau=4, beta=False, roughness=cfg.roughness, normal=cfg.normal, indirect_light=False, glossy_scale=1.0,
-        sun_v="none", MultiBRDF=int(cfg.MultiBRDF), dim_RPV=cfg.dim_RPV, input_viewdir=0, funcM=cfg.funcM, funcF=cfg.funcF,
+        sun_v=getattr(cfg, "sun_v", "none"), MultiBRDF=int(cfg.MultiBRDF), dim_RPV=cfg.dim_RPV, input_viewdir=0, funcM=cfg.funcM, funcF=cfg.funcF,
         funcH=cfg.funcH, b=cfg.b, c=cfg.c, theta=cfg.theta, shell_hapke=cfg.shell_hapke, hpk_scl=cfg.hpk_scl,
         guided_samples=cfg.guided_samples, n_samples=cfg.n_samples, n_importance=0, std_range=cfg.std_range, data=cfg.data,
         sc_lambda=0.0, chunk=5120, noise_std=cfg.noise_std, margin=0.0001, stdscale=1, fresnel_f0=cfg.fresnel_f0,
@@ -804,6 +804,41 @@ def test_render_variants_multibrdf_gsamonly_golden(tag, extra, gs):
     assert brdf_type == str(g["brdf_type"])
     # per-sample shading / 16 tightly clustered samples: the normal's 1e-3 per-sample differences reach the pixel directly
     compare_render(res, g, f"render_{tag}_test", ray_tol=(5e-4, 2e-4), other_tol=(2e-3, 1e-3))
+
+
+@pytest.mark.parametrize("mode", ["train", "test"])
+@pytest.mark.parametrize("base", ["rpv111_nlr", "lambert"])
+def test_render_sun_visibility_pass_golden(base, mode):
+    """--sun_v analystic (rendering.py:244-259): transparency along the sun direction from the
+    pass-1 surface point as per-sample irradiance, gsam_only=True (the combination the reference accepts), against
+    reference goldens incl. the training gradient."""
+    from brdf_nerf_amd import render_rays
+    g = load_golden(f"render_{base}_sunv_{mode}")
+    cfg = mini(**dict(CONFIGS[base], sun_v="analystic"))
+    model = build_model(cfg, 11)
+    args = make_args(cfg)
+    kw = {}
+    if mode == "train":
+        kw = dict(valid_depth=torch.from_numpy(g["tgt/valid_depth"]).to(DEV), target_depths=torch.from_numpy(g["tgt/depths"]).to(DEV),
+                  target_std=torch.from_numpy(g["tgt/depth_std"]).to(DEV))
+    with Replay(replay_list(g)) as rp:
+        res, brdf_type = render_rays({"coarse": model}, args, torch.from_numpy(g["rays"]).to(DEV), None, mode=mode,
+                                     apply_brdf=True, apply_theta=True, cos_irra_on=False, gsam_only=True, **kw)
+        assert rp.draws == []
+    assert brdf_type == str(g["brdf_type"])
+    assert {k[4:] for k in g if k.startswith("out/")} == set(res)
+    g = dict(g)
+    if "out/hpk_scl_coarse" in g:   # 1 / (4 (n.v + n.sun)) is unbounded where the sum passes through 0: compare its inverse
+        assert_close(1.0 / res["hpk_scl_coarse"], 1.0 / g.pop("out/hpk_scl_coarse"), 2e-3, 2e-3, "1/hpk_scl")
+    compare_render(res, g, f"render_{base}_sunv_{mode}", ray_tol=(5e-4, 2e-4), other_tol=(2e-3, 1e-3))
+    if mode == "train":
+        loss = torch.mean((res["rgb_coarse"] - torch.from_numpy(g["tgt/rgbs"]).to(DEV)) ** 2)
+        loss.backward()
+        for k, v in model.named_parameters():
+            ref = g[f"grad/{k}"]
+            got = v.grad.cpu() if v.grad is not None else torch.zeros_like(v).cpu()
+            scale = max(float(np.abs(ref).max()), 1e-12)
+            assert float((got - torch.from_numpy(ref)).abs().max()) <= 5e-3 * scale + 1e-9, k
 
 
 def test_batched_inference_chunks_concatenate():

@@ -96,11 +96,12 @@ def test_init_ranges_follow_reference():
 
 def test_unsupported_flags_raise():
     from brdf_nerf_amd import load_model
-    for over in (dict(beta=True), dict(sun_v="analystic"), dict(input_viewdir=1), dict(indirect_light=True)):
+    for over in (dict(beta=True), dict(sun_v="learned"), dict(input_viewdir=1), dict(indirect_light=True)):
         with pytest.raises(NotImplementedError):
             load_model(make_args(FieldConfig(feat=64), **over))
     with pytest.raises(ValueError):
         load_model(make_args(FieldConfig(feat=64), model="sat-nerf"))
+    assert load_model(make_args(FieldConfig(feat=64), sun_v="analystic")).sun_v == "analystic"   # no parameters: sun pass in render_rays
 
 
 def test_packed_and_stash_sizes():

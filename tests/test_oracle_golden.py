@@ -238,6 +238,38 @@ def test_render_variants_multibrdf_gsamonly(tag, extra, gs):
             assert_close(res[k], g["out/" + k], 2e-4, 2e-5, k)
 
 
+@pytest.mark.parametrize("mode", ["train", "test"])
+@pytest.mark.parametrize("base", ["rpv111_nlr", "lambert"])
+def test_render_sun_visibility_pass(base, mode):
+    """--sun_v analystic (rendering.py:244-259) with gsam_only=True, the combination the reference's pass 2 accepts."""
+    g = load_golden(f"render_{base}_sunv_{mode}")
+    cfg = mini(**dict(CONFIGS[base], sun_v="analystic"))
+    p = tparams(cfg, 11)
+    for v in p.values():
+        v.requires_grad_(True)
+    rnd = RD.Randoms(replay=replay_list(g))
+    kw = {}
+    if mode == "train":
+        kw = dict(valid_depth=torch.from_numpy(g["tgt/valid_depth"]), target_depths=torch.from_numpy(g["tgt/depths"]),
+                  target_std=torch.from_numpy(g["tgt/depth_std"]))
+    res, bt = RD.render_rays(p, cfg, torch.from_numpy(g["rays"]), rnd, mode=mode, apply_brdf=True, apply_theta=True,
+                             cos_irra_on=False, gsam_only=True, **kw)
+    assert rnd.replay == [], "oracle consumed a different number of random draws than the reference"
+    assert bt == str(g["brdf_type"])
+    ref_keys = {k[4:] for k in g if k.startswith("out/")}
+    assert ref_keys == {k for k in res if not k.startswith("_")}, sorted(ref_keys ^ {k for k in res if not k.startswith("_")})
+    for k in sorted(ref_keys):
+        assert_close(res[k], g["out/" + k], 2e-4, 2e-5, k)
+    if mode == "train":
+        loss = torch.mean((res["rgb_coarse"] - torch.from_numpy(g["tgt/rgbs"])) ** 2)
+        loss.backward()
+        for k, v in p.items():
+            ref = g[f"grad/{k}"]
+            got = v.grad if v.grad is not None else torch.zeros_like(v)
+            scale = max(float(np.abs(ref).max()), 1e-12)
+            assert float((got - torch.from_numpy(ref)).abs().max()) <= 2e-3 * scale + 1e-9, k
+
+
 def test_regulariser_losses():
     g = load_golden("loss_regularisers")
     t = {k: torch.from_numpy(v) for k, v in g.items()}
