@@ -946,3 +946,72 @@ def test_train_loop_runs_saves_and_resumes(tmp_path):
     cont2 = [float(loop2.step()["loss"]) for _ in range(3)]
     assert cont[0] == cont2[0]                                   # same state, same draws
     assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(cont, cont2))   # later steps: fp32-atomic summation order only
+
+
+FULL_SIZE = {   # BASELINE.json configs 2-5 at their per-GPU shapes (F=512, 8 layers, PE10)
+    "c2_lambert": (dict(), 4096, 64, 64, dict(apply_brdf=False, apply_theta=False, cos_irra_on=False)),
+    "c3_rpv_nan": (dict(funcM=1, funcF=1, funcH=1, normal="analystic"), 4096, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    "c4_rpv_nlr_s128": (dict(funcM=1, funcF=1, funcH=1, normal="learned"), 1024, 128, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    "c5_hapke": (dict(b=1, c=1, normal="analystic"), 1024, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    "c5_microfacet": (dict(roughness=True, normal="analystic"), 1024, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL_SIZE))
+def test_full_size_render_and_train_step_properties(name):
+    """BASELINE configurations at full width and batch in bf16, through size-independent properties: sorted depths, a
+    permutation as sort index, weights in [0,1] summing to <= 1, pixels in [0,1], finite outputs and gradients, and a
+    few fused training steps (depth supervision, ds_lambda=10) that stay finite and settle below the initial losses."""
+    import bench
+    from brdf_nerf_amd import render_rays
+    from brdf_nerf_amd.trainer import FusedTrainer
+    kw, R, S, G, flags = FULL_SIZE[name]
+    cfg = FieldConfig(n_samples=S, guided_samples=G, **kw)
+    args = make_args(cfg, "bf16")
+    torch.manual_seed(0)
+    from brdf_nerf_amd import load_model
+    model = load_model(args).to(DEV)
+    b = bench.synthetic_batch(R, 5, torch.device(DEV))
+    with torch.no_grad():
+        res, _ = render_rays({"coarse": model}, args, b["rays"], None, mode="test", **flags)
+    z, w, idx = res["z_vals_coarse"], res["weights_coarse"], res["sort_idx_coarse"]
+    assert z.shape == (R, S + G) and bool((z[:, 1:] >= z[:, :-1]).all())
+    assert bool((torch.sort(idx, -1)[0] == torch.arange(S + G, device=DEV)).all())
+    assert float(w.min()) >= 0.0 and float(w.sum(-1).max()) <= 1.0 + 1e-4
+    assert float(res["rgb_coarse"].min()) >= 0.0 and float(res["rgb_coarse"].max()) <= 1.0
+    for k, v in res.items():
+        if v.dtype.is_floating_point and k != "hpk_scl_coarse":
+            assert bool(torch.isfinite(v).all()), k
+    tr = FusedTrainer(model, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+    losses_ = []
+    for i in range(8):
+        loss, _ = tr.step(b["rays"], b["rgbs"], valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"],
+                          near_far=(0.0, 2.0), **flags)
+        assert bool(torch.isfinite(tr.flat_grad).all()), f"step {i}: non-finite gradient"
+        losses_.append(float(loss))
+    # Adam's first steps move every weight by lr whatever the gradient: the loss may spike before it settles
+    assert all(l == l for l in losses_) and losses_[-1] < max(losses_[:3]), losses_
+
+
+def test_bf16_training_psnr_tracks_fp32():
+    """north_star: PSNR within 0.05 dB of the reference.  The fp32 mode is held to the reference by the golden tests;
+    here the bf16 throughput mode is run beside it - same initialisation, same rays, same draws - and the PSNR of the
+    fitted batch must agree within 0.05 dB after 40 fused steps."""
+    import bench
+    from brdf_nerf_amd import load_model, losses
+    from brdf_nerf_amd.trainer import FusedTrainer
+    cfg = FieldConfig(n_samples=64, guided_samples=64)
+    b = bench.synthetic_batch(2048, 9, torch.device(DEV))
+    out = {}
+    for mode in ("fp32", "bf16"):
+        args = make_args(cfg, mode)
+        torch.manual_seed(0)
+        model = load_model(args).to(DEV)
+        tr = FusedTrainer(model, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+        torch.manual_seed(1)
+        for _ in range(40):
+            loss, rgb = tr.step(b["rays"], b["rgbs"], valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"],
+                                near_far=(0.0, 2.0))
+        out[mode] = float(losses.psnr(rgb, b["rgbs"]))
+    diag(f"PSNR after 40 steps: fp32 {out['fp32']:.4f} dB, bf16 {out['bf16']:.4f} dB")
+    assert abs(out["fp32"] - out["bf16"]) <= 0.05, out
