@@ -24,6 +24,11 @@ class FusedTrainer:
         self.model, self.args = model, args
         self.reg = dict(nr_an=nr_reg_an_lambda, nr_lr=nr_reg_lr_lambda, hs=hs_lambda, nr_spv=nr_spv_lambda)
         self.fused_glue = True      # Lambertian steps: one launch for shading + losses + their gradients
+        # The BRDF models have genuine singularities (Hapke's azimuth phi = acos(.) at phi -> 0, grazing angles): autograd -
+        # and the kernels, which follow it - return inf/NaN there, and ONE such ray would poison every weight through Adam.
+        # The fused step drops non-finite per-sample gradients instead (a deviation only where the reference's own
+        # gradient is non-finite); set False for strict autograd semantics.
+        self.sanitize_grads = True
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.lambda_rgb, self.ds_lambda, self.usealldepth = lambda_rgb, ds_lambda, usealldepth
         self.pg, self.strict_rng, self.reuse_coarse = process_group, strict_rng, reuse_coarse
@@ -179,6 +184,8 @@ class FusedTrainer:
             for c0, dn in zip(n_leaf.keys(), grads[3:]):
                 if dn is not None:
                     d_out[..., c0:c0 + 3] += dn          # regulariser gradients on the per-sample normals
+            if self.sanitize_grads and not (lambertian and self.fused_glue):
+                torch.nan_to_num_(d_out, nan=0.0, posinf=0.0, neginf=0.0)
             self.flat_grad.zero_()
             if self.reuse_coarse:
                 d_cat = self._buf("d_cat", (R, S2, C)).scatter_(1, idx_c, d_out)             # back to [coarse | guided] order

@@ -953,6 +953,10 @@ FULL_SIZE = {   # BASELINE.json configs 2-5 at their per-GPU shapes (F=512, 8 la
     "c3_rpv_nan": (dict(funcM=1, funcF=1, funcH=1, normal="analystic"), 4096, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
     "c4_rpv_nlr_s128": (dict(funcM=1, funcF=1, funcH=1, normal="learned"), 1024, 128, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
     "c5_hapke": (dict(b=1, c=1, normal="analystic"), 1024, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    # Hapke with macroscopic roughness: its azimuth term has an infinite derivative at phi = 0; this seed reaches a ray
+    # whose fp32 cos(phi) rounds to exactly 1 (the oracle's autograd is finite only because the CPU rounds it just below).
+    # The fused step drops that ray's non-finite gradient (FusedTrainer.sanitize_grads).
+    "c5_hapke_theta": (dict(b=1, c=1, theta=1, normal="analystic"), 1024, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
     "c5_microfacet": (dict(roughness=True, normal="analystic"), 1024, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
 }
 
