@@ -229,6 +229,19 @@ def main():
                      "traffic": PMC_TRAFFIC_BYTES.get(dom) if (a.config, a.rays, a.samples, a.guided, a.dtype) ==
                      ("lambert", 4096, 64, 64, "bf16") else None,
                      "traffic_unit": "bytes/launch (rocprofv3 PMC, offline pass: profiles/r01_pmc_traffic.txt)"},
+        # SURVEY.md section 8d kernel-level figure: the fused MLP on M = rays x samples rows (one launch of each kernel)
+        "mlp_microbench": {
+            "rows": M2 // 2,
+            "fwd_ms": kernels["field_fwd_full"]["ms_per_launch"],
+            "fwd_tflops": fpp["field_fwd_full"] * (M2 // 2) / (kernels["field_fwd_full"]["ms_per_launch"] * 1e-3) / 1e12,
+            "fwd_bwd_ms": sum(kernels[n]["ms_per_launch"] for n in ("field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad")
+                              if n in kernels),
+            "fwd_bwd_tflops": 3.0 * fpp["field_fwd_full"] * (M2 // 2) /
+                              (sum(kernels[n]["ms_per_launch"] for n in ("field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad")
+                                   if n in kernels) * 1e-3) / 1e12,
+            "note": "fwd = full forward with activation stash; fwd_bwd = forward + backward chain + weight gradients, 3x the "
+                    "forward's algorithmic FLOPs (dX + dW), analytic-normal kernels not included",
+        } if "field_fwd_full" in kernels else None,
         "step_tflops": flops_step / (dt / a.steps) / 1e12, "step_frac_of_peak": flops_step / (dt / a.steps) / 1e12 / peak,
         "step_tflops_reference_accounting": flops_ref / (dt / a.steps) / 1e12,
         "kernels": kernels, "final_loss": float(loss),
