@@ -295,24 +295,11 @@ struct WgradArgs {
 
 #define WG_BK 32
 template <typename T> struct WgTile;
-template <> struct WgTile<bf16> { static constexpr int LD = 128 + 32; };   // 320 B rows: the 4 rows of a tr-read block hit disjoint banks
 template <> struct WgTile<float> { static constexpr int LD = 128 + 4; };
 
+// fp32 parity path (the bf16 path is wgrad256_kernel below).
 // 8-element MFMA fragment of the TRANSPOSED tile: element j <-> contraction index (point) m, fixed column `col`.
 template <typename T> __device__ __forceinline__ typename Elem<T>::frag wg_frag(const T *tile, int mm, int col0, int lane);
-template <> __device__ __forceinline__ bf16x8 wg_frag<bf16>(const bf16 *tile, int mm, int col0, int lane) {
-  // two ds_read_b64_tr_b16: each 16-lane group reads a 4(m) x 16(col) block and gets it column-major:
-  // lane i of the group receives column i, rows 0..3.  Lane 4q+p supplies the address of row q, columns 4p..4p+3.
-  constexpr int LD = WgTile<bf16>::LD;
-  const int h = lane >> 5, grp = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
-  const bf16 *a = tile + (size_t)(mm + 8 * h + q) * LD + col0 + 16 * grp + 4 * p;
-  typedef __attribute__((address_space(3))) s16x4 lds_v4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)a);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a + 4 * LD));
-  union { s16x4 s[2]; bf16x8 b; } u;
-  u.s[0] = lo; u.s[1] = hi;
-  return u.b;
-}
 template <> __device__ __forceinline__ f32x8 wg_frag<float>(const float *tile, int mm, int col0, int lane) {
   // fp32 MFMA j consumes element j of both operands with lane-half h as its k index: m = mm + 2j + h.
   constexpr int LD = WgTile<float>::LD;
@@ -837,8 +824,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   if (w.n_jobs > 0) {
     dim3 grid((unsigned)w.tile0[w.n_jobs], (unsigned)ceil_div64(sl.Mpad, mpb));
     BnProfScope prof_(BN_K_WGRAD, st);
-    if (bf) wgrad_kernel<bf16><<<grid, 256, 0, st>>>(w);
-    else wgrad_kernel<float><<<grid, 256, 0, st>>>(w);
+    wgrad_kernel<float><<<grid, 256, 0, st>>>(w);     // bf16 jobs were consumed by wgrad256_kernel above
     BN_LAUNCH_CHECK("wgrad");
   }
   SkinnyArgs s;
