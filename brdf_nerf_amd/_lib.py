@@ -24,7 +24,7 @@ class FieldDesc(C.Structure):
     _fields_ = [("feat", C.c_int32), ("layers", C.c_int32), ("skip", C.c_int32), ("pe_freqs", C.c_int32),
                 ("act", C.c_int32), ("dtype", C.c_int32), ("n_heads", C.c_int32),
                 ("head_out", C.c_int32 * BN_MAX_HEADS), ("head_kind", C.c_int32 * BN_MAX_HEADS),
-                ("normal_lr", C.c_int32), ("normal_an", C.c_int32), ("out_channels", C.c_int32)]
+                ("normal_lr", C.c_int32), ("normal_an", C.c_int32), ("out_channels", C.c_int32), ("fold_feats", C.c_int32)]
 
 
 class FieldParams(C.Structure):

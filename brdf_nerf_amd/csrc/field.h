@@ -19,6 +19,7 @@ struct FieldGeom {
   int head_col[BN_MAX_HEADS];   // first output channel of head i in `out`
   int C;                        // out channels
   int ch_normal_an, ch_normal_lr;  // channel index or -1
+  int fold;                        // feats layer folded into the heads' first layers (bn_field_desc.fold_feats)
 };
 
 // Tile configuration of the fused chain kernels: 8 waves per workgroup, one workgroup per CU (2 waves per SIMD);
@@ -46,6 +47,7 @@ static inline int bn_make_geom(const bn_field_desc *d, FieldGeom *g) {
     g->NT = per <= 1 ? 1 : (per <= 2 ? 2 : 4);
   }
   g->H2 = d->feat / 2;
+  g->fold = d->fold_feats != 0;
   g->n_heads = d->n_heads;
   g->n_pass = (d->n_heads + 1) / 2;
   int c = 4;
@@ -94,10 +96,10 @@ static inline void bn_make_packed_layout(const FieldGeom &g, PackedLayout *pl) {
     else if (l == g.skip) { pl->fwd_trunk[l][0] = take(g.F, g.KP); pl->fwd_trunk[l][1] = take(g.F, g.F); }
     else pl->fwd_trunk[l][0] = take(g.F, g.F);
   }
-  pl->fwd_feats = take(g.F, g.F);
+  pl->fwd_feats = g.fold ? 0 : take(g.F, g.F);
   for (int p = 0; p < g.n_pass; ++p) pl->fwd_head[p] = take(g.pass_N[p], g.F);
   for (int l = 0; l < g.L; ++l) pl->bwd_trunk[l] = l >= 1 ? take(g.F, g.F) : 0;
-  pl->bwd_feats = take(g.F, g.F);
+  pl->bwd_feats = g.fold ? 0 : take(g.F, g.F);
   for (int p = 0; p < g.n_pass; ++p) pl->bwd_head[p] = take(g.F, g.pass_N[p]);
   pl->bwd_pe[0] = take(g.KP, g.F);
   pl->bwd_pe[1] = g.skip > 0 ? take(g.KP, g.F) : 0;

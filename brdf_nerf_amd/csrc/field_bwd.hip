@@ -166,8 +166,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
     __syncthreads();
     BN_PH(5)
   }
-  // dFeats -> LDS (+ stash below)
-  if (wave_on) {
+  // dFeats -> LDS (+ stash below).  With fold_feats the head products above already are W_f^T W_1^T dG = dL/dY_{L-1}
+  // (before the rank-1 terms and D): they stay in the accumulators for the top epilogue and the W_f^T GEMM is skipped.
+  if (wave_on && !g.fold) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   // ---------------------------------------------------------------- trunk, top layer first
   for (int l = g.L; l >= 1; --l) {
     // l == L: dY_{L-1} = Wf^T dFeats + sigma/normal rank-1 terms; else dY_{l-1} = W_l^T dZ_l
-    zero_acc<MT, NT>(acc);
+    const bool folded_top = g.fold && l == g.L;   // the product is already in the accumulators
+    if (!folded_top) zero_acc<MT, NT>(acc);
     const int lo = l - 1;  // layer whose pre-activation gradient is produced
     // D_lo = d act / d z of that layer, read back in accumulator order.  The loads are issued around the GEMM -
     // n-tile 0 before it (in flight while the MFMAs run), the others right after its last MFMA, when the weight and
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
     const T *Ds = (const T *)(A.stash + A.sl.D[lo]) + (size_t)tile * BM * F;
     typename Elem<T>::frag dpre[NT][2][MT];
     T *zdst = (T *)(A.stash + (l == g.L ? A.sl.dfeats : A.sl.dZ[l])) + (size_t)m0 * F;
-    if (!ride) tile_to_global<T>(ACT, LDA, zdst, F, BM, F);
+    if (!ride && !folded_top) tile_to_global<T>(ACT, LDA, zdst, F, BM, F);
     if (wave_on) {
 #pragma unroll
       for (int gp = 0; gp < 2; ++gp)
@@ -205,7 +207,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
         for (int mt = 0; mt < MT; ++mt) dpre[0][gp][mt] = stash_load((const typename Elem<T>::frag *)(Ds + native_off8<MT, NT>(wave, 0, mt, gp, lane)));
       const size_t off = (l == g.L ? A.pl.bwd_feats : A.pl.bwd_trunk[l]) + (size_t)(ncol0 / 32) * KSF * 512;
       // the row-major stash copy of the tile this GEMM reads (dFeats, then dZ_l) rides inside the GEMM
-      if (ride) {
+      if (folded_top) {
+      } else if (ride) {
         TileCopyExact<T> zcopy(ACT, LDA, zdst, F, F, tid, WAVES * 64);
         gemm_seg<T, MT, NT>(acc, packed + off, KSF, ACT, LDA, lane, zcopy);
       } else {
@@ -767,7 +770,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
       add(dZ, F, 0, S + sl.Y[l - 1], F, 0, G->trunk_w[l] ? G->trunk_w[l] + P0 : nullptr, F + P0, nullptr, F, F);
     } else add(dZ, F, 0, S + sl.Y[l - 1], F, 0, G->trunk_w[l], F, G->trunk_b[l], F, F);
   }
-  add(S + sl.dfeats, F, 0, S + sl.Y[g.L - 1], F, 0, G->feats_w, F, G->feats_b, F, F);
+  if (!g.fold) add(S + sl.dfeats, F, 0, S + sl.Y[g.L - 1], F, 0, G->feats_w, F, G->feats_b, F, F);
   if (a.an) {  // dW_l += delta_l^T [gbar_PE ; abar_l]
     for (int l = 0; l < g.L; ++l) {
       const void *dl = S + sl.adj_delta[l];
@@ -780,7 +783,8 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   }
   for (int hd = 0; hd < g.n_heads; ++hd) {
     const int p = hd / 2, hl = hd % 2;
-    add(S + sl.dG[p], g.pass_N[p], hl * g.H2, S + sl.feats, F, 0, G->head_w1[hd], F, G->head_b1[hd], g.H2, F);
+    // folded: the head's first layer reads Y_{L-1}; the gradient is that of the folded matrix (bn_field_desc.fold_feats)
+    add(S + sl.dG[p], g.pass_N[p], hl * g.H2, S + (g.fold ? sl.Y[g.L - 1] : sl.feats), F, 0, G->head_w1[hd], F, G->head_b1[hd], g.H2, F);
   }
   BN_REQUIRE(w.n_jobs <= BN_MAX_WGRAD_JOBS, "field_backward: too many wgrad jobs");
   if (bf && w.n_jobs > 0) {

@@ -417,6 +417,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
   if (A.sigma_only) { BN_PH_FLUSH return; }
 
   // ---------------------------------------------------------------- feats = Wf h8 + bf (linear)
+  // With fold_feats the caller has multiplied the feats layer into the heads' first layers: the heads read h8 directly.
+  if (g.fold) {
+    if (keep) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[g.L - 1]) + (size_t)m0 * F, F, BM, F);
+  } else {
   zero_acc<MT, NT>(acc);
   if (keep && !ride) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[g.L - 1]) + (size_t)m0 * F, F, BM, F);
   if (wave_on) {
@@ -447,6 +451,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
   }
   __syncthreads();
   if (keep) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.feats) + (size_t)m0 * F, F, BM, F);
+  }
   BN_PH(8)
 
   // ---------------------------------------------------------------- two-layer sigmoid heads, up to 2 per pass
@@ -556,8 +561,11 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
       add(P->trunk_w[l], pl.bwd_trunk[l], ld, F, F, l == g.skip ? P0 : 0, 0, 1);
     }
   }
-  add(P->feats_w, pl.fwd_feats, F, F, F, 0, 0, 0);
-  add(P->feats_w, pl.bwd_feats, F, F, F, 0, 0, 1);
+  if (!g.fold) {
+    BN_REQUIRE(P->feats_w && P->feats_b, "pack: feats layer missing");
+    add(P->feats_w, pl.fwd_feats, F, F, F, 0, 0, 0);
+    add(P->feats_w, pl.bwd_feats, F, F, F, 0, 0, 1);
+  }
   // (W_l[:, :P])^T for the analytic-normal adjoint: packed[row p][k n] = W_l[n][p]
   add(P->trunk_w[0], pl.bwd_pe[0], P0, P0, F, 0, 0, 1);
   a.job[a.n_jobs - 1].rows_pad = g.KP;

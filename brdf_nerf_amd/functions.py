@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and the stream and stitches the 
 every numerical step of the hot path runs in the HIP library.  No CPU fallback exists.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -29,12 +30,21 @@ def _f32(t):
 class FieldSpec:
     """Host-side description of one evaluation of the field: which heads, which dtype."""
 
-    def __init__(self, feat, layers, skip, pe_freqs, act, dtype, heads, normal_lr, normal_an=False):
+    def __init__(self, feat, layers, skip, pe_freqs, act, dtype, heads, normal_lr, normal_an=False, fold_feats=None):
         # heads: list of (name, n_out, kind); heads[0] must be ("rgb_from_xyzdir", 3, PLAIN)
         self.feat, self.layers, self.skip, self.pe_freqs, self.act, self.dtype = feat, layers, skip, pe_freqs, act, dtype
         self.heads, self.normal_lr, self.normal_an = list(heads), bool(normal_lr), bool(normal_an)
+        # feats_from_xyz is linear and feeds only the heads' first (linear) layers: W1 (Wf y + bf) + b1 = (W1 Wf) y + (W1 bf + b1).
+        # Folding the two (one small GEMM per head per weight update, fold()) removes an F x F product per point from the
+        # forward, the backward chain and the weight-gradient kernels; unfold_grads() takes the folded gradients back to
+        # W1, b1, Wf, bf by the chain rule.  BRDFNERF_FOLD_FEATS=0 keeps the layer-by-layer evaluation.
+        if fold_feats is None:
+            fold_feats = os.environ.get("BRDFNERF_FOLD_FEATS", "1") != "0"
+        self.fold_feats = bool(fold_feats)
+        self.folded, self.fold_grads = {}, {}
         d = L.FieldDesc()
         d.feat, d.layers, d.skip, d.pe_freqs, d.act, d.dtype = feat, layers, skip, pe_freqs, act, dtype
+        d.fold_feats = int(self.fold_feats)
         d.n_heads = len(self.heads)
         c = 4 + (3 if normal_an else 0) + (3 if normal_lr else 0)
         self.head_cols = []
@@ -56,7 +66,7 @@ class FieldSpec:
 
     def key(self):
         return (self.feat, self.layers, self.skip, self.pe_freqs, self.act, self.dtype, tuple(self.heads), self.normal_lr,
-                self.normal_an)
+                self.normal_an, self.fold_feats)
 
     def params_struct(self, named, grads=False):
         """named: dict state_dict-key -> tensor (parameters, or same-shaped gradient buffers)."""
@@ -69,9 +79,58 @@ class FieldSpec:
         for i, (name, _, _) in enumerate(self.heads):
             s.head_w1[i], s.head_b1[i] = named[f"{name}.0.weight"].data_ptr(), named[f"{name}.0.bias"].data_ptr()
             s.head_w2[i], s.head_b2[i] = named[f"{name}.2.weight"].data_ptr(), named[f"{name}.2.bias"].data_ptr()
+        if self.fold_feats:
+            if grads:        # the library accumulates d/d(folded w1, b1) here; feats_* are produced by unfold_grads()
+                s.feats_w = s.feats_b = None
+                for i, (name, _, _) in enumerate(self.heads):
+                    w1 = named[f"{name}.0.weight"]
+                    ent = self.fold_grads.get(name)
+                    if ent is None or ent[0].device != w1.device:
+                        ent = (torch.zeros_like(w1), torch.zeros(w1.shape[0], dtype=torch.float32, device=w1.device))
+                        self.fold_grads[name] = ent
+                    s.head_w1[i], s.head_b1[i] = ent[0].data_ptr(), ent[1].data_ptr()
+            else:
+                if any(name not in self.folded for name, _, _ in self.heads):
+                    self.fold(named)     # a spec evaluated with another spec's packed weights (sigma-only passes)
+                for i, (name, _, _) in enumerate(self.heads):
+                    s.head_w1[i], s.head_b1[i] = self.folded[name][0].data_ptr(), self.folded[name][1].data_ptr()
         if self.normal_lr:
             s.normal_w, s.normal_b = named["grad_from_xyz.weight"].data_ptr(), named["grad_from_xyz.bias"].data_ptr()
         return s
+
+    @torch.no_grad()
+    def fold(self, named):
+        """(W1 Wf, W1 bf + b1) per head, refreshed whenever the weights are re-packed."""
+        wf, bf = named["feats_from_xyz.weight"].detach(), named["feats_from_xyz.bias"].detach()
+        for name, _, _ in self.heads:
+            w1, b1 = named[f"{name}.0.weight"].detach(), named[f"{name}.0.bias"].detach()
+            ent = self.folded.get(name)
+            if ent is None or ent[0].device != w1.device:
+                ent = (torch.empty_like(w1), torch.empty_like(b1))
+                self.folded[name] = ent
+            torch.matmul(w1, wf, out=ent[0])
+            torch.addmv(b1, w1, bf, out=ent[1])
+
+    @torch.no_grad()
+    def unfold_grads(self, named, named_grads):
+        """Chain rule from the folded first layers back to the three factors (accumulating, like the library):
+        dW1 += M Wf^T + s bf^T, db1 += s, dWf += W1^T M, dbf += W1^T s, with M = dL/d(W1 Wf), s = dL/d(W1 bf + b1)."""
+        wf, bf = named["feats_from_xyz.weight"].detach(), named["feats_from_xyz.bias"].detach()
+        dwf, dbf = named_grads["feats_from_xyz.weight"], named_grads["feats_from_xyz.bias"]
+        for name, _, _ in self.heads:
+            ent = self.fold_grads.get(name)
+            if ent is None:
+                continue
+            m, sv = ent
+            w1 = named[f"{name}.0.weight"].detach()
+            dw1, db1 = named_grads[f"{name}.0.weight"], named_grads[f"{name}.0.bias"]
+            dw1.addmm_(m, wf.t())
+            dw1.addr_(sv, bf)
+            db1.add_(sv)
+            dwf.addmm_(w1.t(), m)
+            dbf.addmv_(w1.t(), sv)
+            m.zero_()
+            sv.zero_()
 
     def used_param_names(self):
         names = []
@@ -100,6 +159,8 @@ def pack_field(spec, named_params, packed=None):
     dev = named_params["fc_net.0.weight"].device
     if packed is None:
         packed = torch.empty(spec.packed_bytes, dtype=torch.uint8, device=dev)
+    if spec.fold_feats:
+        spec.fold(named_params)
     ps = spec.params_struct(named_params)
     L.check(L.lib().bn_pack_field(C.byref(spec.desc), C.byref(ps), _p(packed), _stream()), "bn_pack_field")
     return packed
@@ -159,13 +220,16 @@ class FieldFunction(torch.autograd.Function):
             tot += (n + 3) // 4 * 4
         flat = torch.zeros(tot, dtype=torch.float32, device=out.device)
         grads = [flat[o:o + n].view(p.shape) for o, n, p in zip(offs, sizes, params)]
-        gs = spec.params_struct(dict(zip(names, grads)))
+        named_grads = dict(zip(names, grads))
+        gs = spec.params_struct(named_grads, grads=True)
         ps = spec.params_struct(named)
         xyz, rays, z = ctx.pts_t
         pts = make_points(xyz, rays, z)
         d_out = _f32(d_out)
         L.check(L.lib().bn_field_backward(C.byref(spec.desc), C.byref(ps), _p(ctx.packed), C.byref(pts), _p(out),
                                           _p(d_out), _p(ctx.stash), C.byref(gs), _stream()), "bn_field_backward")
+        if spec.fold_feats:
+            spec.unfold_grads(named, named_grads)
         ctx.stash = None
         return (None, None, None, None, None, None) + tuple(g if p.requires_grad else None
                                                             for g, p in zip(grads, params))
@@ -265,11 +329,15 @@ def field_forward_raw(spec, named_params, packed, out, stash, xyz=None, rays=Non
     return out
 
 
-def field_backward_raw(spec, named_params, named_grads, packed, out, d_out, stash, xyz=None, rays=None, z=None):
+def field_backward_raw(spec, named_params, named_grads, packed, out, d_out, stash, xyz=None, rays=None, z=None, unfold=True):
+    """unfold=False leaves the folded first-layer gradients in spec.fold_grads (they keep accumulating): a caller that
+    back-propagates several batches before the optimizer step unfolds once, on the last call."""
     pts = make_points(xyz, rays, z)
-    ps, gs = spec.params_struct(named_params), spec.params_struct(named_grads)
+    ps, gs = spec.params_struct(named_params), spec.params_struct(named_grads, grads=True)
     L.check(L.lib().bn_field_backward(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(out), _p(d_out), _p(stash),
                                       C.byref(gs), _stream()), "bn_field_backward")
+    if spec.fold_feats and unfold:
+        spec.unfold_grads(named_params, named_grads)
 
 
 def field_stash_bytes(spec, n_points):

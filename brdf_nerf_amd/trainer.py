@@ -190,7 +190,7 @@ class FusedTrainer:
             if self.reuse_coarse:
                 d_cat = self._buf("d_cat", (R, S2, C)).scatter_(1, idx_c, d_out)             # back to [coarse | guided] order
                 d1o, d2o = d_cat[:, :S].contiguous().view(R * S, C), d_cat[:, S:].contiguous().view(R * G, C)
-                Fn.field_backward_raw(spec, named, self.grad_views, packed, out1, d1o, stash1, rays=rays, z=z)
+                Fn.field_backward_raw(spec, named, self.grad_views, packed, out1, d1o, stash1, rays=rays, z=z, unfold=False)
                 Fn.field_backward_raw(spec, named, self.grad_views, packed, out2, d2o, stash2, rays=rays, z=z2)
             else:
                 Fn.field_backward_raw(spec, named, self.grad_views, packed, out, d_out.view(R * S2, C), stash, rays=rays, z=z_all)

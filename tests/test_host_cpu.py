@@ -110,8 +110,9 @@ def test_packed_and_stash_sizes():
     model = load_model(make_args(FieldConfig()))
     spec = model.spec(False, False, False)
     F, P = 512, 64
-    fwd = F * P + 6 * F * F + (F * P + F * F) + F * F + 256 * F
-    bwd = 7 * F * F + F * F + F * 256 + 2 * P * F            # + (W_0[:, :P])^T and (W_skip[:, :P])^T for the normals adjoint
+    fold = spec.fold_feats                                    # feats layer folded into the heads: no F x F feats blocks
+    fwd = F * P + 6 * F * F + (F * P + F * F) + (0 if fold else F * F) + 256 * F
+    bwd = 7 * F * F + (0 if fold else F * F) + F * 256 + 2 * P * F   # + (W_0[:, :P])^T and (W_skip[:, :P])^T for the normals adjoint
     assert spec.packed_bytes == (fwd + bwd) * 4                      # fp32 parity mode
     n = Fn.field_stash_bytes(spec, 1000)
     assert n > 1024 * F * 4 * 16 and n % 256 == 0
