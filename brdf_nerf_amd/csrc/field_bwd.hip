@@ -432,26 +432,12 @@ __device__ __forceinline__ bf16x8 w2_frag(const bf16 *tile, int mm, int col0, in
 #define W2_WAVES 8
 #endif
 #define W2_RA (256 / ((W2_WAVES / 2) * 32))   // 32-row accumulator tiles per wave along n
-__global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256_kernel(const WgradArgs A, int n_split, int n_blocks) {
-  extern __shared__ __attribute__((aligned(16))) char smem_w[];
-  bf16 *sA = (bf16 *)smem_w;                 // [2][W2_BK][W2_LD]
-  bf16 *sB = sA + 2 * W2_STAGE;
-  // XCD-aware id: hardware deals consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous range
-  const int per = n_blocks / 8;              // n_blocks is a multiple of 8
-  const int lid = (blockIdx.x % 8) * per + blockIdx.x / 8;
-  const int total_tiles = A.tile0[A.n_jobs];
-  if (lid >= total_tiles * n_split) return;
-  const int split = lid / total_tiles, tt = lid % total_tiles;
-  int jb = 0;
-  while (jb + 1 < A.n_jobs && tt >= A.tile0[jb + 1]) ++jb;
-  const WgradJob &J = A.job[jb];
-  const int t = tt - A.tile0[jb];
-  const int tiles_k = (J.K + 255) / 256;
-  const int n0 = (t / tiles_k) * 256, k0 = (t % tiles_k) * 256;
+// One 256 x 256 output tile over the points [mb, me).  NBV = 32-column accumulator tiles this WAVE multiplies (4 for a
+// full tile; the 60-column positional-encoding operand only has columns for two tiles of the wc = 0 waves - the other
+// waves of such a block just take part in staging and barriers).
+template <int NBV>
+__device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64_t mb, int64_t me, bf16 *sA, bf16 *sB) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-  const int64_t mb = (int64_t)split * A.m_per_block;
-  const int64_t me = mb + A.m_per_block < A.Mpad ? mb + A.m_per_block : A.Mpad;
-  if (mb >= me) return;
   const bf16 *gA = (const bf16 *)J.A + J.a_col0 + n0;
   const bf16 *gB = (const bf16 *)J.B + J.b_col0 + k0;
   // W2_BK rows x 32 chunks (16 B) per operand: NC per thread
@@ -505,12 +491,12 @@ __global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256
   // hipcc from sinking the reads below the MFMAs)
   auto compute = [&](int buf) {
     const bf16 *cA = sA + buf * W2_STAGE, *cB = sB + buf * W2_STAGE;
-    bf16x8 fa[2][W2_RA], fb[2][4];
+    bf16x8 fa[2][W2_RA], fb[2][NBV > 0 ? NBV : 1];
     auto frags = [&](int set, int mm) {
 #pragma unroll
       for (int a = 0; a < W2_RA; ++a) fa[set][a] = w2_frag(cA, mm, wr * (W2_RA * 32) + a * 32, lane);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) fb[set][b] = w2_frag(cB, mm, wc * 128 + b * 32, lane);
+      for (int b = 0; b < NBV; ++b) fb[set][b] = w2_frag(cB, mm, wc * 128 + b * 32, lane);
     };
     frags(0, 0);
 #pragma unroll
@@ -522,12 +508,12 @@ __global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256
       if (i + 1 < W2_BK / 16) frags(cur ^ 1, (i + 1) * 16);
       __builtin_amdgcn_sched_barrier(0);
 #ifdef W2_SKIP_MFMA    // diagnostic variant: memory side only (one MFMA keeps the fragment reads alive)
-      mma32(acc[0][0], fa[cur][0] + fa[cur][1], fb[cur][0] + fb[cur][1] + fb[cur][2] + fb[cur][3]);
+      if (NBV == 4) mma32(acc[0][0], fa[cur][0] + fa[cur][1], fb[cur][0] + fb[cur][1] + fb[cur][2] + fb[cur][3]);
 #else
 #pragma unroll
       for (int a = 0; a < W2_RA; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) mma32(acc[a][b], fa[cur][a], fb[cur][b]);
+        for (int b = 0; b < NBV; ++b) mma32(acc[a][b], fa[cur][a], fb[cur][b]);
 #endif
       if (do_bias) {
 #pragma unroll
@@ -579,6 +565,33 @@ __global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256
   }
   WG_PH(4)
   WG_PH_FLUSH
+}
+
+__global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256_kernel(const WgradArgs A, int n_split, int n_blocks) {
+  extern __shared__ __attribute__((aligned(16))) char smem_w[];
+  bf16 *sA = (bf16 *)smem_w;                 // [2][W2_BK][W2_LD]
+  bf16 *sB = sA + 2 * W2_STAGE;
+  // XCD-aware id: hardware deals consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous range
+  const int per = n_blocks / 8;              // n_blocks is a multiple of 8
+  const int lid = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  const int total_tiles = A.tile0[A.n_jobs];
+  if (lid >= total_tiles * n_split) return;
+  const int split = lid / total_tiles, tt = lid % total_tiles;
+  int jb = 0;
+  while (jb + 1 < A.n_jobs && tt >= A.tile0[jb + 1]) ++jb;
+  const WgradJob &J = A.job[jb];
+  const int t = tt - A.tile0[jb];
+  const int tiles_k = (J.K + 255) / 256;
+  const int n0 = (t / tiles_k) * 256, k0 = (t % tiles_k) * 256;
+  const int64_t mb = (int64_t)split * A.m_per_block;
+  const int64_t me = mb + A.m_per_block < A.Mpad ? mb + A.m_per_block : A.Mpad;
+  if (mb >= me) return;
+  const int wc = (threadIdx.x >> 6) & 1;
+  const int cols = J.K - k0 - wc * 128;          // output columns this wave's tiles can reach
+  if (cols >= 65) w2_body<4>(J, n0, k0, mb, me, sA, sB);
+  else if (cols >= 33) w2_body<2>(J, n0, k0, mb, me, sA, sB);
+  else if (cols >= 1) w2_body<1>(J, n0, k0, mb, me, sA, sB);
+  else w2_body<0>(J, n0, k0, mb, me, sA, sB);
 }
 
 struct SkinnyJob {
