@@ -4,6 +4,13 @@
 #include "common.h"
 
 #define BN_MAX_PASS 2
+// 32-column tiles per wave in a single-head pass (N = F/2 columns): NT/2 spreads the pass over all eight waves; NT keeps
+// half of them idle but halves the LDS fragment reads per MFMA (BN_HEAD_WIDE, A/B switch).
+#ifdef BN_HEAD_WIDE
+#define BN_SINGLE_HEAD_NTW(NT) (NT)
+#else
+#define BN_SINGLE_HEAD_NTW(NT) ((NT) > 1 ? (NT) / 2 : 1)
+#endif
 
 struct FieldGeom {
   int F, L, skip, pe_freqs, act;
@@ -67,7 +74,7 @@ static inline int bn_make_geom(const bn_field_desc *d, FieldGeom *g) {
   for (int p = 0; p < g->n_pass; ++p) {
     g->pass_heads[p] = (d->n_heads - 2 * p) >= 2 ? 2 : 1;
     g->pass_N[p] = g->pass_heads[p] * g->H2;
-    g->pass_NTW[p] = g->pass_heads[p] == 2 ? g->NT : (g->NT > 1 ? g->NT / 2 : 1);
+    g->pass_NTW[p] = g->pass_heads[p] == 2 ? g->NT : BN_SINGLE_HEAD_NTW(g->NT);
   }
   return 0;
 }

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   // ---------------------------------------------------------------- heads: dG -> LDS, dFeats += W1^T dG
   for (int p = 0; p < g.n_pass; ++p) {
     if (g.pass_heads[p] == 2) bwd_head_dG<T, MT, NT>(A, p, ACT, DPH, m0, tile);
-    else bwd_head_dG<T, MT, (NT > 1 ? NT / 2 : 1)>(A, p, ACT, DPH, m0, tile);
+    else bwd_head_dG<T, MT, BN_SINGLE_HEAD_NTW(NT)>(A, p, ACT, DPH, m0, tile);
     BN_PH(1)
     __syncthreads();
     BN_PH(2)

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
   // ---------------------------------------------------------------- two-layer sigmoid heads, up to 2 per pass
   for (int p = 0; p < g.n_pass; ++p) {
     if (g.pass_heads[p] == 2) head_pass<T, MT, NT, WAVES, KEEP>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
-    else head_pass<T, MT, (NT > 1 ? NT / 2 : 1), WAVES, KEEP>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
+    else head_pass<T, MT, BN_SINGLE_HEAD_NTW(NT), WAVES, KEEP>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
   }
   BN_PH_FLUSH
 }
