@@ -41,7 +41,9 @@ static __device__ unsigned long long bn_phase_clk[BN_PH_N + 1];
 // packed weights every workgroup re-reads from L2: non-temporal stores / loads keep it from evicting the weights.
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 template <typename V> __device__ __forceinline__ void stash_store(V *p, const V &v) {
-#ifdef BN_NO_NT_STASH
+#ifdef BN_SKIP_STASH_STORES   // diagnostic variant (profiles/ab_bench.sh): what the stash writes cost (results are wrong)
+  if (p == nullptr) *p = v;
+#elif defined(BN_NO_NT_STASH)
   *p = v;
 #else
   __builtin_nontemporal_store(v, p);
