@@ -170,7 +170,8 @@ class SpSBRDFNeRF(nn.Module):
         dtype = L.BN_BF16 if self.compute_dtype == "bf16" else L.BN_F32
         key = (bool(apply_brdf), bool(apply_theta), bool(nr_lr_on), bool(nr_an_on), dtype)
         if key not in self._specs:
-            self._specs[key] = Fn.FieldSpec(self.feat, self.layers, self.skips[0] if self.skips else -1, self.pe_freqs,
+            skip = self.skips[0] if self.skips and 0 < self.skips[0] < self.layers else -1   # --fc_layers <= 4: no skip layer
+            self._specs[key] = Fn.FieldSpec(self.feat, self.layers, skip, self.pe_freqs,
                                             L.BN_ACT_SIN if self.siren_on else L.BN_ACT_RELU, dtype,
                                             self.head_list(apply_brdf, apply_theta), nr_lr_on, nr_an_on)
         return self._specs[key]

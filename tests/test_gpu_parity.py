@@ -388,6 +388,20 @@ def test_field_backward_oracle_fp32_other_widths(feat):
         assert err <= 5e-4 * scale + 1e-7, f"{k}: err {err:.3e} scale {scale:.3e}"
 
 
+@pytest.mark.parametrize("layers", [4, 6])
+def test_field_other_depths_fp32(layers):
+    """--fc_layers 4 (the skip at layer 4 is never reached) and 6 (skip in the middle): forward and gradients vs the oracle."""
+    cfg = FieldConfig(feat=128, layers=layers, funcM=1, funcF=1, funcH=1, normal="learned")
+    flags = dict(apply_brdf=True, nr_lr_on=True)
+    model, p, out, ref = _field_grads(cfg, 8, "fp32", 200, flags)
+    assert_close(out, ref, 1e-4, 2e-5, "out")
+    for k, v in model.named_parameters():
+        want = p[k].grad
+        scale = float(want.abs().max())
+        err = float((v.grad.cpu() - want).abs().max())
+        assert err <= 5e-4 * scale + 1e-7, f"{k}: err {err:.3e} scale {scale:.3e}"
+
+
 @pytest.mark.parametrize("feat", [512, 256])
 def test_field_backward_bf16_direction(feat):
     """bf16 gradients: cosine similarity with the fp32 oracle gradient >= 0.98 per weight matrix (stated bound)."""
