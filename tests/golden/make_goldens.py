@@ -178,6 +178,22 @@ def gen_field(ref):
     save("field_sigma_grad_F64_fp64", xyz=x64, grad=grad, param_seed=11)
 
 
+def gen_field_variants(ref):
+    """--siren 0 (ReLU trunk and heads, default init) and no --mapping (raw xyz into the trunk), forward values and parameter
+    gradients of a random linear functional."""
+    for tag, kw in (("relu", dict(siren=False, funcM=1, funcF=1, funcH=1, normal="learned")),
+                    ("nomap", dict(mapping=False, funcM=1, funcF=1, funcH=1, normal="learned"))):
+        cfg = mini(**kw)
+        model, csum = build_ref_model(ref, cfg, seed=13)
+        g = torch.Generator().manual_seed(9)
+        xyz = torch.rand(201, 3, generator=g) * 2 - 1
+        out = quiet(model, xyz.clone(), apply_brdf=True, apply_theta=True, nr_an_on=False, nr_lr_on=True)
+        coef = torch.randn(out.shape, generator=g)
+        (out * coef).sum().backward()
+        grads = {f"grad/{k}": (p_.grad if p_.grad is not None else torch.zeros_like(p_)) for k, p_ in model.named_parameters()}
+        save(f"field_{tag}_F64", xyz=xyz, out_brdf=out, coef=coef, param_checksum=csum, param_seed=13, **grads)
+
+
 def gen_composite(ref):
     cal_weight = sys.modules["models.spsbrdfnerf"].cal_weight
     for S in (16, 128):
@@ -438,6 +454,9 @@ def gen_regularisers(ref):
 if __name__ == "__main__":
     torch.set_num_threads(4)
     ref = import_reference()
+    if "--only-field-variants" in sys.argv:
+        gen_field_variants(ref)
+        sys.exit(0)
     if "--only-sunv" in sys.argv:
         gen_render_sunv(ref)
         sys.exit(0)
@@ -448,6 +467,7 @@ if __name__ == "__main__":
         gen_render(ref)
         sys.exit(0)
     gen_field(ref)
+    gen_field_variants(ref)
     gen_composite(ref)
     gen_guided(ref)
     gen_brdf(ref)

@@ -388,6 +388,23 @@ def test_field_backward_oracle_fp32_other_widths(feat):
         assert err <= 5e-4 * scale + 1e-7, f"{k}: err {err:.3e} scale {scale:.3e}"
 
 
+@pytest.mark.parametrize("tag,kw", [("relu", dict(siren=False)), ("nomap", dict(mapping=False))])
+def test_field_relu_and_no_mapping_golden_fp32(tag, kw):
+    """--siren 0 (ReLU epilogues) and no --mapping (raw xyz padded into the 64-wide first operand) against reference goldens:
+    forward values and every parameter gradient."""
+    g = load_golden(f"field_{tag}_F64")
+    cfg = mini(funcM=1, funcF=1, funcH=1, normal="learned", **kw)
+    model = build_model(cfg, 13)
+    out = model(torch.from_numpy(g["xyz"]).to(DEV), apply_brdf=True, apply_theta=True, nr_lr_on=True)
+    assert_close(out, g["out_brdf"], 1e-4, 1e-5, "out")
+    (out * torch.from_numpy(g["coef"]).to(DEV)).sum().backward()
+    for k, v in model.named_parameters():
+        ref = g[f"grad/{k}"]
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        got = v.grad.cpu() if v.grad is not None else torch.zeros_like(v).cpu()
+        assert float((got - torch.from_numpy(ref)).abs().max()) <= 3e-4 * scale + 1e-8, k
+
+
 @pytest.mark.parametrize("layers", [4, 6])
 def test_field_other_depths_fp32(layers):
     """--fc_layers 4 (the skip at layer 4 is never reached) and 6 (skip in the middle): forward and gradients vs the oracle."""

@@ -270,6 +270,24 @@ def test_render_sun_visibility_pass(base, mode):
             assert float((got - torch.from_numpy(ref)).abs().max()) <= 2e-3 * scale + 1e-9, k
 
 
+@pytest.mark.parametrize("tag,kw", [("relu", dict(siren=False)), ("nomap", dict(mapping=False))])
+def test_field_relu_and_no_mapping(tag, kw):
+    """--siren 0 and no --mapping: forward and parameter gradients against the reference."""
+    g = load_golden(f"field_{tag}_F64")
+    cfg = mini(funcM=1, funcF=1, funcH=1, normal="learned", **kw)
+    p = tparams(cfg, 13)
+    for v in p.values():
+        v.requires_grad_(True)
+    out = F.field_forward(p, cfg, torch.from_numpy(g["xyz"]), apply_brdf=True, apply_theta=True, nr_lr_on=True)
+    assert_close(out, g["out_brdf"], 1e-5, 1e-6, "out")
+    (out * torch.from_numpy(g["coef"])).sum().backward()
+    for k, v in p.items():
+        ref = g[f"grad/{k}"]
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        got = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert float((got - torch.from_numpy(ref)).abs().max()) <= 1e-4 * scale + 1e-9, k
+
+
 def test_regulariser_losses():
     g = load_golden("loss_regularisers")
     t = {k: torch.from_numpy(v) for k, v in g.items()}
