@@ -179,10 +179,11 @@ def gen_field(ref):
 
 
 def gen_field_variants(ref):
-    """--siren 0 (ReLU trunk and heads, default init) and no --mapping (raw xyz into the trunk), forward values and parameter
-    gradients of a random linear functional."""
+    """--siren 0 (ReLU trunk and heads, default init), no --mapping (raw xyz into the trunk) and --dim_RPV 3 (three-channel
+    RPV heads), forward values and parameter gradients of a random linear functional."""
     for tag, kw in (("relu", dict(siren=False, funcM=1, funcF=1, funcH=1, normal="learned")),
-                    ("nomap", dict(mapping=False, funcM=1, funcF=1, funcH=1, normal="learned"))):
+                    ("nomap", dict(mapping=False, funcM=1, funcF=1, funcH=1, normal="learned")),
+                    ("rpv333", dict(dim_RPV=3, funcM=1, funcF=1, funcH=1, normal="learned"))):
         cfg = mini(**kw)
         model, csum = build_ref_model(ref, cfg, seed=13)
         g = torch.Generator().manual_seed(9)

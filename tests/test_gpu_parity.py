@@ -388,7 +388,7 @@ def test_field_backward_oracle_fp32_other_widths(feat):
         assert err <= 5e-4 * scale + 1e-7, f"{k}: err {err:.3e} scale {scale:.3e}"
 
 
-@pytest.mark.parametrize("tag,kw", [("relu", dict(siren=False)), ("nomap", dict(mapping=False))])
+@pytest.mark.parametrize("tag,kw", [("relu", dict(siren=False)), ("nomap", dict(mapping=False)), ("rpv333", dict(dim_RPV=3))])
 def test_field_relu_and_no_mapping_golden_fp32(tag, kw):
     """--siren 0 (ReLU epilogues) and no --mapping (raw xyz padded into the 64-wide first operand) against reference goldens:
     forward values and every parameter gradient."""

@@ -270,7 +270,7 @@ def test_render_sun_visibility_pass(base, mode):
             assert float((got - torch.from_numpy(ref)).abs().max()) <= 2e-3 * scale + 1e-9, k
 
 
-@pytest.mark.parametrize("tag,kw", [("relu", dict(siren=False)), ("nomap", dict(mapping=False))])
+@pytest.mark.parametrize("tag,kw", [("relu", dict(siren=False)), ("nomap", dict(mapping=False)), ("rpv333", dict(dim_RPV=3))])
 def test_field_relu_and_no_mapping(tag, kw):
     """--siren 0 and no --mapping: forward and parameter gradients against the reference."""
     g = load_golden(f"field_{tag}_F64")
