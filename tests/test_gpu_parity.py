@@ -405,6 +405,23 @@ def test_field_relu_and_no_mapping_golden_fp32(tag, kw):
         assert float((got - torch.from_numpy(ref)).abs().max()) <= 3e-4 * scale + 1e-8, k
 
 
+def test_field_both_normals_fp32():
+    """--normal analystic_learned: analytic (channels 4-6) and learned (7-9) normals together, forward and the gradients
+    through both (the analytic one needs the double backward) against the oracle's autograd."""
+    cfg = mini(b=1, c=1, normal="analystic_learned")
+    flags = dict(apply_brdf=True, apply_theta=True, nr_lr_on=True, nr_an_on=True)
+    model, p, out, ref = _field_grads(cfg, 21, "fp32", 150, flags)
+    assert out.shape[1] == 4 + 3 + 3 + 6
+    assert_close(out, ref, 2e-4, 2e-5, "out")
+    for k, v in model.named_parameters():
+        want = p[k].grad
+        if want is None:
+            continue
+        scale = float(want.abs().max())
+        err = float((v.grad.cpu() - want).abs().max())
+        assert err <= 1e-3 * scale + 1e-7, f"{k}: err {err:.3e} scale {scale:.3e}"
+
+
 @pytest.mark.parametrize("layers", [4, 6])
 def test_field_other_depths_fp32(layers):
     """--fc_layers 4 (the skip at layer 4 is never reached) and 6 (skip in the middle): forward and gradients vs the oracle."""
