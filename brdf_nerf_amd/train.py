@@ -47,8 +47,6 @@ class TrainLoop:
         flags = sch.begin_step()
         tr.lr = sch.lr(self.global_step)
         b = self.table.next_batch(a.batch_size * self.world, self.rank, self.world)
-        if flags["gsam_only"]:
-            raise NotImplementedError("gsam_only training (pass 2 on the guided samples only) is not wired into the fused step")
         has_depth = "depths" in b
         depths = b.get("depths")
         if has_depth and getattr(a, "ds_noweights", False):
@@ -63,7 +61,8 @@ class TrainLoop:
         try:
             loss, rgb = tr.step(b["rays"], b["rgbs"], valid_depth=b.get("valid_depth"), depths=depths,
                                 depth_std=b.get("depth_std"), apply_brdf=flags["apply_brdf"], apply_theta=flags["apply_theta"],
-                                cos_irra_on=flags["cos_irra_on"], depth_loss_on=flags["depth_loss_on"], near_far=self.near_far)
+                                cos_irra_on=flags["cos_irra_on"], depth_loss_on=flags["depth_loss_on"], near_far=self.near_far,
+                                gsam_only=flags["gsam_only"])
         finally:
             tr.reg = saved
         sch.end_step()

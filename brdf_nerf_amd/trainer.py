@@ -76,7 +76,9 @@ class FusedTrainer:
 
     # ------------------------------------------------------------------ one step
     def step(self, rays, rgbs, valid_depth=None, depths=None, depth_std=None, apply_brdf=False, apply_theta=False,
-             cos_irra_on=False, depth_loss_on=True, near_far=None, regularisers=True):
+             cos_irra_on=False, depth_loss_on=True, near_far=None, regularisers=True, gsam_only=False):
+        """gsam_only (main.py:201-203, rendering.py:266-269): pass 1 only guides the sampling; the step renders, and
+        back-propagates through, the G guided samples alone."""
         model, args = self.model, self.args
         S, G = args.n_samples, args.guided_samples
         R = rays.shape[0]
@@ -89,12 +91,13 @@ class FusedTrainer:
         sun_d = rays[:, 8:11] if args.data == "sat" else torch.ones_like(rays[:, 0:3])
         need_noise = self.strict_rng or args.noise_std != 0
         C = spec.out_channels
-        S2 = S + G
+        S2 = G if gsam_only else S + G
+        reuse = self.reuse_coarse and not gsam_only
         with torch.no_grad():
             z = Fn.stratified_z(near, far, torch.rand(R, S, device=dev))
             noise1 = torch.randn(R, S, device=dev) if need_noise else None
             noise1 = noise1 if args.noise_std != 0 else None
-            if self.reuse_coarse:
+            if reuse:
                 # pass 1 = FULL forward on the S coarse samples, kept for the backward: the field is a pointwise function
                 # of xyz, so pass 2 only has to evaluate the G new samples (the reference re-evaluates all S+G: same values)
                 out1 = self._buf("out1", (R * S, C))
@@ -119,10 +122,13 @@ class FusedTrainer:
             # the clamp window is the FIRST ray's (near, far) (rendering.py:133); satellite batches share one pair, so
             # callers pass it to avoid a device->host read per step
             near0, far0 = near_far if near_far is not None else (float(rays[0, 6]), float(rays[0, 7]))
-            z2, z_all, idx = Fn.guided_samples(z, w1, d1, u, near0, far0, args.std_range, use_t, tdep, tstd, u_t, trow)
+            z2, z_all, idx = Fn.guided_samples(z, w1, d1, u, near0, far0, args.std_range, use_t, tdep, tstd, u_t, trow,
+                                               merge=not gsam_only)
+            if gsam_only:
+                z_all = z2
             noise2 = torch.randn(R, S2, device=dev) if need_noise else None
             noise2 = noise2 if args.noise_std != 0 else None
-            if self.reuse_coarse:
+            if reuse:
                 out2 = self._buf("out2", (R * G, C))
                 stash2 = self._buf("stash2", (Fn.field_stash_bytes(spec, R * G),), torch.uint8)
                 Fn.field_forward_raw(spec, named, packed, out2, stash2, rays=rays, z=z2)
@@ -187,7 +193,7 @@ class FusedTrainer:
             if self.sanitize_grads and not (lambertian and self.fused_glue):
                 torch.nan_to_num_(d_out, nan=0.0, posinf=0.0, neginf=0.0)
             self.flat_grad.zero_()
-            if self.reuse_coarse:
+            if reuse:
                 d_cat = self._buf("d_cat", (R, S2, C)).scatter_(1, idx_c, d_out)             # back to [coarse | guided] order
                 d1o, d2o = d_cat[:, :S].contiguous().view(R * S, C), d_cat[:, S:].contiguous().view(R * G, C)
                 Fn.field_backward_raw(spec, named, self.grad_views, packed, out1, d1o, stash1, rays=rays, z=z, unfold=False)
