@@ -214,20 +214,33 @@ __global__ __launch_bounds__(256, 1) void regchain_sigma_kernel(const Args A) {
 #else
 #define TMARK(i)
 #endif
+  // the coordinates of a tile are loaded one tile ahead: by the time they are needed the load is ~100 chunks old and
+  // its wait costs no more than the two weight chunks in flight (vmcnt retires in order)
+  auto load_xyz = [&](int tile, float (&x)[3]) {
+    const int64_t gm = (int64_t)tile * 128 + wave * 32 + j;
+    x[0] = x[1] = x[2] = 0.f;
+    if (tile < A.n_tiles && gm < A.M) { x[0] = A.xyz[gm * 3]; x[1] = A.xyz[gm * 3 + 1]; x[2] = A.xyz[gm * 3 + 2]; }
+  };
+  float xn[3];
+  load_xyz(blockIdx.x, xn);
   for (int tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
     const int64_t gm = (int64_t)tile * 128 + wave * 32 + j;
-    float x[3] = {0.f, 0.f, 0.f};
-    if (gm < A.M) { x[0] = A.xyz[gm * 3]; x[1] = A.xyz[gm * 3 + 1]; x[2] = A.xyz[gm * 3 + 2]; }
+    const float x[3] = {xn[0], xn[1], xn[2]};
+    load_xyz(tile + gridDim.x, xn);
     bf16x8 pe[KSP], ya[KSH], yb[KSH];
+    // PE feature p = 16 s + 8 h + e in the natural order [sin x3, cos x3] per frequency (models/nerf.py:53-70): both
+    // candidates of a lane (h = 0 / 1) have compile-time frequency and component, the lane half selects
 #pragma unroll
     for (int s = 0; s < KSP; ++s) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int p = 16 * s + 8 * h + e;        // natural PE feature order: [sin x3, cos x3] per frequency (models/nerf.py:53-70)
-        const int k = p / 6, c = p - 6 * k;
-        const float xc = c % 3 == 0 ? x[0] : (c % 3 == 1 ? x[1] : x[2]);
-        const float rev = xc * (float)(1 << k) * 0.15915494309189535f + (c >= 3 ? 0.25f : 0.f);
-        pe[s][e] = (bf16)(p < 60 ? __builtin_amdgcn_sinf(rev) : 0.f);
+        float v[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int p = 16 * s + 8 * hh + e, k = p / 6, c = p % 6;
+          v[hh] = p < 60 ? __builtin_amdgcn_sinf(fmaf(x[c % 3], (float)(1 << k) * 0.15915494309189535f, c >= 3 ? 0.25f : 0.f)) : 0.f;
+        }
+        pe[s][e] = (bf16)(h ? v[1] : v[0]);
       }
     }
 #pragma unroll
