@@ -11,7 +11,7 @@ import torch
 
 from . import functions as Fn
 from . import losses
-from .rendering import shade
+from .rendering import shade, get_z_vals, inference
 
 
 class FusedTrainer:
@@ -107,6 +107,21 @@ class FusedTrainer:
             else:
                 sig = Fn.field_sigma(spec, named, packed, rays=rays, z=z).view(R, S)
                 _, _, w1, d1 = Fn.composite(z, sig, noise1, args.noise_std)
+            sun_res = None
+            if getattr(model, "sun_v", "none") == "analystic" and apply_brdf:
+                # sun-visibility pass (rendering.py:244-259), detached upstream: sigma only along the sun direction from
+                # the pass-1 surface point; same draws, in the same order, as render_rays
+                if not gsam_only:
+                    raise NotImplementedError("--sun_v analystic needs gsam_only=True (SURVEY quirk 2: the reference raises a "
+                                              "shape error with the merged S+G sample set)")
+                far_sun = d1.clone().unsqueeze(-1)
+                if abs(float(sun_d[0, 2])) > 0.00001:
+                    far_sun = abs(float(rays_d[0, 2]) / float(sun_d[0, 2])) * far_sun
+                z_sun = get_z_vals(G, dev, far_sun * 0.01, far_sun)
+                sun_rays = torch.cat([rays[:, 0:3] + rays_d * d1.unsqueeze(-1), sun_d], -1).contiguous()
+                rs, _ = inference(model, args, None, z_sun, rays_d=sun_d, mode="train", sigma_only=True, _rays=sun_rays,
+                                  _packed=packed)
+                sun_res = {"sun": rs["transparency"].unsqueeze(-1), "weights_sc": rs["weights"]}
             # depth-guided resampling + merge
             u = torch.rand(R, G, device=dev)
             use_t = tdep = tstd = u_t = trow = None
@@ -142,7 +157,8 @@ class FusedTrainer:
                 out3 = out.view(R, S2, C)
             alphas, trans, weights, depth, acc = Fn.composite_forward_raw(z_all, out3, noise2, args.noise_std)
         reg = self.reg if regularisers else {}
-        lambertian = (len(spec.heads) == 1 and not spec.normal_an and not spec.normal_lr and reg.get("hs", 0) <= 0)
+        lambertian = (len(spec.heads) == 1 and not spec.normal_an and not spec.normal_lr and reg.get("hs", 0) <= 0
+                      and sun_res is None)
         n_leaf = {}                                   # channel offset -> per-sample normal leaf
         grads = ()
         if lambertian and self.fused_glue:
@@ -159,7 +175,7 @@ class FusedTrainer:
             # reads them)
             acc_l, depth_l, weights_l = acc.requires_grad_(True), depth.requires_grad_(True), weights.requires_grad_(True)
             res, _ = shade(model, args, spec, out3, z_all, alphas, trans, weights_l, depth_l, acc_l, rays_d, sun_d, apply_brdf,
-                           cos_irra_on)
+                           cos_irra_on, sun_res=sun_res)
             loss = losses.snerf_loss(res["rgb"], rgbs, self.lambda_rgb)
             if self.ds_lambda > 0 and depth_loss_on and valid_depth is not None:
                 loss = loss + losses.depth_loss(z_all, depth_l, weights_l, depths[:, 0], depths[:, 1], valid_depth, depth_std,

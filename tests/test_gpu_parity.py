@@ -873,6 +873,44 @@ def test_fused_trainer_gsam_only_matches_autograd_path(name):
         assert float((tr.grad_views[k] - v.grad).abs().max()) <= 2e-4 * scale + 1e-9, f"grad {k}"
 
 
+@pytest.mark.parametrize("name", ["rpv111_nlr", "hapke_bct"])
+def test_fused_trainer_sun_visibility_matches_autograd_path(name):
+    """--sun_v analystic inside the fused step (sun pass rendering.py:244-259 + per-sample irradiance spsbrdfnerf.py:259-273),
+    gsam_only=True, against autograd through render_rays on the same draws."""
+    from brdf_nerf_amd import render_rays, losses
+    from brdf_nerf_amd.trainer import FusedTrainer
+    if name not in CONFIGS:
+        pytest.skip(f"no config {name}")
+    cfg = mini(**dict(CONFIGS[name], sun_v="analystic"))
+    args = make_args(cfg)
+    g = torch.Generator().manual_seed(13)
+    R, S, G = 64, cfg.n_samples, cfg.guided_samples
+    rays = torch.from_numpy(load_golden("render_lambert_train")["rays"])[:R // 2].repeat(2, 1).contiguous().to(DEV)
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    draws = [torch.rand(R, S, generator=g), torch.randn(R, S, generator=g), torch.rand(R, G, generator=g),
+             torch.randn(R, G, generator=g), torch.rand(R, G, generator=g), torch.randn(R, G, generator=g)]
+    flags = dict(apply_brdf=True, apply_theta=True, cos_irra_on=False)
+    ma = build_model(cfg, 5)
+    with Replay(list(draws)) as rp:
+        res, _ = render_rays({"coarse": ma}, args, rays, None, mode="train", gsam_only=True, **flags)
+        assert rp.draws == []
+    loss_a = losses.snerf_loss(res["rgb_coarse"], rgbs)
+    loss_a.backward()
+    mb = build_model(cfg, 5)
+    tr = FusedTrainer(mb, args, lr=5e-4)
+    with Replay(list(draws)) as rp:
+        loss_b, _ = tr.step(rays, rgbs, gsam_only=True, **flags)
+        assert rp.draws == []
+    with pytest.raises(NotImplementedError):
+        tr.step(rays, rgbs, gsam_only=False, **flags)
+    assert_close(loss_b, loss_a.detach(), 1e-5, 1e-7, "loss")
+    for k, v in ma.named_parameters():
+        if v.grad is None:
+            continue
+        scale = float(v.grad.abs().max())
+        assert float((tr.grad_views[k] - v.grad).abs().max()) <= 2e-4 * scale + 1e-9, f"grad {k}"
+
+
 @pytest.mark.parametrize("name", ["lambert", "rpv111_nan"])
 def test_trainer_coarse_reuse_equals_full_reevaluation(name):
     """reuse_coarse=True (pass-1 evaluation kept, pass 2 only on the guided samples) must give the reference pipeline's
