@@ -106,13 +106,31 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       }
     }
     __syncthreads();
+    // y_l is stashed row-major (for the weight-gradient GEMMs): stage the tile through ACT, which the GEMM has finished
+    // reading, with coalesced 16-byte loads, instead of 8-byte reads scattered over 32 rows per wave instruction.  Each
+    // lane then reads the values at exactly the positions it overwrites with abar_{l+1}.
+    {
+      constexpr int EPC = 16 / sizeof(T);
+      const int cpr = F / EPC, rpp = (WAVES * 64) / cpr, row0 = tid / cpr, cc = (tid % cpr) * EPC;
+      const int passes = BM / rpp;
+      const T *Yg = (const T *)(A.stash + A.sl.Y[l]) + (size_t)m0 * F;
+      for (int i0 = 0; i0 < passes; i0 += 8) {
+        u32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i0 + i < passes) v[i] = stash_load((const u32x4 *)(Yg + (size_t)(row0 + (i0 + i) * rpp) * F + cc));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i0 + i < passes) *(u32x4 *)(ACT + (size_t)(row0 + (i0 + i) * rpp) * LDA + cc) = v[i];
+      }
+    }
+    __syncthreads();
     if (wave_on) {
       const float w0 = (l == 0) ? 30.f : 1.f;
       const float unscale = A.prescaled ? 6.283185307179586f / w0 : 1.f;
       const float e2 = g.act == BN_ACT_SIN ? -w0 * w0 : 0.f;      // dD/dz = -w0^2 sin(w0 z) = -w0^2 y (0 for ReLU)
       const T *Ds = (const T *)(A.stash + A.sl.D[l]) + (size_t)tile * BM * F;
       const T *As = (const T *)(A.stash + A.sl.adj_a[l]) + (size_t)tile * BM * F;
-      const T *Ys = (const T *)(A.stash + A.sl.Y[l]) + (size_t)m0 * F;
       T *Zs = (T *)(A.stash + A.sl.adj_zbar[l]) + (size_t)tile * BM * F;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
@@ -125,7 +143,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
             float dv[8], av[8], zb[8], db[8];
             ld8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dv);
             ld8(As + native_off8<MT, NT>(wave, nt, mt, gp, lane), av);
-            const vec4 ya = *(const vec4 *)(Ys + (size_t)m * F + n0), yb = *(const vec4 *)(Ys + (size_t)m * F + n0 + 8);
+            const vec4 ya = *(const vec4 *)(ACT + (size_t)m * LDA + n0), yb = *(const vec4 *)(ACT + (size_t)m * LDA + n0 + 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) db[e] = acc[nt][mt][8 * gp + e] * unscale;
 #pragma unroll
