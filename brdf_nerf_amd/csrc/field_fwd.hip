@@ -273,7 +273,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
           pp_wait(WR + 0, 4 * l);                       // half 0 of Y_{l-1} is written
           if (grp == 1) pp_wait(RD + 0, 4 * l);         // group 0 is done with its phase 1 of this layer: the lag
           BN_PH(12)
+#ifdef BN_AB_NO_Y_COPY        // ablation (results wrong): the forward without the row-major Y copies riding in the GEMMs
+          if (false) {
+#else
           if (keep && grp == 0) {                       // a group's half of the stash copy rides in the phase that reads it
+#endif
             TileCopyHalf<T> ycopy(ACT, LDA, ydst, F, 0, F / 2, tid & 255);
             gemm_range<T, MT, NT>(acc, w_h, KSF, 0, half, ACT, LDA, lane, ycopy);
           } else {
@@ -283,7 +287,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
           pp_signal(RD + 0 + grp, lane);
           pp_wait(WR + 1, 4 * l);                       // half 1
           BN_PH(13)
+#ifdef BN_AB_NO_Y_COPY
+          if (false) {
+#else
           if (keep && grp == 1) {
+#endif
             TileCopyHalf<T> ycopy(ACT, LDA, ydst, F, F / 2, F / 2, tid & 255);
             gemm_range<T, MT, NT>(acc, w_h, KSF, half, half, ACT, LDA, lane, ycopy);
           } else {
@@ -346,7 +354,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
               const int m = mt * 32 + r;
               *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), y[0], y[1], y[2], y[3]);
               *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), y[4], y[5], y[6], y[7]);
+#ifndef BN_AB_NO_D_STASH     // ablation (results wrong): the forward without its D stash stores
               if (keep) st8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dd);
+#endif
             }
           }
       };
