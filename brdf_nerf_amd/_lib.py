@@ -79,6 +79,7 @@ _SIGS = {
     "bn_brdf_microfacet_backward": (C.c_int, [fptr] * 5 + [C.c_float, fptr, C.c_int64] + [fptr] * 4),
     "bn_adam_step": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_int32, C.c_float, fptr]),
+    "bn_count_nonfinite": (C.c_int, [fptr, C.c_int64, fptr, fptr]),
     "bn_prof_enable": (C.c_int, [C.c_int]),
     "bn_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
 }

@@ -44,3 +44,27 @@ extern "C" int bn_adam_step(float *param, const float *grad, float *exp_avg, flo
   BN_LAUNCH_CHECK("adam_step");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------ non-finite counter (debug)
+__global__ __launch_bounds__(256) void count_nonfinite_kernel(const float *__restrict__ x, int64_t n, unsigned long long *counts) {
+  unsigned nan = 0, inf = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    nan += v != v;
+    inf += (v - v != 0.f) && (v == v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { nan += __shfl_xor(nan, o); inf += __shfl_xor(inf, o); }
+  if ((threadIdx.x & 63) == 0) {
+    if (nan) atomicAdd(counts, (unsigned long long)nan);
+    if (inf) atomicAdd(counts + 1, (unsigned long long)inf);
+  }
+}
+
+extern "C" int bn_count_nonfinite(const float *x, int64_t n, unsigned long long *counts, void *stream) {
+  BN_REQUIRE(x && counts && n > 0, "count_nonfinite: bad arguments");
+  const int64_t blocks = ceil_div64(n, 256 * 8);
+  count_nonfinite_kernel<<<dim3((unsigned)(blocks < 4096 ? blocks : 4096)), 256, 0, (hipStream_t)stream>>>(x, n, counts);
+  BN_LAUNCH_CHECK("count_nonfinite");
+  return 0;
+}

@@ -489,3 +489,15 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), ep
     L.check(L.lib().bn_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr), float(betas[0]),
                                  float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale), _stream()),
             "bn_adam_step")
+
+
+# ----------------------------------------------------------------------------------------- debug
+def count_nonfinite(x, counts=None):
+    """check_nan without the host round trip (train_utils.py:14-25): adds the number of NaN / Inf elements of `x` to
+    counts[0] / counts[1] (int64 device tensor, created zeroed when None) on the current stream and returns it."""
+    x = _f32(x)
+    if counts is None:
+        counts = torch.zeros(2, dtype=torch.int64, device=x.device)
+    if x.numel():
+        L.check(L.lib().bn_count_nonfinite(_p(x), x.numel(), _p(counts), _stream()), "bn_count_nonfinite")
+    return counts

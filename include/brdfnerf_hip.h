@@ -223,6 +223,14 @@ int bn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
                  void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Debug hook replacing the reference's check_nan / checknan / check_nan_parms (train_utils.py:14-78,
+ * models/spsbrdfnerf.py:32-48,419-424), which copy a flag to the host and print after every call:
+ * counts[0] += number of NaN elements of x[0..n), counts[1] += number of +-Inf elements, on the
+ * stream, without a device->host synchronisation; the caller reads the two counters when it wants.
+ * ------------------------------------------------------------------------------------------- */
+int bn_count_nonfinite(const float *x, int64_t n, unsigned long long *counts, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart; the reference only has Lightning's wall-clock
  * "simple" profiler, main.py:731).  When enabled, every kernel launch of this library is
  * bracketed by HIP events on the caller's stream; bn_prof_collect() synchronises them, adds the

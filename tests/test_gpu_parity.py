@@ -1172,3 +1172,14 @@ def test_bf16_training_psnr_tracks_fp32():
         out[mode] = float(losses.psnr(rgb, b["rgbs"]))
     diag(f"PSNR after 40 steps: fp32 {out['fp32']:.4f} dB, bf16 {out['bf16']:.4f} dB")
     assert abs(out["fp32"] - out["bf16"]) <= 0.05, out
+
+
+def test_count_nonfinite_hook():
+    """Sync-free replacement of check_nan (train_utils.py:14-25): NaN and Inf counters accumulate on the device."""
+    from brdf_nerf_amd import functions as Fn
+    x = torch.randn(100003, device=DEV)
+    x[5] = float("nan"); x[77777] = float("nan"); x[9] = float("inf"); x[100002] = -float("inf"); x[50000] = float("inf")
+    c = Fn.count_nonfinite(x)
+    c = Fn.count_nonfinite(torch.ones(7, device=DEV), c)
+    assert c.tolist() == [2, 3]
+    assert Fn.count_nonfinite(torch.zeros(0, device=DEV)).tolist() == [0, 0]
