@@ -1183,3 +1183,40 @@ def test_count_nonfinite_hook():
     c = Fn.count_nonfinite(torch.ones(7, device=DEV), c)
     assert c.tolist() == [2, 3]
     assert Fn.count_nonfinite(torch.zeros(0, device=DEV)).tolist() == [0, 0]
+
+
+def test_bad_arguments_come_back_as_errors_not_faults():
+    """The C ABI never launches on arguments it cannot serve (SURVEY.md section 8b error convention): empty inputs, sample
+    counts beyond the kernels' limits and missing buffers return a status with a message; the largest supported ray
+    (S = 512 samples) still composites correctly."""
+    from brdf_nerf_amd import functions as Fn
+    near, far = torch.zeros(0, 1, device=DEV), torch.ones(0, 1, device=DEV)
+    with pytest.raises(RuntimeError, match="stratified_z"):
+        Fn.stratified_z(near, far, torch.rand(0, 16, device=DEV))                      # no rays
+    with pytest.raises(RuntimeError, match="stratified_z"):
+        Fn.stratified_z(torch.zeros(4, 1, device=DEV), torch.ones(4, 1, device=DEV), torch.rand(4, 1, device=DEV))   # S = 1
+    z = torch.sort(torch.rand(3, 513, device=DEV), -1)[0]
+    with pytest.raises(RuntimeError, match="composite"):
+        Fn.composite_forward_raw(z, torch.rand(3, 513, 4, device=DEV))                # S beyond 512
+    with pytest.raises(RuntimeError, match="composite"):
+        Fn.composite_forward_raw(z[:, :8].contiguous(), torch.rand(3, 8, 17, device=DEV))   # more channels than supported
+    z16 = torch.sort(torch.rand(5, 16, device=DEV), -1)[0]
+    w = torch.rand(5, 16, device=DEV)
+    with pytest.raises(RuntimeError, match="guided_samples"):
+        Fn.guided_samples(z16, w, (w * z16).sum(-1), torch.rand(5, 2, device=DEV), 0.0, 1.0, 3.0)      # G < 3
+    with pytest.raises(RuntimeError, match="guided_samples"):
+        Fn.guided_samples(z16, w, (w * z16).sum(-1), torch.rand(5, 300, device=DEV), 0.0, 1.0, 3.0)    # G beyond 256
+    cfg = mini()
+    model = build_model(cfg, 3)
+    spec = model.spec(False, False, False)
+    with pytest.raises(RuntimeError, match="field"):
+        Fn.field_sigma(spec, model.named(), model.repack(spec), xyz=torch.zeros(0, 3, device=DEV))     # no points
+    # the largest ray the compositing kernels take
+    g = torch.Generator().manual_seed(5)
+    zc = torch.sort(torch.rand(6, 512, generator=g) * 2, -1)[0]
+    out = torch.randn(6, 512, 4, generator=g)
+    a, T, wr, d = ORD.composite(zc, out[..., 3], None, 0.0)
+    _, _, w2, d2, acc2 = Fn.composite_forward_raw(zc.to(DEV), out.to(DEV))
+    assert_close(w2, wr, 1e-5, 1e-7, "w S=512")
+    assert_close(d2, d, 1e-5, 1e-6, "depth S=512")
+    assert_close(acc2, (wr.unsqueeze(-1) * out).sum(-2), 1e-4, 1e-5, "acc S=512")
