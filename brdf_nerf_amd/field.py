@@ -8,7 +8,6 @@ Checkpoint contract: `fc_net.{0,2,..}.{weight,bias}`, `sig
 """
 import math
 
-import numpy as np
 import torch
 from torch import nn
 

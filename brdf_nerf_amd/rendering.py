@@ -7,7 +7,6 @@ torch.randn (R,S+G)), so a harness that monkeypatches torch.rand/rand_like/randn
 reference's draws.  Documented differences: the reference's print/`check_nan` host syncs are not
 reproduced; pass 1 runs without autograd (its result is detached upstream, rendering.py:262).
 """
-import numpy as np
 import torch
 
 from . import functions as Fn

@@ -5,7 +5,6 @@ All thresholds are fractions of --max_train_steps, rounded as the reference roun
 number of GPUs per optimisation step (main.py:196, `self.train_steps += self.args.gpu_id`).  Comparisons are the
 reference's (strict `>` for switching stages on, `<` for dropping the depth loss).
 """
-import math
 
 
 def _round_half_even(x):

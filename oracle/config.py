@@ -5,7 +5,7 @@ Parameter names/shapes follow the reference's state_dict contract
 Init ranges follow models/nerf.py:9-21 (Siren inits) and torch.nn.Linear's
 default (U(+-1/sqrt(fan_in)) for weight and bias).
 """
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 import math
 import numpy as np
 

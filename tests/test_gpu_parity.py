@@ -10,7 +10,7 @@ import torch
 
 from conftest import load_golden, tparams, replay_list, assert_close
 from oracle.config import FieldConfig
-from oracle import field as OF, render as ORD, brdf as OB
+from oracle import field as OF, render as ORD
 
 pytestmark = pytest.mark.gpu
 
