@@ -41,7 +41,7 @@ __device__ __forceinline__ void head_y_dy(int kind, int nout, const float *o, co
 }
 
 template <typename T, int MT, int NTW>
-__device__ __forceinline__ void bwd_head_dG(const BwdArgs &A, int p, T *ACT, const float *DPH, int64_t m0, int64_t tile) {
+__device__ __forceinline__ void bwd_head_dG(const BwdArgs &A, int p, T *ACT, const float *DPH, int64_t /*m0*/, int64_t tile) {
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
   const FieldGeom &g = A.g;
@@ -450,7 +450,7 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   // is multiplied - every global load has a whole stage of MFMAs to arrive, every LDS buffer one barrier between
   // its last read and its next write.
   u32x4 ra[NC], rb[NC];
-  int64_t m_dbg = mb;   // diagnostic variants only
+  [[maybe_unused]] int64_t m_dbg = mb;   // diagnostic variants only
   auto gload = [&](int64_t m) {
     if (m >= me) return;
 #ifdef W2_SKIP_GLOAD   // diagnostic variant (profiles/ab_bench.sh): compute side only

@@ -53,7 +53,6 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
                                           , unsigned long long (&ph_)[BN_PH_N], unsigned long long &pt_
 #endif
 ) {
-  typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
   constexpr bool FAST = Elem<T>::kFastMath;
   const FieldGeom &g = A.g;
@@ -64,7 +63,6 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
   const int N = g.pass_N[p];
   const int pc0 = wave * 32 * NTW;                // first column of this wave in the pass
   const bool on = pc0 < N;
-  const int hl = pc0 / g.H2;                      // head inside the pass (0/1)
   // PRM[0][n] = b1 (pre-scaled for the fast sine), PRM[1 + c][n] = w2[c] (0 beyond the head's outputs), n < N
   for (int n = tid; n < N; n += WAVES * 64) {
     const int hn = n / g.H2, nl = n - hn * g.H2, hdn = 2 * p + hn;
