@@ -15,6 +15,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def built_library():
+    """The C-ABI library is built in-tree (git-ignored): a fresh checkout compiles it once here (hipcc cross-compiles gfx950
+    without a GPU, a few minutes); an up-to-date build returns at once.  The product path itself never builds or falls back."""
+    from brdf_nerf_amd import build
+    build.build()
+
+
 def pytest_collection_modifyitems(config, items):
     if torch.cuda.is_available():
         return
