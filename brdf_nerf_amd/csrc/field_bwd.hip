@@ -402,6 +402,7 @@ template <typename T> __global__ __launch_bounds__(256) void wgrad_kernel(const 
 // LDS (one barrier per stage; the next stage's global loads are in flight during the MFMAs), transposing
 // ds_read_b64_tr_b16 fragment reads.  Each wave owns 64(n) x 128(k): 2 x 4 accumulator tiles.  Blocks that share an
 // (job, point-split) - i.e. the same A rows - get consecutive ids on ONE XCD so the second read of a tile hits L2.
+__device__ __attribute__((aligned(16))) bf16 w2_zeros[8];   // zero-initialised
 #define W2_LD (256 + 32)       // 576-byte rows: the 4 rows of a tr-read block fall on disjoint bank groups
 #define W2_BK 64               // points per stage (one barrier per stage; 2 stages x 2 operands = 144 KB of LDS)
 #define W2_STAGE (W2_BK * W2_LD)
@@ -452,15 +453,19 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   u32x4 ra[NC], rb[NC];
   [[maybe_unused]] int64_t m_dbg = mb;   // diagnostic variants only
   auto gload = [&](int64_t m) {
-    if (m >= me) return;
+    m = m < me ? m : me - W2_BK;   // the two prefetches past the end re-read the last stage: no branch in the stage loop
 #ifdef W2_SKIP_GLOAD   // diagnostic variant (profiles/ab_bench.sh): compute side only
     if (m > mb + W2_BK) return;
 #endif
+    // columns beyond the operand's extent read one 16-byte block of zeros with row stride 0: the stage loop has no branch
+    // (an exec-masked load per chunk split its basic block and cost 6 % of the kernel: profiles/r01_ablation.txt)
+    const bf16 *pa = a_ok ? gA + cc : w2_zeros, *pb = b_ok ? gB + cc : w2_zeros;
+    const int64_t sa = a_ok ? J.lda : 0, sb = b_ok ? J.ldb : 0;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int64_t row = m + row0 + RPP * c;
-      ra[c] = a_ok ? *(const u32x4 *)(gA + row * J.lda + cc) : u32x4{0, 0, 0, 0};
-      rb[c] = b_ok ? *(const u32x4 *)(gB + row * J.ldb + cc) : u32x4{0, 0, 0, 0};
+      ra[c] = *(const u32x4 *)(pa + row * sa);
+      rb[c] = *(const u32x4 *)(pb + row * sb);
     }
   };
   auto sstore = [&](int buf) {
@@ -515,7 +520,7 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
 #pragma unroll
         for (int b = 0; b < NBV; ++b) mma32(acc[a][b], fa[cur][a], fb[cur][b]);
 #endif
-      if (do_bias) {
+      {   // every wave adds its A fragments up, only the owners of the bias columns store the sums: no branch in the k-loop
 #pragma unroll
         for (int a = 0; a < W2_RA; ++a)
 #pragma unroll
@@ -536,7 +541,7 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
 #endif
     __syncthreads();
     WG_PH(3)
-    if (m + W2_BK < me) sstore(buf ^ 1);
+    if (m + W2_BK < me) sstore(buf ^ 1);   // (an unconditional store of the re-read last stage measured 5 % slower)
     gload(m + 2 * W2_BK);
     WG_PH(2)
     compute(buf);
