@@ -632,7 +632,7 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
     const int lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
     const int mt_n = J.bm / 32, ncb = J.K / 32;
     const T *X = (const T *)J.X;
-    float bs[4] = {0, 0, 0, 0};
+    float bs[4] = {0, 0, 0, 0}, bs0[4] = {0, 0, 0, 0};
     for (int cb = wv; cb < ncb; cb += 4) {
       const int cbp = J.x_col0 / 32 + cb, wave_n = cbp / J.ntw, nt = cbp % J.ntw;
       float s[2][4][8];
@@ -642,17 +642,18 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
         for (int c = 0; c < 4; ++c)
 #pragma unroll
           for (int e = 0; e < 8; ++e) s[gp][c][e] = 0.f;
+      // no branch inside the point loop: all four dpre columns are read and summed (columns beyond nc hold the next head's
+      // values or row padding; their sums are never stored), every lane keeps the bias sums, one lane set stores them
+#pragma unroll 2
       for (int64_t m0 = mb; m0 < me; m0 += 32) {
         const int64_t tile = m0 / J.bm;
         const int mt = (int)(m0 % J.bm) / 32;
         const float *dp = J.dpre + (m0 + r) * J.ldp + J.p_col0;
         float d[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) d[c] = c < J.nc ? dp[c] : 0.f;
-        if (cb == 0 && h == 0) {
+        for (int c = 0; c < 4; ++c) d[c] = dp[c];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) bs[c] += d[c];
-        }
+        for (int c = 0; c < 4; ++c) bs[c] += d[c];
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
           float x[8];
@@ -672,11 +673,17 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
             for (int e = 0; e < 8; ++e)
               atomicAdd(&red[c * 512 + cb * 32 + 16 * gp + 4 * h + (e & 3) + 8 * (e >> 2)], s[gp][c][e]);   // LDS, 32-way
         }
+      if (cb == 0) {   // the bias gradient is the dpre column sum: taken from the pass over the head's first column block
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bs0[c] = bs[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bs[c] = 0.f;
     }
     if (wv == 0 && h == 0) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if (c < J.nc) atomicAdd(&red[4 * 512 + c], bs[c]);
+        if (c < J.nc) atomicAdd(&red[4 * 512 + c], bs0[c]);
     }
   } else {
   const T *X = (const T *)J.X + J.x_col0;
@@ -690,18 +697,18 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[c][e] = 0.f;
   if (rg < nrg) {
-    for (int64_t m = mb + rg; m < me; m += nrg) {
+#pragma unroll 2
+    for (int64_t m = mb + rg; m < me; m += nrg) {   // branch-free like the native form above
       float x[8];
       ld8(X + m * J.ldx + cg * 8, x);
       const float *dp = J.dpre + m * J.ldp + J.p_col0;
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (c < J.nc) {
-          const float d = dp[c];
+      for (int c = 0; c < 4; ++c) {
+        const float d = dp[c];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) s[c][e] += d * x[e];
-          if (cg == 0) bs[c] += d;
-        }
+        for (int e = 0; e < 8; ++e) s[c][e] += d * x[e];
+        bs[c] += d;
+      }
     }
   }
   // row groups meet in LDS (nrg-way LDS atomics)
