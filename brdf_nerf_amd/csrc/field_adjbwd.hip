@@ -114,14 +114,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       const int cpr = F / EPC, rpp = (WAVES * 64) / cpr, row0 = tid / cpr, cc = (tid % cpr) * EPC;
       const int passes = BM / rpp;
       const T *Yg = (const T *)(A.stash + A.sl.Y[l]) + (size_t)m0 * F;
-      for (int i0 = 0; i0 < passes; i0 += 8) {
-        u32x4 v[8];
+      if ((passes & 7) == 0) {           // F >= 256: eight loads in flight per thread, no branch around them
+        for (int i0 = 0; i0 < passes; i0 += 8) {
+          u32x4 v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (i0 + i < passes) v[i] = stash_load((const u32x4 *)(Yg + (size_t)(row0 + (i0 + i) * rpp) * F + cc));
+          for (int i = 0; i < 8; ++i) v[i] = stash_load((const u32x4 *)(Yg + (size_t)(row0 + (i0 + i) * rpp) * F + cc));
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (i0 + i < passes) *(u32x4 *)(ACT + (size_t)(row0 + (i0 + i) * rpp) * LDA + cc) = v[i];
+          for (int i = 0; i < 8; ++i) *(u32x4 *)(ACT + (size_t)(row0 + (i0 + i) * rpp) * LDA + cc) = v[i];
+        }
+      } else {
+        for (int i = 0; i < passes; ++i)
+          *(u32x4 *)(ACT + (size_t)(row0 + i * rpp) * LDA + cc) = stash_load((const u32x4 *)(Yg + (size_t)(row0 + i * rpp) * F + cc));
       }
     }
     __syncthreads();
