@@ -887,7 +887,10 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     for (int c = 0; c < j.nc; ++c) { j.out[c] = G->head_w2[hd] + (size_t)c * g.H2; j.bias[c] = G->head_b2[hd] ? G->head_b2[hd] + c : nullptr; }
   }
   if (s.n_jobs > 0) {
-    int64_t smpb = ceil_div64(ceil_div64(sl.Mpad, 512), BM) * BM;   // whole tiles per block (native jobs walk tile images)
+#ifndef SKINNY_SPLITS
+#define SKINNY_SPLITS 256   // 512: 0.129 ms, 256: 0.102 ms, 128: 0.169 ms per launch (the per-block LDS + global atomics tail vs parallelism)
+#endif
+    int64_t smpb = ceil_div64(ceil_div64(sl.Mpad, SKINNY_SPLITS), BM) * BM;   // whole tiles per block (native jobs walk tile images)
     s.m_per_block = (int)smpb;
     dim3 grid((unsigned)ceil_div64(sl.Mpad, smpb), (unsigned)s.n_jobs);
     BnProfScope prof_(BN_K_SKINNY, st);
