@@ -818,7 +818,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
       w.tile0[j + 1] = w.tile0[j] + ((w.job[j].N + 255) / 256) * ((w.job[j].K + 255) / 256);
     const int tiles = w.tile0[w.n_jobs];
 #ifndef W2_BLOCKS
-#define W2_BLOCKS 1024
+#define W2_BLOCKS 512   // tiles x point splits <= two rounds of the 256 CUs (one 144 KB workgroup per CU): 1024 -> 1.295 ms, 512 -> 1.253, 256 -> 1.290
 #endif
     int64_t n_split = W2_BLOCKS / tiles;
     if (n_split < 1) n_split = 1;
