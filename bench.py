@@ -2,21 +2,32 @@
 """Headline benchmark: spsbrdf-nerf TRAIN rays/s on MI355X (BASELINE.json metric).
 
 One "step" = one full training step on a batch of R rays per GPU:
-  render_rays (pass 1 sigma-only on S samples, depth-guided resampling, pass 2 on S+G samples)
+  render_rays (pass 1 on S stratified samples, depth-guided resampling, pass 2 on the merged S+G samples)
   + SNerfLoss + DepthLoss (ds_lambda=10, README stage 1) + backward + [RCCL grad all-reduce] + Adam.
 Workload at N=1: BASELINE config 2 - Lambertian pretrain, 4096 rays x 64 samples (+64 guided), F=512, 8 Siren layers,
 PE(10), bf16 MFMA, synthetic satellite-shaped rays, random-init weights (seed 0).
-N>1: weak scaling, 4096 rays per GPU, one process per GPU, gradients all-reduced over RCCL.
+N>1: one process per GPU, gradients all-reduced over RCCL; `--scaling weak` (default) keeps 4096 rays per GPU,
+`--scaling strong` splits ONE 4096-ray batch N ways (north_star's "4096-ray/64-sample batches at 8 GPUs").
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W        # N > 1: this process spawns the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (HIP-event timed inside the timed region);
-`cpu_baseline` times the CPU oracle (a port of the reference's PyTorch path) on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0).  Timing protocol: W warm-up steps, then untimed "settling" steps until the chip has been
+under this load for >= 1.5 s (DVFS settles over seconds), then EXACTLY K steps between barrier + synchronize pairs with
+no instrumentation inside; the per-kernel HIP-event times come from a SEPARATE pass after the timed one.  `roofline`
+prices the kernel with the largest share of the step, as a fraction of the dense bf16/fp16 MFMA peak both by the
+reference network's algorithmic FLOPs and by the FLOPs the build executes (the linear feats layer is folded into the
+heads); `traffic` / `mfma_busy` come from the committed rocprofv3 PMC pass of the SAME kernel sources
+(profiles/r02_pmc.json, keyed by a hash of csrc/), null when the sources have changed since.  `cpu_baseline` times the
+CPU oracle (a port of the reference's PyTorch path) on a bounded sample of the same workload.
 """
 import argparse
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,25 +36,35 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_MFMA16_TFLOPS = 2500.0   # MI355X dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3       # fp32-input MFMA
-# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.txt); valid for the
-# default workload only (lambert, 4096 rays, 64+64 samples, bf16), otherwise `traffic` is null
-# HBM-side bytes per launch of the default workload (262,144 points per launch, two launches per step), from rocprofv3
-# PMC passes over profiles/prof_step.py: 2 x FETCH_SIZE + WRITE_SIZE (profiles/r01_pmc_traffic.txt)
-PMC_TRAFFIC_BYTES = {"field_fwd_full": 4.87e9, "field_bwd_chain": 4.75e9, "wgrad": 6.63e9}
+PEAK_HBM_GBS = 8000.0         # HBM3E spec (6.29 TB/s measured copy rate, MI355X_MICROARCH.md)
+METRIC = "train rays/sec (+ MFMA% of roofline), spsbrdf-nerf 64 samples/ray, 1/2/4/8 MI355X"
+
+# name -> (model flags, step flags, BASELINE config it belongs to)
+_BRDF_ON = dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)
+CONFIG_FLAGS = {
+    "lambert": (dict(), dict(apply_brdf=False, apply_theta=False, cos_irra_on=False), 2),
+    "rpv_nan": (dict(funcM=1, funcF=1, funcH=1, normal="analystic"), _BRDF_ON, 3),
+    "rpv_nlr": (dict(funcM=1, funcF=1, funcH=1, normal="learned"), _BRDF_ON, 3),
+    "hapke": (dict(b=1, c=1, theta=1, normal="analystic"), _BRDF_ON, 5),
+    "microfacet": (dict(roughness=True, normal="analystic"), _BRDF_ON, 5),
+}
 
 
-def flops_per_point(F=512, P=60, L=8, n_heads=1):
-    """Algorithmic FLOPs (2*MAC) per sample point, by kernel."""
+def flops_per_point(F=512, P=60, L=8, n_heads=1, executed=False):
+    """FLOPs (2*MAC) per sample point, by kernel.  executed=False: the reference network's algorithmic count (DESIGN.md
+    section 3).  executed=True: what the build runs - the linear F x F feats layer is folded into
+    the heads' first layers, so one F x F product less in forward, backward chain and weight gradient."""
     H2 = F // 2
+    fold = 0 if not executed else 2 * F * F
     trunk = 2 * (P * F + (L - 2) * F * F + (F + P) * F)
     heads1 = n_heads * 2 * F * H2
     heads2 = 2 * 3 * H2 + (n_heads - 1) * 2 * H2          # rgb (3 outputs) + 1-wide BRDF heads
     fwd_sigma = trunk + 2 * F
-    fwd_full = trunk + 2 * F + 2 * F * F + heads1 + heads2
-    bwd_chain = heads1 + heads2 + 2 * F * F + 2 * F + (L - 1) * 2 * F * F     # dX products (h inputs only)
-    wgrad = trunk + 2 * F * F + heads1
+    fwd_full = trunk + 2 * F + 2 * F * F + heads1 + heads2 - fold
+    bwd_chain = heads1 + heads2 + 2 * F * F + 2 * F + (L - 1) * 2 * F * F - fold     # dX products (h inputs only)
+    wgrad = trunk + 2 * F * F + heads1 - fold
     skinny = 2 * F + heads2
     return dict(field_fwd_sigma=fwd_sigma, field_fwd_full=fwd_full, field_bwd_chain=bwd_chain, wgrad=wgrad, skinny_wgrad=skinny)
 
@@ -75,8 +96,10 @@ def synthetic_batch(R, seed, device):
     return {k: v.to(device) for k, v in batch.items()}
 
 
-def cpu_baseline(args, seconds_budget=25.0):
-    """Time the CPU oracle (port of the reference's PyTorch path) on a bounded sample: same network, same S/G, fewer rays."""
+def cpu_baseline(args, rays=1024, seconds_budget=30.0):
+    """Time the CPU oracle (port of the reference's PyTorch path) on a bounded sample: same network, same S/G, `rays` rays
+    per step.  profiles/r02_cpu_cross_timing.txt holds the oracle-vs-imported-reference timing of the same step taken in
+    the build container: the stand-in is within a few per cent of the reference itself."""
     from oracle.config import FieldConfig
     from oracle import render as ORD, losses as OL
     cores = os.cpu_count() or 1
@@ -89,8 +112,7 @@ def cpu_baseline(args, seconds_budget=25.0):
     cfg = FieldConfig(feat=args.fc_feat, layers=args.fc_layers, n_samples=args.n_samples, guided_samples=args.guided_samples)
     params = {k: torch.from_numpy(v).requires_grad_(True) for k, v in cfg.make_params(0).items()}
     opt = torch.optim.Adam(list(params.values()), lr=args.lr)
-    R = 512
-    b = synthetic_batch(R, 123, "cpu")
+    b = synthetic_batch(rays, 123, "cpu")
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -107,152 +129,281 @@ def cpu_baseline(args, seconds_budget=25.0):
     while True:
         step()
         n += 1
-        if time.perf_counter() - t0 > seconds_budget * 0.6 or n >= 8:
+        if time.perf_counter() - t0 > seconds_budget * 0.6 or n >= 6:
             break
     dt = time.perf_counter() - t0
-    return dict(value=R * n / dt, unit="rays/s", cores=cores, kind="port",
-                sample=f"{n} training steps of {R} rays x {args.n_samples}+{args.guided_samples} samples (same network, fp32, "
-                       f"torch CPU oracle, {cores} threads) after 1 warm-up step")
+    return dict(value=rays * n / dt, unit="rays/s", cores=cores, kind="port",
+                sample=f"{n} training steps of {rays} rays x {args.n_samples}+{args.guided_samples} samples (same network, fp32, "
+                       f"torch CPU oracle, {cores} threads) after 1 warm-up step",
+                cross_timing="profiles/r02_cpu_cross_timing.txt (oracle vs the imported reference, build container)")
 
 
-def main():
+def source_hash():
+    """sha256 over the kernel sources the library is built from (csrc/ + the C ABI header): the key under which a PMC pass
+    is valid for the current kernels."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "brdf_nerf_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".cpp")))
+    for f in files + [os.path.join(ROOT, "include", "brdfnerf_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(config, dtype):
+    """Per-kernel counters of the committed rocprofv3 PMC passes (profiles/pmc_collect.sh -> profiles/r02_pmc.json), or
+    ({}, reason) when there is none for this workload or the kernel sources have changed since it was taken."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    if not os.path.exists(path):
+        return {}, "no PMC pass committed"
+    rec = json.load(open(path))
+    if rec.get("source_hash") != source_hash():
+        return {}, f"PMC pass is of other kernel sources ({rec.get('source_hash')}): re-run profiles/pmc_collect.sh"
+    runs = rec.get("workloads", {})
+    key = f"{config}_{dtype}"
+    if key not in runs:
+        return {}, f"no PMC pass for workload {key}"
+    return runs[key], "rocprofv3 --pmc, one counter group per pass over profiles/prof_step.py (profiles/pmc_collect.sh); " \
+                      "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE per launch (gfx950 correction, MI355X_MICROARCH.md section HBM)"
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
+    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step (weak) / per global batch (strong)")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--guided", type=int, default=64)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--config", default="lambert", choices=["lambert", "rpv_nlr", "rpv_nan"],
-                    help="lambert = BASELINE config 2 (headline); rpv_nan = config 3 (RPV + analytic normals); rpv_nlr = learned normals")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--config", default="lambert", choices=list(CONFIG_FLAGS),
+                    help="lambert = BASELINE config 2 (headline); rpv_nan = config 3 (RPV + analytic normals; with --samples 128 "
+                         "--rays 1024: config 4's per-GPU shape); hapke / microfacet = the two halves of config 5 (use --dtype fp16); "
+                         "rpv_nlr = RPV with learned normals")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--settle-seconds", type=float, default=1.5, help="minimum time under load before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
+    return ap.parse_args()
 
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as fresh child processes (this parent never touches
+    the GPU, and nothing is re-exec'ed), rank 0 inherits stdout for the JSON line."""
+    have = torch.cuda.device_count()           # does not initialise the GPU
+    share = os.environ.get("BN_BENCH_SHARE_GPU") == "1"
+    if have < a.gpus and not share:
+        sys.exit(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + 3000
+    while procs and time.time() < deadline:
+        for p in list(procs):
+            c = p.poll()
+            if c is None:
+                continue
+            procs.remove(p)
+            if c != 0:
+                rc = rc or c
+                for q in procs:            # a rank died: the others would wait in a collective forever
+                    q.terminate()
+        time.sleep(0.2)
+    for p in procs:
+        p.kill()
+        rc = rc or 1
+    sys.exit(rc)
+
+
+def main():
+    a = parse_args()
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if a.gpus > 1 and not under_launcher:
+        spawn_ranks(a)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # Rehearsal hooks for a one-GPU box (the N > 1 path end to end on the real kernels): BN_BENCH_SHARE_GPU=1 puts every
     # rank on cuda:0, BN_BENCH_BACKEND=gloo replaces RCCL (which wants one GPU per rank).  Never set by the driver.
     if os.environ.get("BN_BENCH_SHARE_GPU") == "1":
         local = 0
     backend = os.environ.get("BN_BENCH_BACKEND", "nccl")
+    dist = torch.distributed
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
-            torch.distributed.init_process_group(backend)
+            dist.init_process_group(backend)
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+        assert dist.get_backend() == backend, dist.get_backend()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
     from brdf_nerf_amd import load_model, _lib
     from brdf_nerf_amd.trainer import FusedTrainer
 
-    over = {}
-    flags = dict(apply_brdf=False, apply_theta=False, cos_irra_on=False)
-    if a.config in ("rpv_nlr", "rpv_nan"):
-        over = dict(funcM=1, funcF=1, funcH=1, normal="learned" if a.config == "rpv_nlr" else "analystic")
-        flags = dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)
-    args = make_args(a.rays, a.samples, a.guided, a.dtype, **over)
+    over, flags, base_cfg = CONFIG_FLAGS[a.config]
+    rays_gpu = a.rays if a.scaling == "weak" else a.rays // world
+    assert rays_gpu >= 1 and (a.scaling == "weak" or rays_gpu * world == a.rays), "strong scaling: --rays must divide by --gpus"
+    args = make_args(rays_gpu, a.samples, a.guided, a.dtype, **over)
     torch.manual_seed(0)
     model = load_model(args).to(dev)
     trainer = FusedTrainer(model, args, lr=args.lr, ds_lambda=args.ds_lambda)
-    batches = [synthetic_batch(a.rays, 1000 * rank + i + 1, dev) for i in range(4)]
+    if a.scaling == "weak":
+        batches = [synthetic_batch(rays_gpu, 1000 * rank + i + 1, dev) for i in range(4)]
+    else:       # strong: the SAME global batches on every world size, each rank takes its contiguous share
+        from brdf_nerf_amd.distributed import shard_bounds
+        lo, hi = shard_bounds(a.rays, rank, world)
+        batches = [{k: v[lo:hi].contiguous() for k, v in synthetic_batch(a.rays, i + 1, dev).items()} for i in range(4)]
 
     def run(i):
         b = batches[i % len(batches)]
         return trainer.step(b["rays"], b["rgbs"], valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"],
                             near_far=(0.0, 2.0), **flags)
 
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def agree_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([float(x)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- warm-up, then settle: keep the chip under this load until it has seen >= settle_seconds of it
+    barrier()
+    t_load = time.perf_counter()
     for i in range(a.warmup):
         run(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    _lib.prof_enable(True)
-    torch.cuda.synchronize()
+    barrier()
+    est = agree_max((time.perf_counter() - t_load) / max(1, a.warmup)) if a.warmup else 0.02
+    under = time.perf_counter() - t_load
+    settle = int(agree_max(math.ceil(max(0.0, a.settle_seconds - under) / max(est, 1e-4)))) if a.settle_seconds > 0 else 0
+    settle = min(settle, 2000)
+    for i in range(settle):
+        run(a.warmup + i)
+    # ---- the timed region: exactly K steps, nothing else
+    barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss, _ = run(i)
+    barrier()
+    dt = agree_max(time.perf_counter() - t0)
+    # ---- separate pass: per-kernel durations from HIP events around every launch (on the launch stream)
+    prof_steps = max(10, min(a.steps, 20))
+    _lib.prof_enable(True)
+    for i in range(prof_steps):
+        run(i)
     torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
     _lib.prof_enable(False)
     prof = _lib.prof_collect()
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dropped = trainer.dropped_grad_elems()
     if rank != 0:
         if world > 1:
-            torch.distributed.destroy_process_group()
+            dist.barrier()
+            dist.destroy_process_group()
         return
 
-    n_heads = 1 + (3 if a.config != "lambert" else 0)
-    fpp = flops_per_point(n_heads=n_heads)
-    if a.config == "rpv_nan":       # analytic normals: adjoint chain + its backward (transposed / forward trunk products)
-        F, P, Lh = 512, 60, 8
-        fpp["field_adjoint"] = 2 * ((Lh - 1) * F * F + 2 * P * F)
-        fpp["field_adjoint_bwd"] = 2 * (P * F + (Lh - 2) * F * F + (F + P) * F)
-        fpp["wgrad"] += 2 * (P * F + (Lh - 2) * F * F + (F + P) * F)
-    M1, M2 = a.rays * a.samples, a.rays * (a.samples + a.guided)
+    n_heads = len(model.head_list(flags["apply_brdf"], flags["apply_theta"]))
+    F, P, Lh = 512, 60, 8
+    fpp = {False: flops_per_point(n_heads=n_heads), True: flops_per_point(n_heads=n_heads, executed=True)}
+    if model.normal in ("analystic", "analystic_learned"):   # adjoint chain + its backward (transposed / forward trunk products)
+        for f in fpp.values():
+            f["field_adjoint"] = 2 * ((Lh - 1) * F * F + 2 * P * F)
+            f["field_adjoint_bwd"] = 2 * (P * F + (Lh - 2) * F * F + (F + P) * F)
+            f["wgrad"] += 2 * (P * F + (Lh - 2) * F * F + (F + P) * F)
+    M1, M2 = rays_gpu * a.samples, rays_gpu * (a.samples + a.guided)
     pts = dict(field_fwd_sigma=M1, field_fwd_full=M2, field_bwd_chain=M2, wgrad=M2, skinny_wgrad=M2, field_adjoint=M2,
                field_adjoint_bwd=M2)
-    peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+    peak = PEAK_F32_TFLOPS if a.dtype == "fp32" else PEAK_MFMA16_TFLOPS
+    pmc, pmc_note = pmc_record(a.config, a.dtype) if (rays_gpu, a.samples, a.guided) == (4096, 64, 64) else ({}, "PMC passes are of the 4096 x 64+64 shape")
+    # algorithmic bytes per launch of the HBM-bound per-ray kernels (SURVEY.md section 8d; DESIGN.md section 3.3)
+    C_out = model.spec(flags["apply_brdf"], flags["apply_theta"], trainer.nr_lr, trainer.nr_an).out_channels
+    S2 = a.samples + a.guided
+    hbm_bytes = {
+        "composite_fwd": rays_gpu * (2 * S2 * 4 + S2 * C_out * 4 + 3 * S2 * 4 + 4 + C_out * 4),   # z, sigma, chan in; alpha, T, w, depth, acc out
+        "composite_bwd": rays_gpu * (2 * S2 * 4 + S2 * C_out * 4 + S2 * 4 + 4 + C_out * 4 + S2 * C_out * 4),
+        "guided_samples": rays_gpu * (2 * a.samples * 4 + 4 + a.guided * 4 + a.guided * 4 + S2 * 4 + S2 * 8),
+        "adam": trainer.flat_param.numel() * 4 * 7,                                               # p, g, m, v in; p, m, v out
+    }
     kernels = {}
     for name, (ms, cnt) in prof.items():
-        k = dict(ms_per_launch=ms / cnt, launches_per_step=cnt / a.steps)
-        if name in fpp:      # pts[name] = points per STEP through this kernel (however many launches they are split over)
-            k["tflops"] = fpp[name] * pts[name] * a.steps / (ms * 1e-3) / 1e12
+        k = dict(ms_per_launch=ms / cnt, launches_per_step=cnt / prof_steps)
+        if name in fpp[False]:      # pts[name] = points per STEP through this kernel (however many launches they are split over)
+            k["tflops"] = fpp[False][name] * pts[name] * prof_steps / (ms * 1e-3) / 1e12
+            k["tflops_executed"] = fpp[True][name] * pts[name] * prof_steps / (ms * 1e-3) / 1e12
             k["frac_of_peak"] = k["tflops"] / peak
+            k["frac_of_peak_executed"] = k["tflops_executed"] / peak
+        if name in hbm_bytes:       # per-ray kernels: algorithmic bytes per launch / duration (first launch shape of the step)
+            k["algorithmic_GBs"] = hbm_bytes[name] / (ms / cnt * 1e-3) / 1e9
+            k["frac_of_hbm_peak"] = k["algorithmic_GBs"] / PEAK_HBM_GBS
+        if name in pmc:
+            k["pmc"] = pmc[name]
         kernels[name] = k
     mfma = {n: k for n, k in kernels.items() if "tflops" in k and n != "skinny_wgrad"}
     dom = max(mfma, key=lambda n: mfma[n]["ms_per_launch"] * mfma[n]["launches_per_step"])
-    # algorithmic FLOPs of the launched kernels (the network as the reference defines it: the linear feats layer is counted
-    # although the build folds it into the heads and does not execute it)
-    flops_step = sum(fpp[n] * pts[n] for n in fpp if n in kernels)
+    dpm = pmc.get(dom, {})
+    flops_step = {e: sum(fpp[e][n] * pts[n] for n in fpp[e] if n in kernels) for e in (False, True)}
     # the reference pipeline's algorithmic work (SURVEY.md section 8d: pass 1 sigma-only + pass 2 on all S+G samples);
     # the fused trainer evaluates each sample once (pass 1 is kept and reused), so it executes less than this
-    flops_ref = sum(fpp[n] * pts[n] for n in fpp)
+    flops_ref = sum(fpp[False][n] * pts[n] for n in fpp[False])
+    step_s = dt / a.steps
+    rays_step = world * rays_gpu
     line = {
-        "metric": "train rays/sec (+ MFMA% of roofline), spsbrdf-nerf 64 samples/ray, 1/2/4/8 MI355X",
-        "value": world * a.rays * a.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
-        "data": "synthetic",
-        "config": {"workload": f"BASELINE config {3 if a.config == 'rpv_nan' else 2}: Djibouti-shaped synthetic rays, spsbrdf-nerf {a.config} train step "
+        "metric": METRIC, "value": rays_step * a.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE config {base_cfg}: Djibouti-shaped synthetic rays, spsbrdf-nerf {a.config} train step "
                                f"(pass1 {a.samples} + guided {a.guided} samples/ray, F=512, 8 Siren layers, PE10, ds_lambda=10), "
-                               f"{a.rays} rays/GPU/step", "rays_per_gpu": a.rays, "n_samples": a.samples,
-                   "guided_samples": a.guided, "parallelism": f"dp{world}"},
+                               f"{rays_gpu} rays/GPU/step ({rays_step} rays per global step, {a.scaling} scaling)",
+                   "rays_per_gpu": rays_gpu, "n_samples": a.samples, "guided_samples": a.guided, "parallelism": f"dp{world}",
+                   "backend": (backend if world > 1 else None), "settle_steps": settle},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
-                     "frac": mfma[dom]["tflops"] / peak,
-                     "traffic": PMC_TRAFFIC_BYTES.get(dom) if (a.config, a.rays, a.samples, a.guided, a.dtype) ==
-                     ("lambert", 4096, 64, 64, "bf16") else None,
-                     "traffic_unit": "bytes/launch (rocprofv3 PMC, offline pass: profiles/r01_pmc_traffic.txt)"},
+                     "frac": mfma[dom]["tflops"] / peak, "frac_algorithmic": mfma[dom]["tflops"] / peak,
+                     "achieved_executed": mfma[dom]["tflops_executed"], "frac_executed": mfma[dom]["tflops_executed"] / peak,
+                     "mfma_busy": dpm.get("mfma_busy"), "traffic": dpm.get("hbm_bytes"),
+                     "traffic_unit": "bytes/launch", "traffic_source": pmc_note,
+                     "note": "achieved = algorithmic FLOPs per launch (reference network, DESIGN.md section 3) / mean launch "
+                             "duration from HIP events on the launch stream, taken in a pass of its own after the timed region; "
+                             "_executed excludes the folded feats layer, which the build does not run"},
         # SURVEY.md section 8d kernel-level figure: the fused MLP on M = rays x samples rows (one launch of each kernel)
         "mlp_microbench": {
             "rows": M2 // 2,
             "fwd_ms": kernels["field_fwd_full"]["ms_per_launch"],
-            "fwd_tflops": fpp["field_fwd_full"] * (M2 // 2) / (kernels["field_fwd_full"]["ms_per_launch"] * 1e-3) / 1e12,
+            "fwd_tflops": fpp[False]["field_fwd_full"] * (M2 // 2) / (kernels["field_fwd_full"]["ms_per_launch"] * 1e-3) / 1e12,
             "fwd_bwd_ms": sum(kernels[n]["ms_per_launch"] for n in ("field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad")
                               if n in kernels),
-            "fwd_bwd_tflops": 3.0 * fpp["field_fwd_full"] * (M2 // 2) /
+            "fwd_bwd_tflops": 3.0 * fpp[False]["field_fwd_full"] * (M2 // 2) /
                               (sum(kernels[n]["ms_per_launch"] for n in ("field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad")
                                    if n in kernels) * 1e-3) / 1e12,
             "note": "fwd = full forward with activation stash; fwd_bwd = forward + backward chain + weight gradients, 3x the "
                     "forward's algorithmic FLOPs (dX + dW), analytic-normal kernels not included",
         } if "field_fwd_full" in kernels else None,
-        "step_tflops": flops_step / (dt / a.steps) / 1e12, "step_frac_of_peak": flops_step / (dt / a.steps) / 1e12 / peak,
-        "step_tflops_reference_accounting": flops_ref / (dt / a.steps) / 1e12,
-        "kernels": kernels, "final_loss": float(loss),
+        "step_tflops": flops_step[False] / step_s / 1e12, "step_frac_of_peak": flops_step[False] / step_s / 1e12 / peak,
+        "step_tflops_executed": flops_step[True] / step_s / 1e12, "step_frac_of_peak_executed": flops_step[True] / step_s / 1e12 / peak,
+        "step_tflops_reference_accounting": flops_ref / step_s / 1e12,
+        "kernels": kernels, "final_loss": float(loss), "dropped_nonfinite_grad_elems": list(dropped),
     }
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
     if world > 1:
-        torch.distributed.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -12,7 +12,8 @@ LIB_PATH = os.environ.get("BRDFNERF_HIP_LIB") or os.path.join(HERE, "libbrdfnerf
 
 BN_MAX_LAYERS = 12
 BN_MAX_HEADS = 4
-BN_F32, BN_BF16 = 0, 1
+BN_F32, BN_BF16, BN_F16 = 0, 1, 2
+DTYPES = {"fp32": BN_F32, "bf16": BN_BF16, "fp16": BN_F16}
 BN_ACT_SIN, BN_ACT_RELU = 0, 1
 BN_HEAD_PLAIN, BN_HEAD_RPV_K, BN_HEAD_RPV_THETA, BN_HEAD_HAPKE_THETA, BN_HEAD_TILE3 = 0, 1, 2, 3, 4
 BN_BRDF_AUX = 16
@@ -71,6 +72,8 @@ _SIGS = {
     "bn_stratified_z": (C.c_int, [fptr, fptr, C.c_int64, fptr, C.c_int64, C.c_int32, fptr, fptr]),
     "bn_guided_samples": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                     C.c_float, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr]),
+    "bn_guided_samples_nf": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int64, C.c_int32, C.c_int32, fptr, C.c_float, fptr, fptr,
+                                       fptr, fptr, fptr, fptr, fptr, fptr, fptr]),
     "bn_brdf_rpv_forward": (C.c_int, [fptr] * 7 + [C.c_int64, fptr, fptr, fptr]),
     "bn_brdf_rpv_backward": (C.c_int, [fptr] * 8 + [C.c_int64] + [fptr] * 6),
     "bn_brdf_hapke_forward": (C.c_int, [fptr] * 7 + [C.c_float, C.c_int32, C.c_int64, fptr, fptr, fptr]),
@@ -105,20 +108,33 @@ def exported_symbols():
     return sorted(_SIGS)
 
 
+def load(path):
+    """dlopen one build of the library and bind every declared entry point (no fallback: raises if absent)."""
+    if not os.path.exists(path):
+        raise LibraryMissing(f"{path} not found: build the HIP extension first "
+                             f"(python -m brdf_nerf_amd.build). There is no CPU fallback.")
+    L = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if L.bn_abi_version() != 1:
+        raise LibraryMissing(f"{path}: ABI version mismatch; rebuild")
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise LibraryMissing(f"{LIB_PATH} not found: build the HIP extension first "
-                                 f"(python -m brdf_nerf_amd.build). There is no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGS.items():
-            fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
-            fn.restype, fn.argtypes = res, args
-        if L.bn_abi_version() != 1:
-            raise LibraryMissing("libbrdfnerf_hip.so ABI version mismatch; rebuild")
-        _lib = L
+        _lib = load(LIB_PATH)
     return _lib
+
+
+def use(handle):
+    """Measurement harnesses only (profiles/ab_kernels.py): route every call through another build loaded with load(),
+    so that variants are timed alternately in ONE process.  Returns the previous handle."""
+    global _lib
+    prev, _lib = _lib, handle
+    return prev
 
 
 def check(status, what=""):

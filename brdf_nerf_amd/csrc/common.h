@@ -10,12 +10,17 @@
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 void bn_set_error(const char *fmt, ...);
+// Raise a kernel's dynamic-LDS limit to `lds` bytes on the CURRENT device (cached per (device, kernel); thread-safe).
+int bn_configure_lds(const void *kernel, size_t lds, const char *what);
 
 #define BN_REQUIRE(cond, ...)            \
   do {                                   \
@@ -35,24 +40,40 @@ void bn_set_error(const char *fmt, ...);
   } while (0)
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t bn_esize(int dtype) { return dtype == BN_F32 ? 4 : 2; }
+static inline bool bn_half(int dtype) { return dtype != BN_F32; }   // 16-bit throughput modes (bf16, fp16)
 
 // ---------------------------------------------------------------- MFMA element traits
 // A "fragment" is 8 consecutive k-elements of one row (A) / column (B) held by lane (r = lane&31,
-// h = lane>>5) for k = 8h + j.  bf16: one v_mfma_f32_32x32x16_bf16.  f32: eight
+// h = lane>>5) for k = 8h + j.  bf16 / fp16: one v_mfma_f32_32x32x16_{bf16,f16}.  f32: eight
 // v_mfma_f32_32x32x2_f32, MFMA j consuming element j of both fragments (k-permutation is
 // consistent between A and B, so the sum over k is the same).
 template <typename T> struct Elem;
 template <> struct Elem<bf16> {
   typedef bf16x8 frag;
   typedef bf16x4 vec4;
+  typedef bf16 wide;                // storage type of element-wise stashes that need fp32's exponent range
   static constexpr int kBM = 128;   // points per workgroup tile
   static constexpr int kPad = 8;    // LDS row pad (elements) = 16 B
   static constexpr int kU = 2;      // k-steps per prefetch block
   static constexpr bool kFastMath = true;
 };
+// fp16 throughput mode (BN_F16): same tiling and MFMA rate as bf16, 3 more mantissa bits (Siren activations live in
+// [-1, 1]); the backward chains run on loss-scaled gradients (field_bwd.hip, GradScale) because fp16 has bf16's
+// precision problem the other way round: 5 exponent bits.
+template <> struct Elem<f16> {
+  typedef f16x8 frag;
+  typedef f16x4 vec4;
+  typedef bf16 wide;
+  static constexpr int kBM = 128;
+  static constexpr int kPad = 8;
+  static constexpr int kU = 2;
+  static constexpr bool kFastMath = true;
+};
 template <> struct Elem<float> {
   typedef f32x8 frag;
   typedef f32x4 vec4;
+  typedef float wide;
   static constexpr int kBM = 64;
   static constexpr int kPad = 4;
   static constexpr int kU = 2;
@@ -61,6 +82,9 @@ template <> struct Elem<float> {
 
 __device__ __forceinline__ void mma32(f32x16 &acc, const bf16x8 &a, const bf16x8 &b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16 &acc, const f16x8 &a, const f16x8 &b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mma32(f32x16 &acc, const f32x8 &a, const f32x8 &b) {
 #pragma unroll
@@ -71,6 +95,10 @@ __device__ __forceinline__ bf16x4 to_vec4(bf16, float a, float b, float c, float
   bf16x4 v;
   v[0] = (bf16)a; v[1] = (bf16)b; v[2] = (bf16)c; v[3] = (bf16)d;
   return v;
+}
+__device__ __forceinline__ f16x4 to_vec4(f16, float a, float b, float c, float d) {
+  const f32x4 v = {a, b, c, d};
+  return __builtin_convertvector(v, f16x4);   // two v_cvt_pk_f16_f32 (round to nearest even)
 }
 __device__ __forceinline__ f32x4 to_vec4(float, float a, float b, float c, float d) {
   f32x4 v = {a, b, c, d};
@@ -105,6 +133,23 @@ template <bool FAST> __device__ __forceinline__ void sincos_t(float x, float &s,
     sincos_cw(x, s, c);
   }
 }
+
+// Loss scaling of the fp16 backward chains.  `amax` (device, nullable) holds max |seed gradient| as float bits
+// (grad_amax_kernel, field_bwd.hip); the scale is the power of two that brings it into [target/2, target).  Powers of two
+// commute exactly with every fp32 operation of the chains, so the unscaled fp32 gradients differ from an unscaled run
+// only where fp16 would have under- or overflowed.  amax == nullptr (fp32 / bf16 modes): scale 1.
+__device__ __forceinline__ float grad_scale_from(const float *amax, int log2_target) {
+  if (amax == nullptr) return 1.f;
+  const float a = *amax;
+  if (!(a > 0.f) || !(a < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(a, &e);                       // a = m 2^e, m in [0.5, 1)
+  int k = log2_target - e;
+  k = k < -24 ? -24 : (k > 40 ? 40 : k);
+  return ldexpf(1.f, k);
+}
+#define BN_GS_TARGET_CHAIN 8                 // primal backward chain: max |d pre-activation| -> [128, 256)
+#define BN_GS_TARGET_ADJ 6                   // analytic-normal double backward: max |gbar_PE| -> [32, 64)
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }

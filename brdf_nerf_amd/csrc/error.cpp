@@ -1,6 +1,10 @@
 // Thread-local error string of the C ABI (bn_last_error).
 #include <stdarg.h>
 #include <stdio.h>
+#include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "brdfnerf_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -14,3 +18,23 @@ void bn_set_error(const char *fmt, ...) {
 
 extern "C" const char *bn_last_error(void) { return g_err; }
 extern "C" int bn_abi_version(void) { return BN_ABI_VERSION; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of a kernel: remember what has been set for
+// (device, kernel) so that a second device in the same process gets its own call and concurrent callers do not race.
+int bn_configure_lds(const void *kernel, size_t lds, const char *what) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, size_t> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { bn_set_error("%s: hipGetDevice failed", what); return BN_ELAUNCH; }
+  std::lock_guard<std::mutex> lock(mu);
+  size_t &have = done[std::make_pair(dev, kernel)];
+  if (lds > have) {
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      bn_set_error("%s: cannot get %zu B of LDS: %s", what, lds, hipGetErrorString(e));
+      return BN_ELAUNCH;
+    }
+    have = lds;
+  }
+  return 0;
+}

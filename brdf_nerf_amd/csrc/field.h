@@ -34,13 +34,14 @@ struct FieldGeom {
 // workgroups per CU running out of phase - lost 20 % (r01): each workgroup streams the full weight set from L2, so
 // halving the tile doubles the L2->CU weight traffic per flop, which costs more than the phase overlap wins.
 static inline void bn_tile_config(int dtype, int *BM, int *waves) {
-  *BM = dtype == BN_BF16 ? 128 : 64;
+  *BM = bn_half(dtype) ? 128 : 64;
   *waves = 8;
 }
 
 static inline int bn_make_geom(const bn_field_desc *d, FieldGeom *g) {
   BN_REQUIRE(d->feat >= 64 && d->feat <= 512 && d->feat % 64 == 0 && (d->feat == 512 || d->feat <= 256),
              "field: feat=%d unsupported (64,128,192,256,512)", d->feat);
+  BN_REQUIRE(d->dtype == BN_F32 || d->dtype == BN_BF16 || d->dtype == BN_F16, "field: dtype=%d unknown", d->dtype);
   BN_REQUIRE(d->layers >= 2 && d->layers <= BN_MAX_LAYERS, "field: layers=%d unsupported", d->layers);
   BN_REQUIRE(d->skip < d->layers && d->skip != 0, "field: skip=%d invalid", d->skip);
   BN_REQUIRE(d->n_heads >= 1 && d->n_heads <= BN_MAX_HEADS, "field: n_heads=%d", d->n_heads);
@@ -118,6 +119,7 @@ static inline void bn_make_packed_layout(const FieldGeom &g, PackedLayout *pl) {
 // accumulator-register image per tile ([tile][wave][nt][mt][g][lane][4]) and are only re-read by
 // the backward chain, which uses the same tiling.
 struct StashLayout {
+  size_t gscale;                  // fp32 [2] as bits: max |d pre-activation| (primal chain), max |gbar_PE| (adjoint chain): fp16 loss scaling
   size_t sraw;                    // fp32 [Mpad]  pre-softplus sigma
   size_t nraw;                    // fp32 [Mpad][4] learned-normal pre-normalisation vector
   size_t dpre_trunk;              // fp32 [Mpad][4]  (d sigma_raw, d normal_raw xyz)      (bwd-produced)
@@ -139,7 +141,7 @@ struct StashLayout {
   size_t adj_delta[BN_MAX_LAYERS];  // T [Mpad][F]   delta_l = a_{l+1} (.) D_l
   size_t adj_a[BN_MAX_LAYERS];      // T native      a_{l+1}
   size_t adj_abar[BN_MAX_LAYERS + 1];  // T [Mpad][F] abar_l, l = 1..L                                       (bwd-produced)
-  size_t adj_zbar[BN_MAX_LAYERS];   // T native      extra d L / d z_l through D_l                          (bwd-produced)
+  size_t adj_zbar[BN_MAX_LAYERS];   // Elem<T>::wide native  extra d L / d z_l through D_l (bf16 in the fp16 mode)    (bwd-produced)
   size_t total;
   int64_t Mpad;
 };
@@ -149,6 +151,7 @@ static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, in
   s->Mpad = Mpad;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += bn_pad(bytes, 256); return o; };
+  s->gscale = take(256);
   s->sraw = take((size_t)Mpad * 4);
   s->nraw = take((size_t)Mpad * 16);
   s->dpre_trunk = take((size_t)Mpad * 16);

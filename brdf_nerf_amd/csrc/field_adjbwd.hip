@@ -21,7 +21,8 @@ struct AdjBwdArgs {
   bn_points pts;
   const float *d_out;
   char *stash;
-  int prescaled;   // forward packs carry w0/(2 pi) (bf16 Siren): undo it here
+  int prescaled;   // forward packs carry w0/(2 pi) (16-bit Siren modes): undo it here
+  const float *amax;   // fp16 mode: amax[1] = max |gbar_PE| picks this chain's loss scale (common.h); else nullptr
 };
 
 template <typename T, int MT, int NT, int WAVES>
@@ -37,6 +38,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.pts.n_points;
   const T *packed = (const T *)A.packed;
+  // fp16 mode: the chain runs scaled by gs (a power of two): gbar_PE, abar_l, zbar_l carry it (the weight-gradient jobs
+  // and the primal chain remove it); sbar, an fp32 scalar per point, is stored unscaled
+  const float gs = grad_scale_from(A.amax ? A.amax + 1 : nullptr, BN_GS_TARGET_ADJ);
 
   // ---------------------------------------------------------------- dL/dn -> dL/dg -> dL/dg_PE
   if (tid < BM) {
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       const float gd = gx[0] * dn[0] + gx[1] * dn[1] + gx[2] * dn[2];
       const float k = n2 > eps ? gd * inv * inv * inv : 0.f;     // n = -g * inv
 #pragma unroll
-      for (int c = 0; c < 3; ++c) gb[c] = -(dn[c] * inv - gx[c] * k);
+      for (int c = 0; c < 3; ++c) gb[c] = -(dn[c] * inv - gx[c] * k) * gs;
       if (A.pts.xyz) {
         x[0] = A.pts.xyz[gm * 3]; x[1] = A.pts.xyz[gm * 3 + 1]; x[2] = A.pts.xyz[gm * 3 + 2];
       } else {
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       const float e2 = g.act == BN_ACT_SIN ? -w0 * w0 : 0.f;      // dD/dz = -w0^2 sin(w0 z) = -w0^2 y (0 for ReLU)
       const T *Ds = (const T *)(A.stash + A.sl.D[l]) + (size_t)tile * BM * F;
       const T *As = (const T *)(A.stash + A.sl.adj_a[l]) + (size_t)tile * BM * F;
-      T *Zs = (T *)(A.stash + A.sl.adj_zbar[l]) + (size_t)tile * BM * F;
+      typename Elem<T>::wide *Zs = (typename Elem<T>::wide *)(A.stash + A.sl.adj_zbar[l]) + (size_t)tile * BM * F;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
     for (int o = 1; o < TPR; o <<= 1) ds += __shfl_xor(ds, o);
     if (q == 0) {
       const float sp = ((const float *)(A.stash + A.sl.sprime))[m0 + m];
-      ((float *)(A.stash + A.sl.sbar))[m0 + m] = ds * sp * (1.f - sp);
+      ((float *)(A.stash + A.sl.sbar))[m0 + m] = ds * sp * (1.f - sp) / gs;
     }
   }
 }
@@ -188,15 +192,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
 template <typename T, int MT, int NT, int WAVES> static int launch_adjbwd(const AdjBwdArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = ((size_t)BM * (a.g.F + Elem<T>::kPad) + (size_t)BM * (a.g.KP + Elem<T>::kPad)) * sizeof(T);
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)field_adjbwd_kernel<T, MT, NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      bn_set_error("field_adjbwd: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
-      return BN_ELAUNCH;
-    }
-    configured = lds;
-  }
+  if (int e = bn_configure_lds((const void *)field_adjbwd_kernel<T, MT, NT, WAVES>, lds, "field_adjbwd")) return e;
   BnProfScope prof_(BN_K_ADJBWD, st);
   field_adjbwd_kernel<T, MT, NT, WAVES><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_adjbwd");
@@ -210,10 +206,10 @@ int bn_field_adjoint_backward(const bn_field_desc *desc, const bn_field_params *
   if (int e = bn_make_geom(desc, &a.g)) return e;
   a.p = *params; a.packed = packed; a.pts = *pts; a.d_out = d_out; a.stash = (char *)stash;
   bn_make_packed_layout(a.g, &a.pl);
-  const bool bf = desc->dtype == BN_BF16;
-  a.prescaled = bf && desc->act == BN_ACT_SIN;
+  a.prescaled = bn_half(desc->dtype) && desc->act == BN_ACT_SIN;
   const int BM = a.g.BM;
-  bn_make_stash_layout(a.g, pts->n_points, BM, bf ? 2 : 4, &a.sl);
+  bn_make_stash_layout(a.g, pts->n_points, BM, bn_esize(desc->dtype), &a.sl);
+  a.amax = desc->dtype == BN_F16 ? (const float *)((const char *)stash + a.sl.gscale) : nullptr;
   const int64_t tiles = ceil_div64(pts->n_points, BM);
   hipStream_t st = (hipStream_t)stream;
   BN_DISPATCH_TILE(desc->dtype, a.g, launch_adjbwd, (a, tiles, st));

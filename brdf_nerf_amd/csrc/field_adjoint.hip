@@ -192,15 +192,7 @@ template <typename T, int MT, int NT, int WAVES> static int launch_adj(const Adj
 template <typename T, int MT, int NT, int WAVES, bool KEEP> static int launch_adj_k(const AdjArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = (size_t)BM * (a.g.F + Elem<T>::kPad) * sizeof(T) + (size_t)BM * a.g.P * sizeof(float);
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)field_adjoint_kernel<T, MT, NT, WAVES, KEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      bn_set_error("field_normals: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
-      return BN_ELAUNCH;
-    }
-    configured = lds;
-  }
+  if (int e = bn_configure_lds((const void *)field_adjoint_kernel<T, MT, NT, WAVES, KEEP>, lds, "field_normals")) return e;
   BnProfScope prof_(BN_K_ADJOINT, st);
   field_adjoint_kernel<T, MT, NT, WAVES, KEEP><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_normals");
@@ -216,9 +208,8 @@ int bn_field_normals_impl(const bn_field_desc *desc, const bn_field_params *para
   BN_REQUIRE(pts && pts->n_points > 0 && packed && stash && out, "field_normals: null argument");
   a.p = *params; a.packed = packed; a.pts = *pts; a.out = out; a.grad_x = grad_x; a.stash = (const char *)stash; a.keep = keep;
   bn_make_packed_layout(a.g, &a.pl);
-  const bool bf = desc->dtype == BN_BF16;
   const int BM = a.g.BM;
-  bn_make_stash_layout(a.g, pts->n_points, BM, bf ? 2 : 4, &a.sl);
+  bn_make_stash_layout(a.g, pts->n_points, BM, bn_esize(desc->dtype), &a.sl);
   const int64_t tiles = ceil_div64(pts->n_points, BM);
   hipStream_t st = (hipStream_t)stream;
   BN_DISPATCH_TILE(desc->dtype, a.g, launch_adj, (a, tiles, st));

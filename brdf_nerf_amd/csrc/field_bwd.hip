@@ -13,6 +13,7 @@ int bn_field_adjoint_backward(const bn_field_desc *desc, const bn_field_params *
                               const float *d_out, void *stash, void *stream);
 
 BN_PH_DEFINE_READER(bn_debug_phase_read_bwd)
+BN_CLK_DEFINE(bn_debug_clock_read_bwd)
 
 struct BwdArgs {
   FieldGeom g;
@@ -25,6 +26,7 @@ struct BwdArgs {
   const float *out, *d_out;
   char *stash;
   int an;   // analytic normals in the graph: add the adjoint chain's sbar / zbar_l (field_adjbwd.hip)
+  const float *amax;   // fp16 mode: [0] max |d pre-activation|, [1] max |gbar_PE| (loss scaling, common.h); else nullptr
 };
 
 // sigmoid output y and dL/dy of head `hd`, channel c, recovered from the forward's rescaled output.
@@ -38,6 +40,73 @@ __device__ __forceinline__ void head_y_dy(int kind, int nout, const float *o, co
     else if (kind == BN_HEAD_RPV_THETA) { y = ov * 0.5f + 0.5f; dy = 2.f * dv; }
     else { y = ov; dy = dv; }
   }
+}
+
+// d L / d (pre-activation) of the small outputs of point gm: the <= 3 pre-sigmoid values of every head, sigma_raw and
+// the learned-normal vector (shared by the chain kernel's prologue and the fp16 loss-scale reduction).
+__device__ __forceinline__ void bwd_dpre(const BwdArgs &A, int64_t gm, float (&dph)[12], float (&dpt)[4]) {
+  const FieldGeom &g = A.g;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) dph[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dpt[i] = 0.f;
+  if (gm >= A.M) return;
+  const float *o = A.out + gm * g.C, *dgo = A.d_out + gm * g.C;
+  for (int hd = 0; hd < g.n_heads; ++hd) {
+    const int nout = A.d.head_out[hd], kind = A.d.head_kind[hd];
+    for (int c = 0; c < nout; ++c) {
+      float y, dy;
+      head_y_dy(kind, nout, o + g.head_col[hd], dgo + g.head_col[hd], c, y, dy);
+      dph[hd * 3 + c] = dy * y * (1.f - y);
+    }
+  }
+  const float sraw = ((const float *)(A.stash + A.sl.sraw))[gm];
+  dpt[0] = dgo[3] * sigmoid_f(sraw);
+  if (A.an) dpt[0] += ((const float *)(A.stash + A.sl.sbar))[gm];
+  if (g.ch_normal_lr >= 0) {
+    const float *v = (const float *)(A.stash + A.sl.nraw) + gm * 4;
+    const float *dn = dgo + g.ch_normal_lr;
+    const float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const float eps = 1.1920928955078125e-07f;
+    const float inv = 1.f / sqrtf(fmaxf(n2, eps));
+    // out = -v * inv ; inv depends on v only when n2 > eps (torch.maximum passes the gradient to the larger)
+    const float vd = v[0] * dn[0] + v[1] * dn[1] + v[2] * dn[2];
+    const float k = n2 > eps ? vd * inv * inv * inv : 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dpt[1 + i] = -(dn[i] * inv - v[i] * k);
+  }
+}
+
+// fp16 loss scaling: amax[which] = max over the launch of the finite |seed gradients| (float bits; non-negative floats order
+// like their bit patterns).  which = 0: the primal chain's seeds (bwd_dpre); which = 1: the analytic-normal double
+// backward's seeds gbar_PE = J_PE(x) gbar, bounded by 2^(pe_freqs-1) |gbar| (field_adjbwd.hip).
+template <int WHICH> __global__ __launch_bounds__(256) void grad_amax_kernel(const BwdArgs A, float *amax) {
+  const FieldGeom &g = A.g;
+  float mx = 0.f;
+  for (int64_t gm = (int64_t)blockIdx.x * 256 + threadIdx.x; gm < A.M; gm += (int64_t)gridDim.x * 256) {
+    if (WHICH == 0) {
+      float dph[12], dpt[4];
+      bwd_dpre(A, gm, dph, dpt);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) { const float a = fabsf(dph[i]); mx = (a < 3.0e38f && a > mx) ? a : mx; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float a = fabsf(dpt[i]); mx = (a < 3.0e38f && a > mx) ? a : mx; }
+    } else {
+      const float *gx = (const float *)(A.stash + A.sl.gradx) + gm * 4;
+      const float *dn = A.d_out + gm * g.C + g.ch_normal_an;
+      const float n2 = gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2];
+      const float eps = 1.1920928955078125e-07f;
+      const float inv = 1.f / sqrtf(fmaxf(n2, eps));
+      const float gd = gx[0] * dn[0] + gx[1] * dn[1] + gx[2] * dn[2];
+      const float k = n2 > eps ? gd * inv * inv * inv : 0.f;
+      const float fmx = g.pe_freqs > 0 ? (float)(1 << (g.pe_freqs - 1)) : 1.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { const float a = fabsf(dn[c] * inv - gx[c] * k) * fmx; mx = (a < 3.0e38f && a > mx) ? a : mx; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax((unsigned int *)amax + WHICH, __float_as_uint(mx));
 }
 
 template <typename T, int MT, int NTW>
@@ -99,46 +168,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.M;
   const T *packed = (const T *)A.packed;
   BN_PH_DECL
+  BN_CLK_BEGIN
 
   // ---------------------------------------------------------------- pre-activation gradients of the small outputs
+  // fp16 mode: the chain runs on gradients scaled by S (a power of two, from the device-side maximum); the fp32 copies
+  // kept for the skinny weight-gradient kernel stay unscaled, the 16-bit dZ_l / dG stashes carry S and the weight-gradient
+  // kernel removes it from its fp32 sums.
+  const float gs = grad_scale_from(A.amax, BN_GS_TARGET_CHAIN);
   if (tid < BM) {
     const int m = tid;
     const int64_t gm = m0 + m;
-    float dph[12], dpt[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 12; ++i) dph[i] = 0.f;
-    if (gm < M) {
-      const float *o = A.out + gm * g.C, *dgo = A.d_out + gm * g.C;
-      for (int hd = 0; hd < g.n_heads; ++hd) {
-        const int nout = A.d.head_out[hd], kind = A.d.head_kind[hd];
-        for (int c = 0; c < nout; ++c) {
-          float y, dy;
-          head_y_dy(kind, nout, o + g.head_col[hd], dgo + g.head_col[hd], c, y, dy);
-          dph[hd * 3 + c] = dy * y * (1.f - y);
-        }
-      }
-      const float sraw = ((const float *)(A.stash + A.sl.sraw))[gm];
-      dpt[0] = dgo[3] * sigmoid_f(sraw);
-      if (A.an) dpt[0] += ((const float *)(A.stash + A.sl.sbar))[gm];
-      if (g.ch_normal_lr >= 0) {
-        const float *v = (const float *)(A.stash + A.sl.nraw) + gm * 4;
-        const float *dn = dgo + g.ch_normal_lr;
-        const float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-        const float eps = 1.1920928955078125e-07f;
-        const float inv = 1.f / sqrtf(fmaxf(n2, eps));
-        // out = -v * inv ; inv depends on v only when n2 > eps (torch.maximum passes the gradient to the larger)
-        const float vd = v[0] * dn[0] + v[1] * dn[1] + v[2] * dn[2];
-        const float k = n2 > eps ? vd * inv * inv * inv : 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) dpt[1 + i] = -(dn[i] * inv - v[i] * k);
-      }
-    }
+    float dph[12], dpt[4];
+    bwd_dpre(A, gm, dph, dpt);
     float *sh = (float *)(A.stash + A.sl.dpre_head) + gm * 12;
     float *st = (float *)(A.stash + A.sl.dpre_trunk) + gm * 4;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { DPH[m * 12 + i] = dph[i]; sh[i] = dph[i]; }
+    for (int i = 0; i < 12; ++i) { DPH[m * 12 + i] = dph[i] * gs; sh[i] = dph[i]; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { DPT[m * 4 + i] = dpt[i]; st[i] = dpt[i]; }
+    for (int i = 0; i < 4; ++i) { DPT[m * 4 + i] = dpt[i] * gs; st[i] = dpt[i]; }
   }
   __syncthreads();
   BN_PH(0)
@@ -150,6 +197,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   const bool ride = NT == 2 ? true : tile_copy_exact(F, n_on, WAVES);
   f32x16 acc[NT][MT];
   zero_acc<MT, NT>(acc);
+  const float zr = (A.an && A.amax) ? gs / grad_scale_from(A.amax + 1, BN_GS_TARGET_ADJ) : 1.f;
 
   // ---------------------------------------------------------------- heads: dG -> LDS, dFeats += W1^T dG
   for (int p = 0; p < g.n_pass; ++p) {
@@ -255,11 +303,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= dv[e];
-            if (A.an) {  // + dL/dz_l through D_l of the analytic-normal adjoint chain
+            if (A.an) {  // + dL/dz_l through D_l of the analytic-normal adjoint chain (stored at that chain's own scale)
               float zb[8];
-              ld8((const T *)(A.stash + A.sl.adj_zbar[lo]) + (size_t)tile * BM * F + native_off8<MT, NT>(wave, nt, mt, gp, lane), zb);
+              ld8((const typename Elem<T>::wide *)(A.stash + A.sl.adj_zbar[lo]) + (size_t)tile * BM * F + native_off8<MT, NT>(wave, nt, mt, gp, lane), zb);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += zb[e];
+              for (int e = 0; e < 8; ++e) v[e] += zb[e] * zr;
             }
             *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), v[0], v[1], v[2], v[3]);
             *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), v[4], v[5], v[6], v[7]);
@@ -275,6 +323,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
 #ifndef BN_PHASE_TIMING_WGRAD
   BN_PH_FLUSH
 #endif
+#ifndef BN_CLOCK_STAMP_WGRAD
+  BN_CLK_END
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ weight gradients
@@ -286,7 +337,13 @@ struct WgradJob {
   int lda, ldb, ldc;
   int a_col0, b_col0;  // first column used in A / B
   int N, K;            // valid output extents (rows of C, cols of C)
+  int scale_sel;       // fp16 loss scaling carried by A: 0 none, 1 the primal chain's (amax[0]), 2 the adjoint chain's (amax[1])
 };
+// 1 / (scale carried by the job's gradient operand): multiplies the fp32 sums before they are accumulated
+__device__ __forceinline__ float wg_unscale(const float *amax, int sel) {
+  if (amax == nullptr || sel == 0) return 1.f;
+  return 1.f / (sel == 1 ? grad_scale_from(amax, BN_GS_TARGET_CHAIN) : grad_scale_from(amax + 1, BN_GS_TARGET_ADJ));
+}
 #define BN_MAX_WGRAD_JOBS 40
 struct WgradArgs {
   WgradJob job[BN_MAX_WGRAD_JOBS];
@@ -294,6 +351,7 @@ struct WgradArgs {
   int n_jobs;
   int64_t Mpad;
   int m_per_block;                   // points per split (multiple of 32)
+  const float *amax;                 // fp16 mode only (else nullptr): see wg_unscale
 };
 
 #define WG_BK 32
@@ -402,17 +460,17 @@ template <typename T> __global__ __launch_bounds__(256) void wgrad_kernel(const 
 // LDS (one barrier per stage; the next stage's global loads are in flight during the MFMAs), transposing
 // ds_read_b64_tr_b16 fragment reads.  Each wave owns 64(n) x 128(k): 2 x 4 accumulator tiles.  Blocks that share an
 // (job, point-split) - i.e. the same A rows - get consecutive ids on ONE XCD so the second read of a tile hits L2.
-__device__ __attribute__((aligned(16))) bf16 w2_zeros[8];   // zero-initialised
+__device__ __attribute__((aligned(16))) unsigned short w2_zeros[8];   // zero-initialised (16 bytes of +0 in bf16 and fp16)
 #define W2_LD (256 + 32)       // 576-byte rows: the 4 rows of a tr-read block fall on disjoint bank groups
 #define W2_BK 64               // points per stage (one barrier per stage; 2 stages x 2 operands = 144 KB of LDS)
 #define W2_STAGE (W2_BK * W2_LD)
-__device__ __forceinline__ bf16x8 w2_frag(const bf16 *tile, int mm, int col0, int lane) {
+template <typename T> __device__ __forceinline__ typename Elem<T>::frag w2_frag(const T *tile, int mm, int col0, int lane) {
   const int h = lane >> 5, grp = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
-  const bf16 *a = tile + (size_t)(mm + 8 * h + q) * W2_LD + col0 + 16 * grp + 4 * p;
+  const T *a = tile + (size_t)(mm + 8 * h + q) * W2_LD + col0 + 16 * grp + 4 * p;
   typedef __attribute__((address_space(3))) s16x4 lds_v4;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)a);
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a + 4 * W2_LD));
-  union { s16x4 s[2]; bf16x8 b; } u;
+  union { s16x4 s[2]; typename Elem<T>::frag b; } u;   // the transposing read moves 16-bit lanes: element type agnostic
   u.s[0] = lo; u.s[1] = hi;
   return u.b;
 }
@@ -436,11 +494,12 @@ __device__ __forceinline__ bf16x8 w2_frag(const bf16 *tile, int mm, int col0, in
 // One 256 x 256 output tile over the points [mb, me).  NBV = 32-column accumulator tiles this WAVE multiplies (4 for a
 // full tile; the 60-column positional-encoding operand only has columns for two tiles of the wc = 0 waves - the other
 // waves of such a block just take part in staging and barriers).
-template <int NBV>
-__device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64_t mb, int64_t me, bf16 *sA, bf16 *sB) {
+template <typename T, int NBV>
+__device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64_t mb, int64_t me, T *sA, T *sB, float osc) {
+  typedef typename Elem<T>::frag frag_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-  const bf16 *gA = (const bf16 *)J.A + J.a_col0 + n0;
-  const bf16 *gB = (const bf16 *)J.B + J.b_col0 + k0;
+  const T *gA = (const T *)J.A + J.a_col0 + n0;
+  const T *gB = (const T *)J.B + J.b_col0 + k0;
   // W2_BK rows x 32 chunks (16 B) per operand: NC per thread
   constexpr int RPP = W2_WAVES * 2;                          // rows per pass of the workgroup
   constexpr int NC = W2_BK / RPP;
@@ -459,7 +518,7 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
 #endif
     // columns beyond the operand's extent read one 16-byte block of zeros with row stride 0: the stage loop has no branch
     // (an exec-masked load per chunk split its basic block and cost 6 % of the kernel: profiles/r01_ablation.txt)
-    const bf16 *pa = a_ok ? gA + cc : w2_zeros, *pb = b_ok ? gB + cc : w2_zeros;
+    const T *pa = a_ok ? gA + cc : (const T *)w2_zeros, *pb = b_ok ? gB + cc : (const T *)w2_zeros;
     const int64_t sa = a_ok ? J.lda : 0, sb = b_ok ? J.ldb : 0;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -470,7 +529,7 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   };
   auto gload1 = [&](int64_t m, int c) {
     m = m < me ? m : me - W2_BK;
-    const bf16 *pa = a_ok ? gA + cc : w2_zeros, *pb = b_ok ? gB + cc : w2_zeros;
+    const T *pa = a_ok ? gA + cc : (const T *)w2_zeros, *pb = b_ok ? gB + cc : (const T *)w2_zeros;
     const int64_t sa = a_ok ? J.lda : 0, sb = b_ok ? J.ldb : 0;
     const int64_t row = m + row0 + RPP * c;
     ra[c] = *(const u32x4 *)(pa + row * sa);
@@ -507,13 +566,13 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   // fragments of 16-point step i+1 are read while the MFMAs of step i run (two fragment sets; sched_barrier keeps
   // hipcc from sinking the reads below the MFMAs)
   auto compute = [&](int buf, int64_t m_next2) {
-    const bf16 *cA = sA + buf * W2_STAGE, *cB = sB + buf * W2_STAGE;
-    bf16x8 fa[2][W2_RA], fb[2][NBV > 0 ? NBV : 1];
+    const T *cA = sA + buf * W2_STAGE, *cB = sB + buf * W2_STAGE;
+    frag_t fa[2][W2_RA], fb[2][NBV > 0 ? NBV : 1];
     auto frags = [&](int set, int mm) {
 #pragma unroll
-      for (int a = 0; a < W2_RA; ++a) fa[set][a] = w2_frag(cA, mm, wr * (W2_RA * 32) + a * 32, lane);
+      for (int a = 0; a < W2_RA; ++a) fa[set][a] = w2_frag<T>(cA, mm, wr * (W2_RA * 32) + a * 32, lane);
 #pragma unroll
-      for (int b = 0; b < NBV; ++b) fb[set][b] = w2_frag(cB, mm, wc * 128 + b * 32, lane);
+      for (int b = 0; b < NBV; ++b) fb[set][b] = w2_frag<T>(cB, mm, wc * 128 + b * 32, lane);
     };
     frags(0, 0);
 #pragma unroll
@@ -577,13 +636,13 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int n = n0 + wr * (W2_RA * 32) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (n < J.N && k < J.K) atomicAdd(J.C + (size_t)n * J.ldc + k, acc[a][b][i]);
+        if (n < J.N && k < J.K) atomicAdd(J.C + (size_t)n * J.ldc + k, acc[a][b][i] * osc);
       }
     }
   if (do_bias) {
 #pragma unroll
     for (int a = 0; a < W2_RA; ++a) {
-      const float v = bsum[a] + __shfl_xor(bsum[a], 32);
+      const float v = (bsum[a] + __shfl_xor(bsum[a], 32)) * osc;
       const int n = n0 + wr * (W2_RA * 32) + a * 32 + r;
       if (h == 0 && n < J.N) atomicAdd(J.bias + n, v);
     }
@@ -592,10 +651,11 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   WG_PH_FLUSH
 }
 
+template <typename T>
 __global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256_kernel(const WgradArgs A, int n_split, int n_blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem_w[];
-  bf16 *sA = (bf16 *)smem_w;                 // [2][W2_BK][W2_LD]
-  bf16 *sB = sA + 2 * W2_STAGE;
+  T *sA = (T *)smem_w;                 // [2][W2_BK][W2_LD]
+  T *sB = sA + 2 * W2_STAGE;
   // XCD-aware id: hardware deals consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous range
   const int per = n_blocks / 8;              // n_blocks is a multiple of 8
   const int lid = (blockIdx.x % 8) * per + blockIdx.x / 8;
@@ -613,10 +673,17 @@ __global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256
   if (mb >= me) return;
   const int wc = (threadIdx.x >> 6) & 1;
   const int cols = J.K - k0 - wc * 128;          // output columns this wave's tiles can reach
-  if (cols >= 65) w2_body<4>(J, n0, k0, mb, me, sA, sB);
-  else if (cols >= 33) w2_body<2>(J, n0, k0, mb, me, sA, sB);
-  else if (cols >= 1) w2_body<1>(J, n0, k0, mb, me, sA, sB);
-  else w2_body<0>(J, n0, k0, mb, me, sA, sB);
+  const float osc = wg_unscale(A.amax, J.scale_sel);
+#ifdef BN_CLOCK_STAMP_WGRAD
+  BN_CLK_BEGIN
+#endif
+  if (cols >= 65) w2_body<T, 4>(J, n0, k0, mb, me, sA, sB, osc);
+  else if (cols >= 33) w2_body<T, 2>(J, n0, k0, mb, me, sA, sB, osc);
+  else if (cols >= 1) w2_body<T, 1>(J, n0, k0, mb, me, sA, sB, osc);
+  else w2_body<T, 0>(J, n0, k0, mb, me, sA, sB, osc);
+#ifdef BN_CLOCK_STAMP_WGRAD
+  BN_CLK_END
+#endif
 }
 
 struct SkinnyJob {
@@ -627,6 +694,7 @@ struct SkinnyJob {
   int bm, ntw, tstride;
   float *out[4];       // row c of the gradient: out[c][k], k < K
   float *bias[4];      // scalar bias gradient of row c (nullable)
+  int scale_sel;       // fp16 loss scaling carried by X (see WgradJob.scale_sel; the fp32 dpre columns are never scaled)
 };
 #define BN_MAX_SKINNY_JOBS 8
 struct SkinnyArgs {
@@ -634,10 +702,12 @@ struct SkinnyArgs {
   int n_jobs;
   int64_t Mpad;
   int m_per_block;
+  const float *amax;
 };
 
 template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const SkinnyArgs A) {
   const SkinnyJob &J = A.job[blockIdx.y];
+  const float osc = wg_unscale(A.amax, J.scale_sel);
   const int64_t mb = (int64_t)blockIdx.x * A.m_per_block;
   const int64_t me = mb + A.m_per_block < A.Mpad ? mb + A.m_per_block : A.Mpad;
   const int tid = threadIdx.x;
@@ -747,23 +817,15 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
   __syncthreads();
   for (int i = tid; i < J.nc * J.K; i += 256) {
     const int c = i / J.K, k = i % J.K;
-    atomicAdd(J.out[c] + k, red[c * 512 + k]);
+    atomicAdd(J.out[c] + k, red[c * 512 + k] * osc);
   }
-  if (tid < J.nc && J.bias[tid]) atomicAdd(J.bias[tid], red[4 * 512 + tid]);
+  if (tid < J.nc && J.bias[tid]) atomicAdd(J.bias[tid], red[4 * 512 + tid]);   // bias sums come from the unscaled fp32 dpre
 }
 
 template <typename T, int MT, int NT, int WAVES> static int launch_bwd(const BwdArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = (size_t)BM * (a.g.F + Elem<T>::kPad) * sizeof(T) + (size_t)BM * 16 * sizeof(float);
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)field_bwd_kernel<T, MT, NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      bn_set_error("field_bwd: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
-      return BN_ELAUNCH;
-    }
-    configured = lds;
-  }
+  if (int e = bn_configure_lds((const void *)field_bwd_kernel<T, MT, NT, WAVES>, lds, "field_bwd")) return e;
   BnProfScope prof_(BN_K_BWD_CHAIN, st);
   field_bwd_kernel<T, MT, NT, WAVES><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_bwd");
@@ -780,16 +842,32 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   const FieldGeom &g = a.g;
   a.d = *desc; a.p = *params; a.packed = packed; a.M = pts->n_points; a.out = out; a.d_out = d_out; a.stash = (char *)stash;
   bn_make_packed_layout(g, &a.pl);
-  const bool bf = desc->dtype == BN_BF16;
+  const bool bf = bn_half(desc->dtype);    // 16-bit throughput modes (bf16, fp16)
+  const bool f16m = desc->dtype == BN_F16;
   const int BM = g.BM;
-  const size_t esz = bf ? 2 : 4;
+  const size_t esz = bn_esize(desc->dtype);
   bn_make_stash_layout(g, pts->n_points, BM, esz, &a.sl);
   const int64_t tiles = ceil_div64(pts->n_points, BM);
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  // fp16: the seeds' maxima pick the loss scales of the two backward chains on the device (no host round trip)
+  float *amax = f16m ? (float *)((char *)stash + a.sl.gscale) : nullptr;
+  a.amax = amax;
+  const unsigned amax_grid = (unsigned)(ceil_div64(pts->n_points, 256) < 1024 ? ceil_div64(pts->n_points, 256) : 1024);
+  if (f16m) {
+    if (hipMemsetAsync(amax, 0, 8, st) != hipSuccess) { bn_set_error("field_backward: memset failed"); return BN_ELAUNCH; }
+    if (a.an) {
+      grad_amax_kernel<1><<<amax_grid, 256, 0, st>>>(a, amax);
+      BN_LAUNCH_CHECK("grad_amax<1>");
+    }
+  }
   if (a.an) {  // double backward of the normals: produces gbar_PE, abar_l, zbar_l, sbar in the stash
     rc = bn_field_adjoint_backward(desc, params, packed, pts, d_out, stash, stream);
     if (rc) return rc;
+  }
+  if (f16m) {   // after the adjoint backward: the primal seeds include its sbar
+    grad_amax_kernel<0><<<amax_grid, 256, 0, st>>>(a, amax);
+    BN_LAUNCH_CHECK("grad_amax<0>");
   }
   rc = [&]() -> int { BN_DISPATCH_TILE(desc->dtype, g, launch_bwd, (a, tiles, st)); }();
   if (rc) return rc;
@@ -799,10 +877,12 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   char *S = (char *)stash;
   const int F = g.F, P0 = g.P;
   WgradArgs w;
-  w.n_jobs = 0; w.Mpad = sl.Mpad; w.tile0[0] = 0;
+  w.n_jobs = 0; w.Mpad = sl.Mpad; w.tile0[0] = 0; w.amax = amax;
+  int scale_sel = 1;   // gradient operand of the jobs added next: 1 = primal chain (dZ_l, dG), 2 = adjoint chain (gbar_PE, abar_l)
   auto add = [&](const void *A_, int lda, int a0, const void *B_, int ldb, int b0, float *C, int ldc, float *bias, int N, int K) {
     if (!C) return;
     WgradJob &j = w.job[w.n_jobs];
+    j.scale_sel = scale_sel;
     j.A = A_; j.B = B_; j.C = C; j.bias = bias; j.lda = lda; j.ldb = ldb; j.ldc = ldc; j.a_col0 = a0; j.b_col0 = b0; j.N = N; j.K = K;
     w.tile0[w.n_jobs + 1] = w.tile0[w.n_jobs] + ((N + 127) / 128) * ((K + 127) / 128);
     ++w.n_jobs;
@@ -816,7 +896,8 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     } else add(dZ, F, 0, S + sl.Y[l - 1], F, 0, G->trunk_w[l], F, G->trunk_b[l], F, F);
   }
   if (!g.fold) add(S + sl.dfeats, F, 0, S + sl.Y[g.L - 1], F, 0, G->feats_w, F, G->feats_b, F, F);
-  if (a.an) {  // dW_l += delta_l^T [gbar_PE ; abar_l]
+  if (a.an) {  // dW_l += delta_l^T [gbar_PE ; abar_l]  (delta_l is a forward quantity: the scale rides on gbar_PE / abar_l)
+    scale_sel = 2;
     for (int l = 0; l < g.L; ++l) {
       const void *dl = S + sl.adj_delta[l];
       if (l == 0) add(dl, F, 0, S + sl.gbar_pe, g.KP, 0, G->trunk_w[l], P0, nullptr, F, P0);
@@ -826,6 +907,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
       } else add(dl, F, 0, S + sl.adj_abar[l], F, 0, G->trunk_w[l], F, nullptr, F, F);
     }
   }
+  scale_sel = 1;
   for (int hd = 0; hd < g.n_heads; ++hd) {
     const int p = hd / 2, hl = hd % 2;
     // folded: the head's first layer reads Y_{L-1}; the gradient is that of the folded matrix (bn_field_desc.fold_feats)
@@ -847,19 +929,13 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     n_split = ceil_div64(sl.Mpad, mpb2);
     w.m_per_block = (int)mpb2;
     const int n_blocks = (int)ceil_div64((int64_t)tiles * n_split, 8) * 8;
-    const size_t lds = (size_t)4 * W2_STAGE * sizeof(bf16);
-    static bool configured = false;
-    if (!configured) {
-      hipError_t e = hipFuncSetAttribute((const void *)wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) {
-        bn_set_error("wgrad256: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
-        return BN_ELAUNCH;
-      }
-      configured = true;
-    }
+    const size_t lds = (size_t)4 * W2_STAGE * 2;
+    const void *kfn = f16m ? (const void *)wgrad256_kernel<f16> : (const void *)wgrad256_kernel<bf16>;
+    if (int e = bn_configure_lds(kfn, lds, "wgrad256")) return e;
     {
       BnProfScope prof_(BN_K_WGRAD, st);
-      wgrad256_kernel<<<dim3((unsigned)n_blocks), W2_WAVES * 64, lds, st>>>(w, (int)n_split, n_blocks);
+      if (f16m) wgrad256_kernel<f16><<<dim3((unsigned)n_blocks), W2_WAVES * 64, lds, st>>>(w, (int)n_split, n_blocks);
+      else wgrad256_kernel<bf16><<<dim3((unsigned)n_blocks), W2_WAVES * 64, lds, st>>>(w, (int)n_split, n_blocks);
       BN_LAUNCH_CHECK("wgrad256");
     }
     w.n_jobs = 0;  // done
@@ -877,7 +953,8 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     BN_LAUNCH_CHECK("wgrad");
   }
   SkinnyArgs s;
-  s.n_jobs = 0; s.Mpad = sl.Mpad;
+  s.n_jobs = 0; s.Mpad = sl.Mpad; s.amax = amax;
+  for (int i = 0; i < BN_MAX_SKINNY_JOBS; ++i) s.job[i].scale_sel = 0;   // X = forward activations unless noted
   {
     SkinnyJob &j = s.job[s.n_jobs];
     j.X = S + sl.Y[g.L - 1]; j.ldx = F; j.x_col0 = 0; j.K = F; j.dpre = (const float *)(S + sl.dpre_trunk); j.ldp = 4; j.p_col0 = 0;
@@ -892,6 +969,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   }
   if (a.an && G->sigma_w) {  // dw_sigma += sum_m s'(m) abar_L[m][:]
     SkinnyJob &j = s.job[s.n_jobs++];
+    j.scale_sel = 2;   // abar_L carries the adjoint chain's loss scale
     j.X = S + sl.adj_abar[g.L]; j.ldx = F; j.x_col0 = 0; j.K = F; j.dpre = (const float *)(S + sl.sprime); j.ldp = 1; j.p_col0 = 0; j.nc = 1; j.native = 0;
     for (int c = 0; c < 4; ++c) { j.out[c] = nullptr; j.bias[c] = nullptr; }
     j.out[0] = G->sigma_w;
@@ -914,7 +992,8 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     s.m_per_block = (int)smpb;
     dim3 grid((unsigned)ceil_div64(sl.Mpad, smpb), (unsigned)s.n_jobs);
     BnProfScope prof_(BN_K_SKINNY, st);
-    if (bf) skinny_wgrad_kernel<bf16><<<grid, 256, 0, st>>>(s);
+    if (f16m) skinny_wgrad_kernel<f16><<<grid, 256, 0, st>>>(s);
+    else if (bf) skinny_wgrad_kernel<bf16><<<grid, 256, 0, st>>>(s);
     else skinny_wgrad_kernel<float><<<grid, 256, 0, st>>>(s);
     BN_LAUNCH_CHECK("skinny_wgrad");
   }

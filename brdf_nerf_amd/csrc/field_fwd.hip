@@ -24,6 +24,7 @@ struct FwdArgs {
 #define BN_INV_2PI 0.15915494309189535f
 
 BN_PH_DEFINE_READER(bn_debug_phase_read_fwd)
+BN_CLK_DEFINE(bn_debug_clock_read_fwd)
 template <bool FAST, int ACT> __device__ __forceinline__ void act_eval(float z, float w0, float &y, float &d) {
   if (ACT == BN_ACT_SIN) {
     if (FAST) {
@@ -105,10 +106,11 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
               act_eval<FAST, ACTK>(acc[nt][mt][8 * gp + 4 + e] + bb[e], 1.f, y[4 + e], dd[4 + e]);
             }
             // the second layer sees the stored (rounded) hidden value: fwd and bwd stay consistent
+            const typename Elem<T>::frag yq = cvt8(T(), y);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = (float)(T)y[e];
+            for (int e = 0; e < 8; ++e) y[e] = (float)yq[e];
             if (keep) {
-              st8(Gs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), y);
+              st_frag(Gs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), yq);
               st8(DGs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), dd);
             }
 #pragma unroll
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
   const T *packed = (const T *)A.packed;
   constexpr bool keep = KEEP;   // compile-time: the inference variant drops every derivative (cos) computation
   BN_PH_DECL
+  BN_CLK_BEGIN
 
   // ---------------------------------------------------------------- points + positional encoding
   {
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
     }
   }
   BN_PH(6)
-  if (A.sigma_only) { BN_PH_FLUSH return; }
+  if (A.sigma_only) { BN_PH_FLUSH BN_CLK_END return; }
 
   // ---------------------------------------------------------------- feats = Wf h8 + bf (linear)
   // With fold_feats the caller has multiplied the feats layer into the heads' first layers: the heads read h8 directly.
@@ -468,6 +471,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
     else head_pass<T, MT, BN_SINGLE_HEAD_NTW(NT), WAVES, KEEP>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
   }
   BN_PH_FLUSH
+  BN_CLK_END
 }
 
 // ------------------------------------------------------------------------------------------ weight packing
@@ -510,7 +514,7 @@ template <typename T> __global__ void pack_kernel(const PackArgs A) {
   }
 }
 
-static size_t esize(int dtype) { return dtype == BN_BF16 ? 2 : 4; }
+static size_t esize(int dtype) { return bn_esize(dtype); }
 
 extern "C" size_t bn_field_packed_bytes(const bn_field_desc *desc) {
   FieldGeom g;
@@ -543,7 +547,7 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
     j.row_off = row_off; j.col_off = col_off; j.transposed = tr; j.k_lo = 0; j.masked = 0; j.scale = 1.f;
   };
   // bf16 Siren: forward matrices carry w0/(2 pi) so the epilogue feeds v_sin/v_cos directly (see act_eval)
-  const bool prescale = desc->dtype == BN_BF16 && desc->act == BN_ACT_SIN;
+  const bool prescale = bn_half(desc->dtype) && desc->act == BN_ACT_SIN;
   auto fwd_scale = [&](int n_last, float w0) {
     if (prescale)
       for (int q = 0; q < n_last; ++q) a.job[a.n_jobs - 1 - q].scale = w0 * BN_INV_2PI;
@@ -602,6 +606,7 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
   dim3 grid(64, a.n_jobs);
   BnProfScope prof_(BN_K_PACK, (hipStream_t)stream);
   if (desc->dtype == BN_BF16) pack_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  else if (desc->dtype == BN_F16) pack_kernel<f16><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   else pack_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   BN_LAUNCH_CHECK("bn_pack_field");
   return 0;
@@ -615,16 +620,7 @@ template <typename T, int MT, int NT, int WAVES, bool KEEP> static int launch_fw
   constexpr int BM = MT * 32;
   const size_t lds = ((size_t)BM * (a.g.F + Elem<T>::kPad) + (size_t)BM * (a.g.KP + Elem<T>::kPad)) * sizeof(T) +
                      (size_t)WAVES * 3 * BM * sizeof(float);
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)field_fwd_kernel<T, MT, NT, WAVES, KEEP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) {
-      bn_set_error("field_fwd: cannot get %zu B of LDS: %s", lds, hipGetErrorString(e));
-      return BN_ELAUNCH;
-    }
-    configured = lds;
-  }
+  if (int e = bn_configure_lds((const void *)field_fwd_kernel<T, MT, NT, WAVES, KEEP>, lds, "field_fwd")) return e;
   BnProfScope prof_(a.sigma_only ? BN_K_FWD_SIGMA : BN_K_FWD_FULL, st);
   field_fwd_kernel<T, MT, NT, WAVES, KEEP><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_fwd");

@@ -37,6 +37,30 @@ static __device__ unsigned long long bn_phase_clk[BN_PH_N + 1];
 #define BN_PH_FLUSH
 #endif
 
+// In-kernel clock stamps, compiled only into the diagnostic library built by profiles/clock_probe.py (-DBN_CLOCK_STAMP):
+// wave 0 of every workgroup stamps s_memtime (shader clock) and s_memrealtime (100 MHz) at entry and exit; the quotient of
+// the two differences is the clock the chip holds under this kernel (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps
+// go to a buffer nothing else reads; no output depends on them.
+#ifdef BN_CLOCK_STAMP
+#define BN_CLK_N 8192
+#define BN_CLK_DEFINE(NAME)                                                                                    \
+  static __device__ unsigned long long bn_clk_buf[BN_CLK_N][2];                                               \
+  extern "C" int NAME(unsigned long long *out, int n) {                                                        \
+    if (n > BN_CLK_N) n = BN_CLK_N;                                                                            \
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bn_clk_buf), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -1; \
+  }
+#define BN_CLK_BEGIN const unsigned long long clk0_ = __builtin_amdgcn_s_memtime(), clk1_ = __builtin_amdgcn_s_memrealtime();
+#define BN_CLK_END                                                                                             \
+  if (threadIdx.x == 0 && blockIdx.x < BN_CLK_N) {                                                             \
+    bn_clk_buf[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - clk0_;                                          \
+    bn_clk_buf[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - clk1_;                                      \
+  }
+#else
+#define BN_CLK_DEFINE(NAME)
+#define BN_CLK_BEGIN
+#define BN_CLK_END
+#endif
+
 // Stash traffic is streaming (written once here, read once by a later kernel) and several times larger than the
 // packed weights every workgroup re-reads from L2: non-temporal stores / loads keep it from evicting the weights.
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -64,6 +88,10 @@ template <typename V> __device__ __forceinline__ V stash_load(const V *p) {
       if ((G).NT == 2) return FN<bf16, 4, 2, 8> ARGS;                                            \
       return FN<bf16, 4, 1, 8> ARGS;                                                             \
     }                                                                                            \
+    if ((DTYPE) == BN_F16) {                                                                     \
+      if ((G).NT == 2) return FN<f16, 4, 2, 8> ARGS;                                             \
+      return FN<f16, 4, 1, 8> ARGS;                                                              \
+    }                                                                                            \
     if ((G).NT == 2) return FN<float, 2, 2, 8> ARGS;                                             \
     return FN<float, 2, 1, 8> ARGS;                                                              \
   } while (0)
@@ -71,6 +99,7 @@ template <typename V> __device__ __forceinline__ V stash_load(const V *p) {
 
 template <typename T> __device__ __forceinline__ typename Elem<T>::frag lds_frag(const T *p);
 template <> __device__ __forceinline__ bf16x8 lds_frag<bf16>(const bf16 *p) { return *(const bf16x8 *)p; }
+template <> __device__ __forceinline__ f16x8 lds_frag<f16>(const f16 *p) { return *(const f16x8 *)p; }
 template <> __device__ __forceinline__ f32x8 lds_frag<float>(const float *p) {
   f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
   f32x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -158,6 +187,7 @@ __device__ __forceinline__ void pp_signal(int *flag, int lane) {
 #endif
 template <typename T> struct PipeDepth { static constexpr int value = 4; };
 template <> struct PipeDepth<bf16> { static constexpr int value = BN_DEPTH_BF16; };
+template <> struct PipeDepth<f16> { static constexpr int value = BN_DEPTH_BF16; };
 
 template <typename T, int MT, int NTW, typename Side>
 __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, int ks0, int nks, const T *bsrc,
@@ -185,7 +215,24 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) B[mt] = lds_frag<T>(bl + (size_t)mt * 32 * ldb + ks * 16);
   };
-  auto step = [&](frag(&a)[NTW], int ks) {   // consumes Bc (fragments of k-step ks), leaves those of ks+1 in Bc
+#ifdef BN_AB_MFMA16
+  // Ablation (results WRONG by construction; profiles/ab_bench.sh): what would v_mfma_f32_16x16x32_bf16 buy through the
+  // clock the chip holds (MI355X_MICROARCH.md, DVFS give-back item 7)?  The same two operand registers go to two 16x16x32
+  // MFMAs per 32x32x16 one - equal FLOPs, equal matrix-pipe cycles, equal operand and accumulator register traffic per
+  // FLOP; every accumulator quad is written every second k-step - on accumulator quads held as separate 4-register values
+  // inside the loop (copied in and out around it), before fragment / accumulator / stash layouts are re-plumbed for it.
+  constexpr bool AB16 = std::is_same<T, bf16>::value;
+  f32x4 q[NTW][MT][4];
+  if (AB16) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[nt][mt][i] = f32x4{acc[nt][mt][4 * i], acc[nt][mt][4 * i + 1], acc[nt][mt][4 * i + 2], acc[nt][mt][4 * i + 3]};
+  }
+#endif
+  auto step = [&](frag(&a)[NTW], int ks, int par) {   // consumes Bc (fragments of k-step ks), leaves those of ks+1 in Bc
     frag Bn[MT];
 #ifdef BN_SKIP_B       // diagnostic variant: no LDS fragment reads after the first
 #pragma unroll
@@ -196,7 +243,16 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], a[nt], Bc[mt]);
+      for (int mt = 0; mt < MT; ++mt) {
+#ifdef BN_AB_MFMA16
+        if constexpr (AB16) {
+          q[nt][mt][2 * par] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], Bc[mt], q[nt][mt][2 * par], 0, 0, 0);
+          q[nt][mt][2 * par + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[mt], a[nt], q[nt][mt][2 * par + 1], 0, 0, 0);
+          continue;
+        }
+#endif
+        mma32(acc[nt][mt], a[nt], Bc[mt]);
+      }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) Bc[mt] = Bn[mt];
   };
@@ -208,7 +264,7 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
   for (; ks + DEPTH <= kend; ks += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      step(A[d], ks + d);
+      step(A[d], ks + d, d & 1);
       loadA(A[d], ks + d + DEPTH);
       side.at(d & 1);   // constant after unrolling
       __builtin_amdgcn_sched_barrier(0);
@@ -217,9 +273,19 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
     if (ks + d < kend) {
-      step(A[d], ks + d);
+      step(A[d], ks + d, d & 1);
       side.at(d & 1);
     }
+#ifdef BN_AB_MFMA16
+  if (AB16) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][mt][i] = q[nt][mt][i >> 2][i & 3];
+  }
+#endif
 }
 template <typename T, int MT, int NTW, typename Side>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb,
@@ -248,11 +314,36 @@ template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x16 (&acc
 template <int MT, int NTW> __device__ __forceinline__ size_t native_off8(int wave, int nt, int mt, int gp, int lane) {
   return ((((size_t)(wave * NTW + nt) * MT + mt) * 2 + gp) * 64 + lane) * 8;
 }
+// 8 floats -> one 16-bit fragment (round to nearest even), and the store of a ready-made fragment
+__device__ __forceinline__ bf16x8 cvt8(bf16, const float (&v)[8]) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
+  return o;
+}
+__device__ __forceinline__ f16x8 cvt8(f16, const float (&v)[8]) {
+  const f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+  return __builtin_convertvector(f, f16x8);
+}
+__device__ __forceinline__ f32x8 cvt8(float, const float (&v)[8]) {
+  const f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+  return f;
+}
+__device__ __forceinline__ void st_frag(bf16 *p, const bf16x8 &o) { stash_store((bf16x8 *)p, o); }
+__device__ __forceinline__ void st_frag(f16 *p, const f16x8 &o) { stash_store((f16x8 *)p, o); }
+__device__ __forceinline__ void st_frag(float *p, const f32x8 &o) {
+  stash_store((f32x4 *)p, f32x4{o[0], o[1], o[2], o[3]});
+  stash_store((f32x4 *)(p + 4), f32x4{o[4], o[5], o[6], o[7]});
+}
 __device__ __forceinline__ void st8(bf16 *p, const float (&v)[8]) {
   bf16x8 o;
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
   stash_store((bf16x8 *)p, o);
+}
+__device__ __forceinline__ void st8(f16 *p, const float (&v)[8]) {
+  const f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+  stash_store((f16x8 *)p, __builtin_convertvector(f, f16x8));
 }
 __device__ __forceinline__ void st8(float *p, const float (&v)[8]) {
   stash_store((f32x4 *)p, f32x4{v[0], v[1], v[2], v[3]});
@@ -260,6 +351,11 @@ __device__ __forceinline__ void st8(float *p, const float (&v)[8]) {
 }
 __device__ __forceinline__ void ld8(const bf16 *p, float (&v)[8]) {
   const bf16x8 o = stash_load((const bf16x8 *)p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)o[i];
+}
+__device__ __forceinline__ void ld8(const f16 *p, float (&v)[8]) {
+  const f16x8 o = stash_load((const f16x8 *)p);
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = (float)o[i];
 }

@@ -1,5 +1,6 @@
 // Fused Adam over one flat fp32 parameter buffer (torch.optim.Adam semantics, main.py:147-168:
 // lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0 by default; L2-style weight decay when non-zero).
+#include <math.h>
 #include "common.h"
 
 __global__ void adam_kernel(float *p, const float *g, float *m, float *v, int64_t n, float lr, float b1, float b2, float eps,
@@ -35,8 +36,9 @@ extern "C" int bn_adam_step(float *param, const float *grad, float *exp_avg, flo
   BN_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_step: bad arguments");
   BN_REQUIRE(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0,
              "adam_step: buffers must be 16-byte aligned");
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2 = 1.f - powf(beta2, (float)step);
+  // bias corrections in double on the host, like torch.optim.Adam (1 - beta2^step loses half its digits in fp32 early on)
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   const int64_t blocks = ceil_div64(ceil_div64(n, 4), 256);
   BnProfScope prof_(BN_K_ADAM, (hipStream_t)stream);
   adam_kernel<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), 256, 0, (hipStream_t)stream>>>(

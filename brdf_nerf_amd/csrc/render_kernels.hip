@@ -313,6 +313,7 @@ struct GuidedArgs {
   float near0, far0, d_range;
   float *z2_sorted, *z_all;
   int64_t *sort_idx;
+  const float *near_far;   // device [2] (near0, far0), e.g. &rays[0][6]; overrides the two scalars when set (no host read)
 };
 
 // in-LDS bitonic sort of n2 (power of two) (key, index) pairs by one wave; ties broken by index (= stable).
@@ -366,8 +367,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void guided_kernel(const Guid
   }
   // 2. symmetric 3-sigma window inside [near0, far0] (rendering.py:76-83)
   float lo = centre - A.d_range * std, hi = centre + A.d_range * std;
-  lo = fminf(fmaxf(lo, A.near0), A.far0);
-  hi = fminf(fmaxf(hi, A.near0), A.far0);
+  const float near0 = A.near_far ? A.near_far[0] : A.near0, far0 = A.near_far ? A.near_far[1] : A.far0;
+  lo = fminf(fmaxf(lo, near0), far0);
+  hi = fminf(fmaxf(hi, near0), far0);
   const float rng = fminf(fabsf(hi - centre), fabsf(lo - centre));
   lo = centre - rng;
   hi = centre + rng;
@@ -454,18 +456,37 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void guided_kernel(const Guid
   }
 }
 
+static int guided_samples_impl(const float *z, const float *weights, const float *depth, const float *u, int64_t R,
+                               int32_t S, int32_t G, float near0, float far0, const float *near_far, float d_range,
+                               const float *use_target, const float *target_depth, const float *target_std,
+                               const float *u_target, const int32_t *target_row, float *z2_sorted, float *z_all,
+                               int64_t *sort_idx, void *stream) {
+  BN_REQUIRE(z && weights && depth && u && z2_sorted && R > 0, "guided_samples: null argument");
+  BN_REQUIRE(G >= 3 && G <= BN_MAX_G && S >= 1 && S + G <= BN_MAX_SG, "guided_samples: S=%d G=%d unsupported", S, G);
+  BN_REQUIRE(!use_target || (target_depth && target_std && u_target && target_row), "guided_samples: target arrays");
+  GuidedArgs a = {z, weights, depth, u, use_target, target_depth, target_std, u_target, target_row, R, S, G,
+                  near0, far0, d_range, z2_sorted, z_all, sort_idx, near_far};
+  BnProfScope prof_(BN_K_GUIDED, (hipStream_t)stream);
+  guided_kernel<<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
+  BN_LAUNCH_CHECK("guided_samples");
+  return 0;
+}
+
 extern "C" int bn_guided_samples(const float *z, const float *weights, const float *depth, const float *u, int64_t R,
                                  int32_t S, int32_t G, float near0, float far0, float d_range, const float *use_target,
                                  const float *target_depth, const float *target_std, const float *u_target,
                                  const int32_t *target_row, float *z2_sorted, float *z_all, int64_t *sort_idx,
                                  void *stream) {
-  BN_REQUIRE(z && weights && depth && u && z2_sorted && R > 0, "guided_samples: null argument");
-  BN_REQUIRE(G >= 3 && G <= BN_MAX_G && S >= 1 && S + G <= BN_MAX_SG, "guided_samples: S=%d G=%d unsupported", S, G);
-  BN_REQUIRE(!use_target || (target_depth && target_std && u_target && target_row), "guided_samples: target arrays");
-  GuidedArgs a = {z, weights, depth, u, use_target, target_depth, target_std, u_target, target_row, R, S, G,
-                  near0, far0, d_range, z2_sorted, z_all, sort_idx};
-  BnProfScope prof_(BN_K_GUIDED, (hipStream_t)stream);
-  guided_kernel<<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
-  BN_LAUNCH_CHECK("guided_samples");
-  return 0;
+  return guided_samples_impl(z, weights, depth, u, R, S, G, near0, far0, nullptr, d_range, use_target, target_depth, target_std,
+                             u_target, target_row, z2_sorted, z_all, sort_idx, stream);
+}
+
+extern "C" int bn_guided_samples_nf(const float *z, const float *weights, const float *depth, const float *u, int64_t R,
+                                    int32_t S, int32_t G, const float *near_far, float d_range, const float *use_target,
+                                    const float *target_depth, const float *target_std, const float *u_target,
+                                    const int32_t *target_row, float *z2_sorted, float *z_all, int64_t *sort_idx,
+                                    void *stream) {
+  BN_REQUIRE(near_far, "guided_samples_nf: near_far is null");
+  return guided_samples_impl(z, weights, depth, u, R, S, G, 0.f, 0.f, near_far, d_range, use_target, target_depth, target_std,
+                             u_target, target_row, z2_sorted, z_all, sort_idx, stream);
 }

@@ -22,10 +22,19 @@ def batched_inference(models, rays, ts, args, mode="test", apply_brdf=False, app
     return {k: torch.cat(v, 0) for k, v in results.items()}
 
 
-def extract_model_state_dict(ckpt_path, model_name="model", prefixes_to_ignore=(), drop_len=-1):
+def extract_model_state_dict(ckpt_path, model_name="model", prefixes_to_ignore=(), drop_len=-1, trusted=False):
     """eval.py:26-47: keep the entries whose key starts with `model_name` and drop the first drop_len+1 characters
-    (drop_len = len(model_name) by default; main.py:97-104 passes 'nerf_coarse.<sub>' with drop_len=11 for partial warm starts)."""
-    checkpoint = torch.load(ckpt_path, map_location="cpu")
+    (drop_len = len(model_name) by default; main.py:97-104 passes 'nerf_coarse.<sub>' with drop_len=11 for partial warm starts).
+    Checkpoints written by the reference (Lightning 1.3) pickle callback classes and optimizer state next to the weights,
+    which torch's safe unpickler (the default of torch.load since 2.6) refuses: pass trusted=True for files you trust."""
+    try:
+        checkpoint = torch.load(ckpt_path, map_location="cpu", weights_only=not trusted)
+    except Exception as e:      # pickle.UnpicklingError from the safe unpickler
+        if trusted:
+            raise
+        raise RuntimeError(f"{ckpt_path}: not loadable with weights_only=True ({type(e).__name__}: {str(e)[:200]}). A Lightning "
+                           f"checkpoint of the reference carries pickled callback / optimizer objects: pass trusted=True "
+                           f"(load_ckpt(..., trusted=True)) if you trust the file.") from e
     sd = checkpoint["state_dict"] if "state_dict" in checkpoint else checkpoint
     if drop_len < 0:
         drop_len = len(model_name)
@@ -40,10 +49,10 @@ def extract_model_state_dict(ckpt_path, model_name="model", prefixes_to_ignore=(
     return out
 
 
-def load_ckpt(model, ckpt_path, model_name="model", prefixes_to_ignore=(), drop_len=-1):
+def load_ckpt(model, ckpt_path, model_name="model", prefixes_to_ignore=(), drop_len=-1, trusted=False):
     """eval.py:49-54: partial load (strict=False semantics of updating the model's own state_dict)."""
     sd = model.state_dict()
-    sd.update(extract_model_state_dict(ckpt_path, model_name, prefixes_to_ignore, drop_len))
+    sd.update(extract_model_state_dict(ckpt_path, model_name, prefixes_to_ignore, drop_len, trusted))
     model.load_state_dict(sd)
     return model
 

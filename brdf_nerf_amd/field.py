@@ -166,7 +166,9 @@ class SpSBRDFNeRF(nn.Module):
         return heads
 
     def spec(self, apply_brdf=False, apply_theta=False, nr_lr_on=False, nr_an_on=False):
-        dtype = L.BN_BF16 if self.compute_dtype == "bf16" else L.BN_F32
+        if self.compute_dtype not in L.DTYPES:
+            raise ValueError(f"compute_dtype {self.compute_dtype!r}: expected one of {sorted(L.DTYPES)}")
+        dtype = L.DTYPES[self.compute_dtype]
         key = (bool(apply_brdf), bool(apply_theta), bool(nr_lr_on), bool(nr_an_on), dtype)
         if key not in self._specs:
             skip = self.skips[0] if self.skips and 0 < self.skips[0] < self.layers else -1   # --fc_layers <= 4: no skip layer

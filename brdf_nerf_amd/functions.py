@@ -380,12 +380,20 @@ def stratified_z(near, far, u):
 
 def guided_samples(z, weights, depth, u, near0, far0, d_range, use_target=None, target_depth=None, target_std=None,
                    u_target=None, target_row=None, merge=True):
+    """near0 may be a device tensor holding (near0, far0) as two consecutive floats - e.g. rays[0, 6:8] - with far0 = None:
+    the kernel then reads the clamp window itself (no device->host read)."""
     R, S = z.shape
     G = u.shape[1]
     dev = z.device
     z2 = torch.empty(R, G, dtype=torch.float32, device=dev)
     z_all = torch.empty(R, S + G, dtype=torch.float32, device=dev) if merge else None
     idx = torch.empty(R, S + G, dtype=torch.int64, device=dev) if merge else None
+    if torch.is_tensor(near0):
+        assert far0 is None and near0.is_cuda and near0.dtype == torch.float32 and near0.numel() == 2 and near0.is_contiguous()
+        L.check(L.lib().bn_guided_samples_nf(_p(z), _p(weights), _p(depth), _p(u), R, S, G, C.c_void_p(near0.data_ptr()),
+                                             float(d_range), _p(use_target), _p(target_depth), _p(target_std), _p(u_target),
+                                             _p(target_row), _p(z2), _p(z_all), _p(idx), _stream()), "bn_guided_samples_nf")
+        return z2, z_all, idx
     L.check(L.lib().bn_guided_samples(_p(z), _p(weights), _p(depth), _p(u), R, S, G, float(near0), float(far0),
                                       float(d_range), _p(use_target), _p(target_depth), _p(target_std), _p(u_target),
                                       _p(target_row), _p(z2), _p(z_all), _p(idx), _stream()), "bn_guided_samples")

@@ -19,6 +19,15 @@ def l2_normalize(x):
     return x / torch.sqrt(torch.clamp_min((x * x).sum(-1, keepdim=True), FP32_EPS))
 
 
+def sun_far(depth, rays_d, sun_d):
+    """far bound of the sun-visibility pass (rendering.py:246-248): depth scaled by |d_z / sun_z| of ROW 0 (fp32 tensor
+    arithmetic like upstream, without its host read)."""
+    far_sun = depth.clone().unsqueeze(-1)
+    s0, r0 = sun_d[0, 2], rays_d[0, 2]
+    ratio = torch.where(s0.abs() > 0.00001, (r0 / s0).abs(), torch.ones_like(s0))
+    return ratio * far_sun
+
+
 def get_z_vals(N_samples, device, near, far, use_disp=False, perturb=1.0):
     if use_disp or perturb != 1.0:
         raise NotImplementedError("render path always uses linear depth with perturb=1 (rendering.py:175)")
@@ -141,7 +150,7 @@ def shade(model, args, spec, out, z_vals, alphas, transparency, weights, depth, 
         kind = "Hapke"
     if kind is not None:
         if normal is None:
-            raise RuntimeError("BRDF shading needs a normal (--normal learned); analytic normals are not implemented")
+            raise RuntimeError("BRDF shading needs a normal field (--normal learned | analystic | analystic_learned)")
         brdf_type = kind
         if model.MultiBRDF:
             rep = lambda t: t.repeat_interleave(S, 0)
@@ -237,9 +246,7 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
             raise NotImplementedError("--sun_v analystic needs gsam_only=True: with the merged S+G sample set the reference "
                                       "raises a shape error in pass 2 (SURVEY quirk 2)")
         with torch.no_grad():
-            far_sun = d1.clone().unsqueeze(-1)
-            if abs(float(sun_d[0, 2])) > 0.00001:
-                far_sun = abs(float(rays_d[0, 2]) / float(sun_d[0, 2])) * far_sun
+            far_sun = sun_far(d1, rays_d, sun_d)
             z_sun = get_z_vals(G, rays.device, far_sun * 0.01, far_sun)
             sun_rays = torch.cat([rays[:, 0:3] + rays_d * d1.unsqueeze(-1), sun_d], -1).contiguous()
             rs, _ = inference(model, args, None, z_sun, rays_d=sun_d, mode=mode, sigma_only=True, _rays=sun_rays, _packed=packed)
@@ -249,7 +256,10 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
     use_t = tdep = tstd = u_t = trow = None
     if mode == "train" and valid_depth is not None:
         valid = (valid_depth > 0)
-        n_valid = int(valid.sum())            # one host sync per step; the reference does three (np.where(...cpu()))
+        # the reference draws rand(n_valid, G): the SHAPE of that draw is data dependent, so replaying its random stream
+        # needs n_valid on the host (one sync; the reference does three via np.where(...cpu())).  The fused training step
+        # draws (R, G) and indexes it by the valid-row rank instead: same distribution, no sync (trainer.py).
+        n_valid = int(valid.sum())
         if n_valid > 0:
             u_t = torch.rand(n_valid, G, device=rays.device)
             use_t = valid.float().contiguous()
@@ -257,7 +267,8 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
             tstd = target_std.float().reshape(-1).contiguous()
             trow = (torch.cumsum(valid.int(), 0) - 1).clamp_min(0).int().contiguous()
     with torch.no_grad():
-        z2, z_all, idx = Fn.guided_samples(z_vals, w1, d1, u, float(near[0, 0]), float(far[0, 0]), args.std_range, use_t, tdep,
+        # the clamp window is the FIRST ray's (near, far) (rendering.py:133,144): read by the kernel from rays[0, 6:8]
+        z2, z_all, idx = Fn.guided_samples(z_vals, w1, d1, u, rays[0, 6:8], None, args.std_range, use_t, tdep,
                                            tstd, u_t, trow, merge=not gsam_only)
     if gsam_only:
         result, brdf_type = inference(model, args, None, z2, rays_d=rays_d, sun_d=sun_d, z_vals_unsort=z2, apply_brdf=apply_brdf,

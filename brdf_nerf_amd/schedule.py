@@ -22,7 +22,11 @@ class StageSchedule:
         self.cos_irra_on = _round_half_even(getattr(args, "cos_irra_on", 1.0) * m)
         self.depth = getattr(args, "ds_lambda", 0.0) > 0
         self.ds_drop = _round_half_even(getattr(args, "ds_drop", 1.0) * m) if self.depth else 0.0
-        self.steps_per_epoch = max(1, n_train_rays // args.batch_size)
+        self.steps_per_epoch = max(1, n_train_rays // args.batch_size)      # get_current_epoch's divisor (train_utils.py:117-118)
+        # optimiser steps per pass over the data: Lightning gives every rank a DistributedSampler share of ceil(N / world)
+        # rays, i.e. ceil(N / (B world)) batches per epoch - the unit StepLR(interval='epoch') ticks in (main.py:161-167),
+        # and the number of global batches RayTable serves per permutation
+        self.lr_steps_per_epoch = max(1, -(-n_train_rays // (args.batch_size * self.world)))
         self.train_steps = 0
         self.lr0 = args.lr
         # Lightning stops after max_steps optimiser steps (main.py:718)
@@ -36,9 +40,10 @@ class StageSchedule:
         return self.epoch_of(self.train_steps)
 
     def lr(self, optimiser_steps_done):
-        """StepLR(step_size=1, gamma=0.9), interval 'epoch': the scheduler ticks once per finished pass over the loader,
-        i.e. per `steps_per_epoch` OPTIMISER steps (not train_steps, which count GPUs)."""
-        return self.lr0 * 0.9 ** (optimiser_steps_done // self.steps_per_epoch)
+        """StepLR(step_size=1, gamma=0.9), interval 'epoch': the scheduler ticks once per finished pass over a rank's
+        loader, i.e. per `lr_steps_per_epoch` OPTIMISER steps - with W GPUs an epoch is W times shorter, so the rate
+        decays W times faster per step, as upstream under DDP."""
+        return self.lr0 * 0.9 ** (optimiser_steps_done // self.lr_steps_per_epoch)
 
     def begin_step(self):
         """Advance the counters for one optimisation step and return the flags the step runs with."""

@@ -20,10 +20,12 @@ from .trainer import FusedTrainer
 
 
 class TrainLoop:
-    def __init__(self, args, table, device=None, compute_dtype=None, process_group=None, near_far=None):
+    def __init__(self, args, table, device=None, compute_dtype=None, process_group=None, near_far=None, trusted_ckpts=False):
         """near_far: the (near, far) pair the guided-sampling clamp uses (rendering.py:133 reads row 0 of the batch;
         satellite batches share one pair per image) - pass it to keep the step free of device->host reads."""
         self.args, self.table, self.near_far = args, table, near_far
+        # trusted_ckpts: --in_ckpts points at a checkpoint written by the reference (Lightning pickles callback objects
+        # beside the weights; torch's safe loader refuses those unless the caller vouches for the file)
         self.rank, self.world = world_info()
         dev = torch.device(device) if device is not None else table.device
         self.model = load_model(args, compute_dtype).to(dev)
@@ -31,7 +33,7 @@ class TrainLoop:
         if in_ckpts != "none":                              # stage-2 warm start of the shared sub-modules (main.py:97-104)
             subs = ["fc_net", "sigma_from_xyz", "feats_from_xyz"] + ([] if args.b == True else ["rgb_from_xyzdir"])  # noqa: E712
             for sub in subs:
-                load_ckpt(self.model, in_ckpts, model_name=f"nerf_coarse.{sub}", drop_len=11)
+                load_ckpt(self.model, in_ckpts, model_name=f"nerf_coarse.{sub}", drop_len=11, trusted=trusted_ckpts)
         g = lambda k, d=0.0: getattr(args, k, d)
         self.trainer = FusedTrainer(self.model, args, lr=args.lr, lambda_rgb=g("lambda_rgb", 1.0), ds_lambda=g("ds_lambda"),
                                     usealldepth=bool(g("usealldepth", False)), process_group=process_group, strict_rng=False,
@@ -75,8 +77,9 @@ class TrainLoop:
         for i in range(n):
             out = self.step()
             if log_every and (i + 1) % log_every == 0 and self.rank == 0:
+                nan, inf = self.trainer.dropped_grad_elems()
                 print(f"step {self.global_step} epoch {out['epoch']} loss {float(out['loss']):.5f} "
-                      f"psnr {float(out['psnr']):.2f} lr {out['lr']:.2e}", flush=True)
+                      f"psnr {float(out['psnr']):.2f} lr {out['lr']:.2e} dropped non-finite gradient elements {nan}+{inf}", flush=True)
         return self.last
 
     # ------------------------------------------------------------------ checkpoints
@@ -87,7 +90,7 @@ class TrainLoop:
         ckpt = {"state_dict": {f"nerf_coarse.{k}": v.detach().clone() for k, v in self.model.state_dict().items()},
                 "epoch": self.schedule.epoch, "global_step": self.global_step,
                 "fused_trainer": {"exp_avg": tr.exp_avg.clone(), "exp_avg_sq": tr.exp_avg_sq.clone(),
-                                  "steps_a": tr.steps_a, "steps_b": tr.steps_b},
+                                  "adam_steps": dict(tr.adam_steps)},
                 "schedule": self.schedule.state_dict(), "ray_table": self.table.state_dict()}
         path = os.path.join(ckpts_dir, f"epoch={self.schedule.epoch}.ckpt")
         torch.save(ckpt, path)
@@ -104,7 +107,10 @@ class TrainLoop:
         tr = self.trainer
         ft = ckpt["fused_trainer"]
         tr.exp_avg.copy_(ft["exp_avg"]); tr.exp_avg_sq.copy_(ft["exp_avg_sq"])
-        tr.steps_a, tr.steps_b = ft["steps_a"], ft["steps_b"]
+        if "adam_steps" in ft:
+            tr.adam_steps.update({k: int(v) for k, v in ft["adam_steps"].items() if k in tr.adam_steps})
+        else:                                        # round-1 checkpoints: two counters (base / everything else)
+            tr.adam_steps = {k: int(ft["steps_a"] if k == "base" else ft["steps_b"]) for k in tr.adam_steps}
         self.schedule.load_state_dict(ckpt["schedule"])
         self.table.load_state_dict(ckpt["ray_table"])
         self.global_step = int(ckpt["global_step"])

@@ -11,13 +11,14 @@ import torch
 
 from . import functions as Fn
 from . import losses
-from .rendering import shade, get_z_vals, inference
+from .distributed import allreduce_sum_
+from .rendering import shade, get_z_vals, inference, sun_far
 
 
 class FusedTrainer:
     def __init__(self, model, args, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lambda_rgb=1.0, ds_lambda=0.0,
                  usealldepth=False, process_group=None, strict_rng=True, reuse_coarse=True, nr_reg_an_lambda=0.0,
-                 nr_reg_lr_lambda=0.0, hs_lambda=0.0, nr_spv_lambda=0.0):
+                 nr_reg_lr_lambda=0.0, hs_lambda=0.0, nr_spv_lambda=0.0, data_parallel=True):
         """The regulariser lambdas are the reference's --nr_reg_an_lambda / --nr_reg_lr_lambda / --hs_lambda /
         --nr_spv_lambda (opt.py:232-246, all 0 by default); WHEN they act (train_steps > nrrg_on, epoch > 2, main.py:271-327)
         is the caller's schedule: pass regularisers=False to step() until then."""
@@ -32,27 +33,42 @@ class FusedTrainer:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.lambda_rgb, self.ds_lambda, self.usealldepth = lambda_rgb, ds_lambda, usealldepth
         self.pg, self.strict_rng, self.reuse_coarse = process_group, strict_rng, reuse_coarse
+        # data_parallel=False: a purely local trainer even inside an initialised process group (reference runs in tests)
         self.world = 1
-        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        if data_parallel and (process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())):
             self.world = torch.distributed.get_world_size(process_group)
         self.nr_lr = model.normal in ("analystic_learned", "learned")
         self.nr_an = model.normal in ("analystic_learned", "analystic")
         self._flatten()
-        self.steps_a = self.steps_b = 0
         self._bufs = {}
+        # sanitize_grads bookkeeping: NaN / Inf elements of d(loss)/d(per-sample outputs) zeroed so far, counted on the
+        # device (bn_count_nonfinite, no host round trip); read it with dropped_grad_elems()
+        self._nonfinite = torch.zeros(2, dtype=torch.int64, device=self.flat_param.device)
 
     # ------------------------------------------------------------------ flat parameter / gradient storage
     def _flatten(self):
+        """One flat fp32 buffer, in Adam GROUPS: [base | BRDF heads | theta head].  torch.optim.Adam (the reference's
+        optimiser) skips a parameter whose grad is None and keeps a step counter per parameter, so a head that joins the
+        graph later (BRDF heads at brdf_on, Hapke's theta head at 2 * brdf_on, main.py:207-210) starts its bias
+        corrections at step 1 then: every group has its own counter and is stepped only while it is in the graph."""
         model = self.model
         named = dict(model.named_parameters())
         base = set(model.spec(False, False, self.nr_lr).used_param_names())
-        order = [n for n in named if n in base] + [n for n in named if n not in base]
+        theta = {n for n in named if n.startswith("theta_from_xyz.")}
+        groups = [("base", [n for n in named if n in base]),
+                  ("brdf", [n for n in named if n not in base and n not in theta]),
+                  ("theta", [n for n in named if n in theta])]
         offs, tot = {}, 0
-        for n in order:
-            offs[n] = tot
-            tot += (named[n].numel() + 3) // 4 * 4
-            if n in base:
-                self.n_base = tot
+        self.groups = []                               # (name, lo, hi) element ranges of the flat buffer
+        for gname, names in groups:
+            lo = tot
+            for n in names:
+                offs[n] = tot
+                tot += (named[n].numel() + 3) // 4 * 4
+            if tot > lo:
+                self.groups.append((gname, lo, tot))
+        self.n_base = self.groups[0][2]
+        self.adam_steps = {gname: 0 for gname, _, _ in self.groups}
         dev = next(model.parameters()).device
         self.flat_param = torch.zeros(tot, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros_like(self.flat_param)
@@ -60,12 +76,30 @@ class FusedTrainer:
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.grad_views = {}
         with torch.no_grad():
-            for n in order:
-                p, o = named[n], offs[n]
-                view = self.flat_param[o:o + p.numel()].view(p.shape)
-                view.copy_(p.data)
-                p.data = view                     # the module's parameters now alias the flat buffer
-                self.grad_views[n] = self.flat_grad[o:o + p.numel()].view(p.shape)
+            for _, names in groups:
+                for n in names:
+                    p, o = named[n], offs[n]
+                    view = self.flat_param[o:o + p.numel()].view(p.shape)
+                    view.copy_(p.data)
+                    p.data = view                     # the module's parameters now alias the flat buffer
+                    self.grad_views[n] = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    # kept for checkpoints written by round 1 (two counters: base / everything else)
+    @property
+    def steps_a(self):
+        return self.adam_steps["base"]
+
+    @property
+    def steps_b(self):
+        return self.adam_steps.get("brdf", self.adam_steps.get("theta", 0))
+
+    def dropped_grad_elems(self):
+        """(NaN, Inf) elements of the per-sample output gradients zeroed by sanitize_grads since construction (host read)."""
+        return tuple(int(v) for v in self._nonfinite.tolist())
+
+    @property
+    def dropped_samples(self):
+        return sum(self.dropped_grad_elems())
 
     def _buf(self, key, shape, dtype=torch.float32):
         b = self._bufs.get(key)
@@ -114,9 +148,7 @@ class FusedTrainer:
                 if not gsam_only:
                     raise NotImplementedError("--sun_v analystic needs gsam_only=True (SURVEY quirk 2: the reference raises a "
                                               "shape error with the merged S+G sample set)")
-                far_sun = d1.clone().unsqueeze(-1)
-                if abs(float(sun_d[0, 2])) > 0.00001:
-                    far_sun = abs(float(rays_d[0, 2]) / float(sun_d[0, 2])) * far_sun
+                far_sun = sun_far(d1, rays_d, sun_d)
                 z_sun = get_z_vals(G, dev, far_sun * 0.01, far_sun)
                 sun_rays = torch.cat([rays[:, 0:3] + rays_d * d1.unsqueeze(-1), sun_d], -1).contiguous()
                 rs, _ = inference(model, args, None, z_sun, rays_d=sun_d, mode="train", sigma_only=True, _rays=sun_rays,
@@ -134,9 +166,9 @@ class FusedTrainer:
                 tdep = depths[:, 0].float().contiguous()
                 tstd = depth_std.float().reshape(-1).contiguous()
                 trow = (torch.cumsum(valid.int(), 0) - 1).clamp_min(0).int().contiguous()
-            # the clamp window is the FIRST ray's (near, far) (rendering.py:133); satellite batches share one pair, so
-            # callers pass it to avoid a device->host read per step
-            near0, far0 = near_far if near_far is not None else (float(rays[0, 6]), float(rays[0, 7]))
+            # the clamp window is the FIRST ray's (near, far) (rendering.py:133): read on the device from rays[0, 6:8]
+            # unless the caller passes the pair
+            near0, far0 = near_far if near_far is not None else (rays[0, 6:8], None)
             z2, z_all, idx = Fn.guided_samples(z, w1, d1, u, near0, far0, args.std_range, use_t, tdep, tstd, u_t, trow,
                                                merge=not gsam_only)
             if gsam_only:
@@ -161,6 +193,7 @@ class FusedTrainer:
                       and sun_res is None)
         n_leaf = {}                                   # channel offset -> per-sample normal leaf
         grads = ()
+        d_out3 = None
         if lambertian and self.fused_glue:
             # Lambertian step: shading + SNerfLoss + DepthLoss + their gradients in ONE launch (bn_lambert_loss)
             use_ds = self.ds_lambda > 0 and depth_loss_on and valid_depth is not None
@@ -174,7 +207,12 @@ class FusedTrainer:
             # ray-level loss glue under autograd (leaves: acc, depth, weights; the per-sample normals too when a regulariser
             # reads them)
             acc_l, depth_l, weights_l = acc.requires_grad_(True), depth.requires_grad_(True), weights.requires_grad_(True)
-            res, _ = shade(model, args, spec, out3, z_all, alphas, trans, weights_l, depth_l, acc_l, rays_d, sun_d, apply_brdf,
+            # shade() reads PER-SAMPLE channels of the field output when every sample has its own BRDF (--MultiBRDF,
+            # spsbrdfnerf.py:289-307,350-352) or its own sun visibility (:265-273): the loss then depends on out3 directly,
+            # not only through the composited sums, so out3 is a leaf as well and its gradient joins d_out below
+            per_sample = (bool(model.MultiBRDF) and apply_brdf) or sun_res is not None
+            out3_l = out3.detach().requires_grad_(True) if per_sample else out3
+            res, _ = shade(model, args, spec, out3_l, z_all, alphas, trans, weights_l, depth_l, acc_l, rays_d, sun_d, apply_brdf,
                            cos_irra_on, sun_res=sun_res)
             loss = losses.snerf_loss(res["rgb"], rgbs, self.lambda_rgb)
             if self.ds_lambda > 0 and depth_loss_on and valid_depth is not None:
@@ -193,11 +231,15 @@ class FusedTrainer:
                 loss = loss + losses.hard_surface_loss(z_all, depth_l, weights_l, reg["hs"])
             if abs(reg.get("nr_spv", 0)) > 1e-5 and spec.normal_an and spec.normal_lr:   # nr_spv_type 1 (main.py:297-303)
                 loss = loss + losses.normal_loss(weights_l, normal_leaf("normal_an"), normal_leaf("normal_lr"), reg["nr_spv"])
-            leaves = [acc_l, depth_l, weights_l] + list(n_leaf.values())
+            leaves = [acc_l, depth_l, weights_l] + list(n_leaf.values()) + ([out3_l] if per_sample else [])
             grads = torch.autograd.grad(loss, leaves, allow_unused=True)
             d_acc, d_depth, d_weights = grads[:3]
+            d_out3 = grads[-1] if per_sample else None
+            grads = grads[:3 + len(n_leaf)]
         with torch.no_grad():
-            if d_acc is not None:
+            if d_acc is None:      # nothing read the composited sums: the kernel must still write (zero) channel gradients
+                d_acc = torch.zeros(R, C, dtype=torch.float32, device=dev)
+            else:
                 d_acc = d_acc.contiguous()
                 d_acc[:, 3] = 0
             d_out = Fn.composite_backward_raw(z_all, out3, None if d_weights is None else d_weights.contiguous(),
@@ -206,7 +248,12 @@ class FusedTrainer:
             for c0, dn in zip(n_leaf.keys(), grads[3:]):
                 if dn is not None:
                     d_out[..., c0:c0 + 3] += dn          # regulariser gradients on the per-sample normals
+            if not (lambertian and self.fused_glue) and d_out3 is not None:
+                d_out3 = d_out3.clone()
+                d_out3[..., 3] = 0                       # sigma acts through the compositing only (already in d_out)
+                d_out += d_out3                          # per-sample shading terms (MultiBRDF / per-sample sun visibility)
             if self.sanitize_grads and not (lambertian and self.fused_glue):
+                Fn.count_nonfinite(d_out, self._nonfinite)
                 torch.nan_to_num_(d_out, nan=0.0, posinf=0.0, neginf=0.0)
             self.flat_grad.zero_()
             if reuse:
@@ -217,17 +264,16 @@ class FusedTrainer:
             else:
                 Fn.field_backward_raw(spec, named, self.grad_views, packed, out, d_out.view(R * S2, C), stash, rays=rays, z=z_all)
             if self.world > 1:
-                torch.distributed.all_reduce(self.flat_grad, group=self.pg)   # RCCL over xGMI: one ~10 MB buffer
-            self._adam(apply_brdf)
+                allreduce_sum_(self.flat_grad, self.pg)       # RCCL over xGMI: ONE collective over the ~10 MB flat buffer
+            self._adam(apply_brdf, apply_theta)
         return loss.detach(), res["rgb"].detach()
 
-    def _adam(self, apply_brdf):
+    def _adam(self, apply_brdf, apply_theta=False):
         scale = 1.0 / self.world          # DDP averages gradients
-        nb = self.n_base
-        self.steps_a += 1
-        Fn.adam_step(self.flat_param[:nb], self.flat_grad[:nb], self.exp_avg[:nb], self.exp_avg_sq[:nb], self.steps_a, self.lr,
-                     self.betas, self.eps, self.wd, scale)
-        if apply_brdf and self.flat_param.numel() > nb:
-            self.steps_b += 1
-            Fn.adam_step(self.flat_param[nb:], self.flat_grad[nb:], self.exp_avg[nb:], self.exp_avg_sq[nb:], self.steps_b,
-                         self.lr, self.betas, self.eps, self.wd, scale)
+        on = {"base": True, "brdf": bool(apply_brdf), "theta": bool(apply_brdf and apply_theta)}
+        for gname, lo, hi in self.groups:
+            if not on[gname]:
+                continue                  # not in this step's graph: torch.optim.Adam would see grad None and skip it
+            self.adam_steps[gname] += 1
+            Fn.adam_step(self.flat_param[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                         self.adam_steps[gname], self.lr, self.betas, self.eps, self.wd, scale)

@@ -19,7 +19,10 @@
  *    (train_utils.py:61-78) in-kernel, without its prints and host syncs.
  *  - `dtype`: BN_F32 computes the MLP with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32; parity
  *    mode, 1e-4 relative vs the reference), BN_BF16 with bf16 MFMA (v_mfma_f32_32x32x16_bf16,
- *    fp32 accumulate; throughput mode).  Everything outside the dense layers is fp32.
+ *    fp32 accumulate; throughput mode), BN_F16 with fp16 MFMA (v_mfma_f32_32x32x16_f16, fp32
+ *    accumulate; same rate as bf16, 3 more mantissa bits; the backward chains run on gradients
+ *    scaled by a power of two chosen on the device from max|d_out|, removed again before the
+ *    fp32 gradient accumulation - BASELINE config 5).  Everything outside the dense layers is fp32.
  */
 #ifndef BRDFNERF_HIP_H
 #define BRDFNERF_HIP_H
@@ -36,7 +39,7 @@ extern "C" {
 #define BN_MAX_HEADS 4 /* rgb + up to 3 BRDF heads evaluated together */
 
 typedef enum { BN_OK = 0, BN_EINVAL = -1, BN_EUNSUPPORTED = -2, BN_ELAUNCH = -3 } bn_status;
-typedef enum { BN_F32 = 0, BN_BF16 = 1 } bn_dtype;
+typedef enum { BN_F32 = 0, BN_BF16 = 1, BN_F16 = 2 } bn_dtype;
 typedef enum { BN_ACT_SIN = 0, BN_ACT_RELU = 1 } bn_act;
 /* post-sigmoid rescale of a head (spsbrdfnerf.py:730,735,754) */
 typedef enum {
@@ -187,6 +190,13 @@ int bn_guided_samples(const float *z, const float *weights, const float *depth, 
                       int32_t S, int32_t G, float near0, float far0, float d_range, const float *use_target,
                       const float *target_depth, const float *target_std, const float *u_target,
                       const int32_t *target_row, float *z2_sorted, float *z_all, int64_t *sort_idx, void *stream);
+
+/* The same with the clamp window read on the device: near_far -> two floats (near0, far0), e.g. &rays[0][6] for
+ * the reference's `near[0,0]`, `far[0,0]` (rendering.py:133,144) - no device->host read in the caller. */
+int bn_guided_samples_nf(const float *z, const float *weights, const float *depth, const float *u, int64_t R,
+                         int32_t S, int32_t G, const float *near_far, float d_range, const float *use_target,
+                         const float *target_depth, const float *target_std, const float *u_target,
+                         const int32_t *target_row, float *z2_sorted, float *z_all, int64_t *sort_idx, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-ray BRDF shading (eval_RPV / eval_Hapke / eval_microfacet_brdf, models/spsbrdfnerf.py:9-30;

@@ -316,10 +316,16 @@ def test_field_forward_oracle_fp32(feat, B):
     assert_close(got, ref, 1e-4, 2e-5, f"F={feat}")
 
 
-def test_field_forward_bf16_close():
-    """bf16 throughput mode: per-point outputs within 3e-2 absolute of the fp32 oracle at F=512 (stated bound)."""
+# stated bounds of the 16-bit throughput modes against the fp32 oracle at F=512 (their acceptance criterion is the held-out
+# PSNR gate further down): bf16 keeps 8 significant bits, fp16 11 - its bounds are 6x tighter.
+HALF_BOUNDS = {"bf16": dict(rgb=3e-2, sig=0.15, cos=0.98, ncos=0.98), "fp16": dict(rgb=5e-3, sig=0.025, cos=0.999, ncos=0.9995)}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_field_forward_half_close(dtype):
+    """16-bit throughput modes: per-point outputs within the stated absolute bound of the fp32 oracle at F=512."""
     cfg = FieldConfig(funcM=1, funcF=1, funcH=1, normal="learned")
-    model = build_model(cfg, 3, "bf16")
+    model = build_model(cfg, 3, dtype)
     p = tparams(cfg, 3)
     xyz = torch.rand(2000, 3, generator=torch.Generator().manual_seed(5)) * 2 - 1
     ref = OF.field_forward(p, cfg, xyz, apply_brdf=True, nr_lr_on=True)
@@ -327,8 +333,10 @@ def test_field_forward_bf16_close():
         got = model(xyz.to(DEV), apply_brdf=True, nr_lr_on=True).cpu()
     err = (got - ref).abs()
     sig_rel = (err[:, 3] / (ref[:, 3].abs() + 1e-2)).max()
-    print("bf16 max abs err per channel", err.max(0)[0])
-    assert float(err[:, :3].max()) < 3e-2 and float(sig_rel) < 0.15
+    diag(f"{dtype} field forward F512: max abs err rgb {float(err[:, :3].max()):.3e}, sigma rel {float(sig_rel):.3e}, "
+         f"heads {float(err[:, 7:].max()):.3e}")
+    b = HALF_BOUNDS[dtype]
+    assert float(err[:, :3].max()) < b["rgb"] and float(sig_rel) < b["sig"]
 
 
 def _field_grads(cfg, seed, compute_dtype, B, heads_flags):
@@ -436,17 +444,50 @@ def test_field_other_depths_fp32(layers):
         assert err <= 5e-4 * scale + 1e-7, f"{k}: err {err:.3e} scale {scale:.3e}"
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("feat", [512, 256])
-def test_field_backward_bf16_direction(feat):
-    """bf16 gradients: cosine similarity with the fp32 oracle gradient >= 0.98 per weight matrix (stated bound)."""
+def test_field_backward_half_direction(feat, dtype):
+    """16-bit gradients: cosine similarity with the fp32 oracle gradient per weight matrix above the stated bound."""
     cfg = FieldConfig(feat=feat)
-    model, p, out, ref = _field_grads(cfg, 4, "bf16", 1024, {})
+    model, p, out, ref = _field_grads(cfg, 4, dtype, 1024, {})
+    worst = 1.0
     for k, v in model.named_parameters():
         want = p[k].grad.flatten()
         got = v.grad.cpu().flatten()
+        assert bool(torch.isfinite(got).all()), k
         cos = float((want * got).sum() / (want.norm() * got.norm() + 1e-30))
-        print(k, "cos", cos)
-        assert cos > 0.98, f"{k}: cosine {cos}"
+        worst = min(worst, cos)
+        assert cos > HALF_BOUNDS[dtype]["cos"], f"{k}: cosine {cos}"
+    diag(f"{dtype} field backward F{feat}: worst gradient cosine vs fp32 oracle {worst:.6f}")
+
+
+@pytest.mark.parametrize("name", ["lambert", "rpv111_nan"])
+def test_fp16_loss_scaling_is_scale_free(name):
+    """fp16 has 5 exponent bits: the backward chains run on gradients scaled by a power of two chosen on the device from
+    max |d_out| (grad_amax_kernel).  Upstream gradients 1e-7 times smaller (deep in fp16's subnormals without the
+    scaling) or 1e+4 times larger (beyond its maximum) must give the same parameter gradients up to that factor -
+    through the primal chain and through the analytic-normal double backward."""
+    cfg = FieldConfig(**(dict(funcM=1, funcF=1, funcH=1, normal="analystic") if name == "rpv111_nan" else {}))
+    flags = dict(apply_brdf=True, nr_an_on=True) if name == "rpv111_nan" else {}
+    model = build_model(cfg, 6, "fp16")
+    g = torch.Generator().manual_seed(3)
+    xyz = (torch.rand(1500, 3, generator=g) * 2 - 1).to(DEV)
+    coef = None
+    grads = {}
+    for scale in (1.0, 1e-7, 1e4):
+        model.zero_grad()
+        out = model(xyz, **flags)
+        if coef is None:
+            coef = torch.randn(out.shape, generator=g).to(DEV)
+        (out * coef * scale).sum().backward()
+        grads[scale] = {k: v.grad.clone() / scale for k, v in model.named_parameters() if v.grad is not None}
+    for scale in (1e-7, 1e4):
+        for k, g0 in grads[1.0].items():
+            g1 = grads[scale][k]
+            assert bool(torch.isfinite(g1).all()), (k, scale)
+            ref_mag = float(g0.abs().max())
+            err = float((g1 - g0).abs().max())
+            assert err <= 4e-3 * ref_mag + 1e-12, f"{k} at upstream scale {scale:g}: err {err:.3e} of {ref_mag:.3e}"
 
 
 @pytest.mark.parametrize("name", ["lambert", "rpv111_nlr"])
@@ -477,12 +518,13 @@ def test_feats_folding_is_the_same_function(name):
         assert float((res["1"][1][k] - g0).abs().max()) <= 2e-4 * scale + 1e-8, k
 
 
-def test_bf16_forward_variants_agree_and_repeat():
-    """The bf16 trunk runs without workgroup barriers (two wave groups hand columns over through LDS counters): the
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_half_forward_variants_agree_and_repeat(dtype):
+    """The 16-bit trunk runs without workgroup barriers (two wave groups hand columns over through LDS counters): the
     repeated launches must give the same bits, and the inference and training (stash-keeping) variants - two
     instantiations whose fp32 head sums the compiler may contract differently - the same values to fp32 rounding."""
     cfg = FieldConfig(funcM=1, funcF=1, funcH=1, normal="learned")
-    model = build_model(cfg, 9, "bf16")
+    model = build_model(cfg, 9, dtype)
     xyz = (torch.rand(5000, 3, generator=torch.Generator().manual_seed(2)) * 2 - 1).to(DEV)
     with torch.no_grad():
         a = model(xyz, apply_brdf=True, nr_lr_on=True)
@@ -601,18 +643,20 @@ def test_field_forward_analytic_normal_golden_fp32(name):
     assert_close(out0, g["out_nobrdf"], 2e-4, 2e-5, "out_nobrdf")
 
 
-def test_field_forward_analytic_normal_F512_fp32_and_bf16():
+def test_field_forward_analytic_normal_F512_fp32_and_half():
     g = load_golden("field_rpv111_nan_F512")
     cfg = FieldConfig(**CONFIGS_AN["rpv111_nan"])
     xyz = torch.from_numpy(g["xyz"]).to(DEV)
     with torch.no_grad():
         out = build_model(cfg, 12)(xyz, apply_brdf=True, nr_an_on=True)
-        out16 = build_model(cfg, 12, "bf16")(xyz, apply_brdf=True, nr_an_on=True).cpu()
     assert_close(out, g["out_brdf"], 5e-4, 5e-5, "F512 out")
     ref_n = torch.from_numpy(g["out_brdf"][:, 4:7])
-    cos = (out16[:, 4:7] * ref_n).sum(-1)
-    print("bf16 analytic normal: min cosine vs reference", float(cos.min()))
-    assert float(cos.min()) > 0.98           # stated bf16 bound: normals within ~11 degrees worst case
+    for dtype in ("bf16", "fp16"):
+        with torch.no_grad():
+            out16 = build_model(cfg, 12, dtype)(xyz, apply_brdf=True, nr_an_on=True).cpu()
+        cos = (out16[:, 4:7] * ref_n).sum(-1)
+        diag(f"{dtype} analytic normal F512: min cosine vs reference {float(cos.min()):.6f}")
+        assert float(cos.min()) > HALF_BOUNDS[dtype]["ncos"]      # bf16: within ~11 degrees worst case; fp16: ~1.8 degrees
 
 
 def test_sigma_grad_matches_oracle_many_points():
@@ -1101,30 +1145,38 @@ def test_train_loop_runs_saves_and_resumes(tmp_path):
     assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(cont, cont2))   # later steps: fp32-atomic summation order only
 
 
-FULL_SIZE = {   # BASELINE.json configs 2-5 at their per-GPU shapes (F=512, 8 layers, PE10)
-    "c2_lambert": (dict(), 4096, 64, 64, dict(apply_brdf=False, apply_theta=False, cos_irra_on=False)),
-    "c3_rpv_nan": (dict(funcM=1, funcF=1, funcH=1, normal="analystic"), 4096, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
-    "c4_rpv_nlr_s128": (dict(funcM=1, funcF=1, funcH=1, normal="learned"), 1024, 128, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
-    "c5_hapke": (dict(b=1, c=1, normal="analystic"), 1024, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+FULL_SIZE = {   # BASELINE.json configs 2-5 at their per-GPU shapes (F=512, 8 layers, PE10), in the dtype BASELINE.json names
+    "c2_lambert": (dict(), 4096, 64, 64, dict(apply_brdf=False, apply_theta=False, cos_irra_on=False), "bf16"),
+    "c3_rpv_nan": (dict(funcM=1, funcF=1, funcH=1, normal="analystic"), 4096, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True), "bf16"),
+    # config 4 = config 3's model (RPV + analytic normals, SURVEY 8d "C4 as C3") at 8192 rays x 128 samples over 8 GPUs: the
+    # per-rank shape is 1024 rays x (128 + 64) samples; the learned-normal variant stays as a second shape check
+    "c4_rpv_nan_s128": (dict(funcM=1, funcF=1, funcH=1, normal="analystic"), 1024, 128, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True), "bf16"),
+    "c4_rpv_nlr_s128": (dict(funcM=1, funcF=1, funcH=1, normal="learned"), 1024, 128, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True), "bf16"),
+    # config 5 (Hapke + microfacet, ds_lambda = 10, fp16): the reference's model classes are mutually exclusive (SURVEY
+    # quirk 10), so "mix" = both kernels exercised, each in fp16 as BASELINE.json states; the bf16 runs stay beside them
+    "c5_hapke_fp16": (dict(b=1, c=1, normal="analystic"), 1024, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True), "fp16"),
     # Hapke with macroscopic roughness: its azimuth term has an infinite derivative at phi = 0; this seed reaches a ray
     # whose fp32 cos(phi) rounds to exactly 1 (the oracle's autograd is finite only because the CPU rounds it just below).
     # The fused step drops that ray's non-finite gradient (FusedTrainer.sanitize_grads).
-    "c5_hapke_theta": (dict(b=1, c=1, theta=1, normal="analystic"), 1024, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
-    "c5_microfacet": (dict(roughness=True, normal="analystic"), 1024, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    "c5_hapke_theta_fp16": (dict(b=1, c=1, theta=1, normal="analystic"), 1024, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True), "fp16"),
+    "c5_microfacet_fp16": (dict(roughness=True, normal="analystic"), 1024, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True), "fp16"),
+    "c5_hapke_theta_bf16": (dict(b=1, c=1, theta=1, normal="analystic"), 1024, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True), "bf16"),
+    "c5_microfacet_bf16": (dict(roughness=True, normal="analystic"), 1024, 64, 64, dict(apply_brdf=True, apply_theta=True, cos_irra_on=True), "bf16"),
+    "c2_lambert_fp16": (dict(), 4096, 64, 64, dict(apply_brdf=False, apply_theta=False, cos_irra_on=False), "fp16"),
 }
 
 
 @pytest.mark.parametrize("name", list(FULL_SIZE))
 def test_full_size_render_and_train_step_properties(name):
-    """BASELINE configurations at full width and batch in bf16, through size-independent properties: sorted depths, a
-    permutation as sort index, weights in [0,1] summing to <= 1, pixels in [0,1], finite outputs and gradients, and a
-    few fused training steps (depth supervision, ds_lambda=10) that stay finite and settle below the initial losses."""
+    """BASELINE configurations at full width and batch in their stated dtype, through size-independent properties: sorted
+    depths, a permutation as sort index, weights in [0,1] summing to <= 1, pixels in [0,1], finite outputs and gradients,
+    and a few fused training steps (depth supervision, ds_lambda=10) that stay finite and settle below the initial losses."""
     import bench
     from brdf_nerf_amd import render_rays
     from brdf_nerf_amd.trainer import FusedTrainer
-    kw, R, S, G, flags = FULL_SIZE[name]
+    kw, R, S, G, flags, dtype = FULL_SIZE[name]
     cfg = FieldConfig(n_samples=S, guided_samples=G, **kw)
-    args = make_args(cfg, "bf16")
+    args = make_args(cfg, dtype)
     torch.manual_seed(0)
     from brdf_nerf_amd import load_model
     model = load_model(args).to(DEV)
@@ -1145,33 +1197,98 @@ def test_full_size_render_and_train_step_properties(name):
         loss, _ = tr.step(b["rays"], b["rgbs"], valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"],
                           near_far=(0.0, 2.0), **flags)
         assert bool(torch.isfinite(tr.flat_grad).all()), f"step {i}: non-finite gradient"
+        assert float(tr.flat_grad.abs().max()) > 0.0, f"step {i}: all-zero gradient"
         losses_.append(float(loss))
     # Adam's first steps move every weight by lr whatever the gradient: the loss may spike before it settles
     assert all(l == l for l in losses_) and losses_[-1] < max(losses_[:3]), losses_
+    diag(f"full size {name} ({dtype}): losses {losses_[0]:.4f} -> {losses_[-1]:.4f}, dropped samples {int(tr.dropped_samples)}")
 
 
-def test_bf16_training_psnr_tracks_fp32():
-    """north_star: PSNR within 0.05 dB of the reference.  The fp32 mode is held to the reference by the golden tests;
-    here the bf16 throughput mode is run beside it - same initialisation, same rays, same draws - and the PSNR of the
-    fitted batch must agree within 0.05 dB after 40 fused steps."""
-    import bench
+def _learnable_table(n_rays, seed):
+    """Djibouti-shaped synthetic table whose colours are a smooth function of the ray origin (something to learn):
+    training rays and held-out rays are different draws (seeds) of the same scene."""
+    from brdf_nerf_amd.raytable import synthetic_table
+    t = synthetic_table(n_rays, device=DEV, seed=seed)
+    o = t.data["rays"][:, :3]
+    t.data["rgbs"] = torch.stack([0.5 + 0.4 * torch.sin(3 * o[:, 0]), 0.5 + 0.4 * torch.cos(2 * o[:, 1]),
+                                  0.5 + 0.3 * torch.sin(2 * o[:, 0] + o[:, 1])], -1).contiguous()
+    return t
+
+
+PSNR_GATE = {   # name -> (model flags, steps of Lambertian pretraining, steps of the BRDF stage)
+    "lambert": (dict(), 320, 0),
+    "rpv_nan": (dict(funcM=1, funcF=1, funcH=1, normal="analystic"), 160, 160),
+}
+
+
+@pytest.mark.parametrize("name", list(PSNR_GATE))
+def test_reduced_precision_heldout_psnr_tracks_fp32(name):
+    """north_star: PSNR within 0.05 dB of the reference.  The fp32 mode is held to the reference by the golden tests; here
+    the bf16 and fp16 throughput modes are trained beside it on a LEARNABLE scene - same initialisation, same batches,
+    same random draws, 320 fused steps of 1024 rays x (64 + 64) samples at F = 512 - and the PSNR of 8192 HELD-OUT rays
+    (never trained on) must agree with fp32's within 0.05 dB.  The run-to-run spread of fp32 itself (its fp32 atomics
+    are order dependent) is measured by a second fp32 run and reported."""
     from brdf_nerf_amd import load_model, losses
+    from brdf_nerf_amd.evaluate import render_image
     from brdf_nerf_amd.trainer import FusedTrainer
-    cfg = FieldConfig(n_samples=64, guided_samples=64)
-    b = bench.synthetic_batch(2048, 9, torch.device(DEV))
-    out = {}
-    for mode in ("fp32", "bf16"):
-        args = make_args(cfg, mode)
+    kw, n_pre, n_brdf = PSNR_GATE[name]
+    cfg = FieldConfig(n_samples=64, guided_samples=64, **kw)
+    train, held = _learnable_table(1024 * 64, 3), _learnable_table(8192, 11)
+    psnr, first = {}, {}
+    for run in ("fp32", "bf16", "fp16", "fp32_again"):
+        dtype = run.split("_")[0]
+        args = make_args(cfg, dtype)
         torch.manual_seed(0)
         model = load_model(args).to(DEV)
         tr = FusedTrainer(model, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+        train.load_state_dict({"gen": torch.Generator(device=DEV).manual_seed(5).get_state(), "perm": None, "cursor": 0, "epoch": 0})
         torch.manual_seed(1)
-        for _ in range(40):
+        for i in range(n_pre + n_brdf):
+            b = train.next_batch(1024)
+            on = i >= n_pre
             loss, rgb = tr.step(b["rays"], b["rgbs"], valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"],
-                                near_far=(0.0, 2.0))
-        out[mode] = float(losses.psnr(rgb, b["rgbs"]))
-    diag(f"PSNR after 40 steps: fp32 {out['fp32']:.4f} dB, bf16 {out['bf16']:.4f} dB")
-    assert abs(out["fp32"] - out["bf16"]) <= 0.05, out
+                                near_far=(0.0, 2.2), apply_brdf=on, apply_theta=on, cos_irra_on=on)
+            if i == 0:
+                first[run] = float(losses.psnr(rgb, b["rgbs"]))
+        torch.manual_seed(2)
+        on = n_brdf > 0
+        res = render_image({"coarse": model}, args, held.data["rays"], held.data["rgbs"], keys=("rgb",), chunk=2048,
+                           apply_brdf=on, apply_theta=on, cos_irra_on=on)
+        psnr[run] = float(res["psnr"])
+        assert all(bool(torch.isfinite(p).all()) for p in model.parameters()), run
+    diag(f"held-out PSNR {name} after {n_pre}+{n_brdf} steps (first-step train PSNR {first['fp32']:.2f} dB): "
+         + ", ".join(f"{k} {v:.4f} dB" for k, v in psnr.items())
+         + f"; |bf16-fp32| {abs(psnr['bf16'] - psnr['fp32']):.4f}, |fp16-fp32| {abs(psnr['fp16'] - psnr['fp32']):.4f}, "
+           f"fp32 run-to-run {abs(psnr['fp32_again'] - psnr['fp32']):.4f}")
+    assert psnr["fp32"] > first["fp32"] + 3.0, (psnr, first)          # the scene was learned, the gate is not vacuous
+    assert abs(psnr["bf16"] - psnr["fp32"]) <= 0.05, psnr
+    assert abs(psnr["fp16"] - psnr["fp32"]) <= 0.05, psnr
+
+
+@pytest.mark.parametrize("name", ["lambert", "rpv_nan"])
+def test_two_rank_step_matches_one_rank(name):
+    """ray-batch data parallelism.  Two ranks (both on cuda:0, gloo - the one-GPU box has no second device for
+    RCCL) each run FusedTrainer.step on half of a batch; the all-reduced flat gradient / 2 and the parameters after Adam
+    must equal a one-rank step on the concatenated batch (tests/dist_step_worker.py)."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_step_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2", BN_DIST_CONFIG=name,
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append("TIMEOUT")
+    for o in outs:
+        for line in o.splitlines():
+            if line.startswith("RESULT"):
+                diag(line)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
 
 
 def test_count_nonfinite_hook():

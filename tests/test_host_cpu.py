@@ -180,10 +180,23 @@ def test_stage_schedule_follows_reference_thresholds():
     assert seen[29]["epoch"] == 2 and not seen[29]["hs_on"] and seen[30]["epoch"] == 3 and seen[30]["hs_on"]
     assert not any(f["gsam_only"] for f in seen.values())
     assert abs(a.noise_std - 0.9 ** 60) < 1e-12
-    assert abs(s.lr(0) - 5e-4) < 1e-15 and abs(s.lr(10) - 4.5e-4) < 1e-12 and abs(s.lr(25) - 5e-4 * 0.81) < 1e-12
+    # StepLR(0.9) ticks per pass over the rank's loader: len(DataLoader(83 rays, batch 8, drop_last=False)) = 11 steps
+    assert s.lr_steps_per_epoch == 11
+    assert abs(s.lr(0) - 5e-4) < 1e-15 and abs(s.lr(10) - 5e-4) < 1e-15 and abs(s.lr(11) - 4.5e-4) < 1e-12
+    assert abs(s.lr(25) - 5e-4 * 0.81) < 1e-12
     s4 = StageSchedule(argparse.Namespace(**dict(vars(a), noise_std=0.0)), 83, world=4)
     f = [s4.begin_step() for _ in range(6)]
     assert s4.train_steps == 24 and s4.max_steps == 25 and not f[4]["apply_brdf"] and f[5]["apply_brdf"]
+    # 4 GPUs: DistributedSampler gives each rank ceil(83/4) = 21 rays = 3 batches per epoch -> the rate decays 4x faster
+    # per optimiser step than on one GPU (Lightning DDP), and RayTable serves 3 global batches of 32 per permutation
+    assert s4.lr_steps_per_epoch == 3 and abs(s4.lr(2) - 5e-4) < 1e-15 and abs(s4.lr(3) - 4.5e-4) < 1e-12
+    from brdf_nerf_amd.raytable import synthetic_table
+    t = synthetic_table(83, device="cpu", seed=0)
+    for _ in range(3):
+        t.next_batch(8 * 4, rank=1, world=4)
+    assert t.epoch == 0
+    t.next_batch(8 * 4, rank=1, world=4)
+    assert t.epoch == 1
 
 
 def test_ray_table_epochs_and_shards():
