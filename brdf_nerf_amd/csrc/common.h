@@ -150,6 +150,14 @@ __device__ __forceinline__ float grad_scale_from(const float *amax, int log2_tar
 }
 #define BN_GS_TARGET_CHAIN 8                 // primal backward chain: max |d pre-activation| -> [128, 256)
 #define BN_GS_TARGET_ADJ 6                   // analytic-normal double backward: max |gbar_PE| -> [32, 64)
+// amax slots (fp32 as bits, in the stash header): [0] primal seeds, [1] adjoint-chain seeds, [2] the zbar_l terms the
+// adjoint backward adds to the primal chain at every layer (true scale; layer 0 carries w0^2 = 900).  The primal chain's
+// scale must cover [0] and [2]; fmaxf ignores a NaN operand.
+__device__ __forceinline__ float chain_scale(const float *amax) {
+  if (amax == nullptr) return 1.f;
+  const float m = fmaxf(amax[0], amax[2]);
+  return grad_scale_from(&m, BN_GS_TARGET_CHAIN);
+}
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }

@@ -22,7 +22,8 @@ struct AdjBwdArgs {
   const float *d_out;
   char *stash;
   int prescaled;   // forward packs carry w0/(2 pi) (16-bit Siren modes): undo it here
-  const float *amax;   // fp16 mode: amax[1] = max |gbar_PE| picks this chain's loss scale (common.h); else nullptr
+  float *amax;         // fp16 mode: amax[1] = max |gbar_PE| picks this chain's loss scale (common.h); amax[2] receives
+                       // max |zbar_l| (true scale) for the primal chain's; else nullptr
 };
 
 template <typename T, int MT, int NT, int WAVES>
@@ -41,6 +42,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
   // fp16 mode: the chain runs scaled by gs (a power of two): gbar_PE, abar_l, zbar_l carry it (the weight-gradient jobs
   // and the primal chain remove it); sbar, an fp32 scalar per point, is stored unscaled
   const float gs = grad_scale_from(A.amax ? A.amax + 1 : nullptr, BN_GS_TARGET_ADJ);
+  constexpr bool TRACK = std::is_same<T, f16>::value;   // fp16 only: the largest |zbar| this workgroup hands to the primal chain
+  float zmax = 0.f;
 
   // ---------------------------------------------------------------- dL/dn -> dL/dg -> dL/dg_PE
   if (tid < BM) {
@@ -158,6 +161,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
               zb[e] = e2 * (float)ya[e] * db[e] * av[e];
               zb[4 + e] = e2 * (float)yb[e] * db[4 + e] * av[4 + e];
             }
+            if (TRACK) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { const float az = fabsf(zb[e]); zmax = (az < 3.0e38f && az > zmax) ? az : zmax; }
+            }
             st8(Zs + native_off8<MT, NT>(wave, nt, mt, gp, lane), zb);
             *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), db[0] * dv[0], db[1] * dv[1], db[2] * dv[2], db[3] * dv[3]);
             *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), db[4] * dv[4], db[5] * dv[5], db[6] * dv[6], db[7] * dv[7]);
@@ -165,6 +172,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
         }
     }
     __syncthreads();
+  }
+  if (TRACK && A.amax) {   // ONE atomic per workgroup (non-negative floats order like their bit patterns); true scale = stored / gs
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o));
+    float *red = (float *)PE;            // the encoding tile is free after the last layer (the loop ends on a barrier)
+    if (lane == 0) red[wave] = zmax;
+    __syncthreads();
+    if (tid == 0) {
+      float m = 0.f;
+      for (int w = 0; w < WAVES; ++w) m = fmaxf(m, red[w]);
+      if (m > 0.f) atomicMax((unsigned int *)A.amax + 2, __float_as_uint(m / gs));
+    }
   }
   // abar_L (the tile the loop leaves in LDS) has no later GEMM to ride in
   tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.adj_abar[g.L]) + (size_t)m0 * F, F, BM, F);
@@ -209,7 +228,7 @@ int bn_field_adjoint_backward(const bn_field_desc *desc, const bn_field_params *
   a.prescaled = bn_half(desc->dtype) && desc->act == BN_ACT_SIN;
   const int BM = a.g.BM;
   bn_make_stash_layout(a.g, pts->n_points, BM, bn_esize(desc->dtype), &a.sl);
-  a.amax = desc->dtype == BN_F16 ? (const float *)((const char *)stash + a.sl.gscale) : nullptr;
+  a.amax = desc->dtype == BN_F16 ? (float *)((char *)stash + a.sl.gscale) : nullptr;
   const int64_t tiles = ceil_div64(pts->n_points, BM);
   hipStream_t st = (hipStream_t)stream;
   BN_DISPATCH_TILE(desc->dtype, a.g, launch_adjbwd, (a, tiles, st));

@@ -26,7 +26,7 @@ struct BwdArgs {
   const float *out, *d_out;
   char *stash;
   int an;   // analytic normals in the graph: add the adjoint chain's sbar / zbar_l (field_adjbwd.hip)
-  const float *amax;   // fp16 mode: [0] max |d pre-activation|, [1] max |gbar_PE| (loss scaling, common.h); else nullptr
+  const float *amax;   // fp16 mode: [0] max |d pre-activation|, [1] max |gbar_PE|, [2] max |zbar_l| (loss scaling, common.h); else nullptr
 };
 
 // sigmoid output y and dL/dy of head `hd`, channel c, recovered from the forward's rescaled output.
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   // fp16 mode: the chain runs on gradients scaled by S (a power of two, from the device-side maximum); the fp32 copies
   // kept for the skinny weight-gradient kernel stay unscaled, the 16-bit dZ_l / dG stashes carry S and the weight-gradient
   // kernel removes it from its fp32 sums.
-  const float gs = grad_scale_from(A.amax, BN_GS_TARGET_CHAIN);
+  const float gs = chain_scale(A.amax);
   if (tid < BM) {
     const int m = tid;
     const int64_t gm = m0 + m;
@@ -342,7 +342,7 @@ struct WgradJob {
 // 1 / (scale carried by the job's gradient operand): multiplies the fp32 sums before they are accumulated
 __device__ __forceinline__ float wg_unscale(const float *amax, int sel) {
   if (amax == nullptr || sel == 0) return 1.f;
-  return 1.f / (sel == 1 ? grad_scale_from(amax, BN_GS_TARGET_CHAIN) : grad_scale_from(amax + 1, BN_GS_TARGET_ADJ));
+  return 1.f / (sel == 1 ? chain_scale(amax) : grad_scale_from(amax + 1, BN_GS_TARGET_ADJ));
 }
 #define BN_MAX_WGRAD_JOBS 40
 struct WgradArgs {
@@ -855,7 +855,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   a.amax = amax;
   const unsigned amax_grid = (unsigned)(ceil_div64(pts->n_points, 256) < 1024 ? ceil_div64(pts->n_points, 256) : 1024);
   if (f16m) {
-    if (hipMemsetAsync(amax, 0, 8, st) != hipSuccess) { bn_set_error("field_backward: memset failed"); return BN_ELAUNCH; }
+    if (hipMemsetAsync(amax, 0, 16, st) != hipSuccess) { bn_set_error("field_backward: memset failed"); return BN_ELAUNCH; }
     if (a.an) {
       grad_amax_kernel<1><<<amax_grid, 256, 0, st>>>(a, amax);
       BN_LAUNCH_CHECK("grad_amax<1>");

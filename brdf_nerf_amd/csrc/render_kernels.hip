@@ -66,7 +66,65 @@ struct CompArgs {
   const float *d_weights, *d_depth, *d_acc;
   float *d_sigma, *d_chan;
   int64_t d_sigma_stride, d_chan_stride;
+  int flat_lg;     // >= 0: dense 16-byte aligned channel rows with C = 4 << flat_lg (4, 8, 16): the channel phase walks the ray's
+                   // [S][C] block as flat float4s - every wave instruction moves 1 KB of consecutive bytes - instead of one
+                   // 4-byte load per (sample, channel) per lane.  -1: generic path (any C, any stride)
+  int fused_dsigma;  // backward, flat path: d_sigma aliases channel 3 of d_chan -> written with the d_chan rows
 };
+
+// Channel phase of the flat path.  Lane l handles float4 q = l + 64 k of the ray's block: sample q >> LG, channel group
+// l & (2^LG - 1) (the same for every k).  The per-sample weights come from the wave's LDS slice.
+template <int LG> __device__ __forceinline__ void comp_flat_fwd(const CompArgs &A, int64_t ray, int lane, const float *wl) {
+  constexpr int LPS = 1 << LG;
+  const int nq = A.S << LG;
+  const f32x4 *src = (const f32x4 *)(A.chan + ray * A.S * A.C);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int q = lane; q < nq; q += 64) {
+    const float w = wl[q >> LG];
+    const f32x4 v = src[q];
+    a += w * v;
+  }
+#pragma unroll
+  for (int o = LPS; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] += __shfl_xor(a[e], o);
+  }
+  if (lane < LPS) ((f32x4 *)(A.acc + ray * A.C))[lane] = a;
+}
+// backward, part A: gs[s] = sum_c d_acc[c] chan[s][c]
+template <int LG> __device__ __forceinline__ void comp_flat_bwd_dot(const CompArgs &A, int64_t ray, int lane, float *gs) {
+  constexpr int LPS = 1 << LG;
+  const int nq = A.S << LG;
+  const f32x4 *src = (const f32x4 *)(A.chan + ray * A.S * A.C);
+  const f32x4 da = ((const f32x4 *)(A.d_acc + ray * A.C))[lane & (LPS - 1)];
+  for (int q = lane; q < nq; q += 64) {
+    const f32x4 v = src[q];
+    float p = da[0] * v[0] + da[1] * v[1] + da[2] * v[2] + da[3] * v[3];
+#pragma unroll
+    for (int o = 1; o < LPS; o <<= 1) p += __shfl_xor(p, o);
+    if ((lane & (LPS - 1)) == 0) gs[q >> LG] = p;
+  }
+}
+// backward, part B: d_chan[s][c] = w_s d_acc[c], channel 3 replaced by d sigma_s when the two alias
+template <int LG> __device__ __forceinline__ void comp_flat_bwd_store(const CompArgs &A, int64_t ray, int lane, const float *wl,
+                                                                      const float *dsl) {
+  constexpr int LPS = 1 << LG;
+  const int nq = A.S << LG;
+  f32x4 *dst = (f32x4 *)(A.d_chan + ray * A.S * A.C);
+  const f32x4 da = ((const f32x4 *)(A.d_acc + ray * A.C))[lane & (LPS - 1)];
+  const bool sig = A.fused_dsigma && (lane & (LPS - 1)) == 0;
+  for (int q = lane; q < nq; q += 64) {
+    const int sm = q >> LG;
+    f32x4 o = wl[sm] * da;
+    if (sig) o[3] = dsl[sm];
+    dst[q] = o;
+  }
+}
+__device__ __forceinline__ void lds_wave_sync() {   // LDS hand-over inside one wave: its DS operations execute in order
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ float wave_excl_prod(float v, int lane) {
   // inclusive Hillis-Steele scan, then shift by one lane
@@ -92,9 +150,14 @@ __device__ __forceinline__ float wave_excl_sum_rev(float v, int lane) {
 }
 
 template <bool BWD> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void composite_kernel(const CompArgs A) {
-  const int lane = threadIdx.x & 63;
-  const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  __shared__ float lds_w[WAVES_PER_BLOCK][64 * BN_MAX_CPL];                 // per-wave slices: weights,
+  __shared__ float lds_g[BWD ? WAVES_PER_BLOCK : 1][BWD ? 64 * BN_MAX_CPL : 1];   // sum_c d_acc[c] chan[s][c],
+  __shared__ float lds_d[BWD ? WAVES_PER_BLOCK : 1][BWD ? 64 * BN_MAX_CPL : 1];   // d sigma
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv;
   if (ray >= A.R) return;
+  float *wl = lds_w[wv], *gs = lds_g[BWD ? wv : 0], *dsl = lds_d[BWD ? wv : 0];
+  const bool flat = A.flat_lg >= 0;
   const int S = A.S, cpl = (S + 63) / 64;
   const float *z = A.z + ray * S;
   float zv[BN_MAX_CPL], al[BN_MAX_CPL], u[BN_MAX_CPL], dad[BN_MAX_CPL];  // dad = d alpha / d sigma
@@ -139,7 +202,17 @@ template <bool BWD> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void comp
     }
     dsum = wave_sum(dsum);
     if (lane == 0 && A.depth) A.depth[ray] = dsum;
-    if (A.chan && A.acc) {
+    if (flat) {
+#pragma unroll
+      for (int j = 0; j < BN_MAX_CPL; ++j) {
+        const int s = lane * cpl + j;
+        if (j < cpl && s < S) wl[s] = w[j];
+      }
+      lds_wave_sync();
+      if (A.flat_lg == 0) comp_flat_fwd<0>(A, ray, lane, wl);
+      else if (A.flat_lg == 1) comp_flat_fwd<1>(A, ray, lane, wl);
+      else comp_flat_fwd<2>(A, ray, lane, wl);
+    } else if (A.chan && A.acc) {
       for (int c = 0; c < A.C; ++c) {
         float a = 0.f;
 #pragma unroll
@@ -154,9 +227,20 @@ template <bool BWD> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void comp
   } else {
     // g_s = dL/dw_s; dL/dalpha_s = g_s T_s - (1/u_s) sum_{k>s} g_k w_k   
     const float dd = A.d_depth ? A.d_depth[ray] : 0.f;
+    if (flat) {
+#pragma unroll
+      for (int j = 0; j < BN_MAX_CPL; ++j) {
+        const int s = lane * cpl + j;
+        if (j < cpl && s < S) wl[s] = w[j];
+      }
+      if (A.flat_lg == 0) comp_flat_bwd_dot<0>(A, ray, lane, gs);
+      else if (A.flat_lg == 1) comp_flat_bwd_dot<1>(A, ray, lane, gs);
+      else comp_flat_bwd_dot<2>(A, ray, lane, gs);
+      lds_wave_sync();
+    }
     float dacc[BN_MAX_CH];
 #pragma unroll
-    for (int c = 0; c < BN_MAX_CH; ++c) dacc[c] = (A.d_acc && c < A.C) ? A.d_acc[ray * A.C + c] : 0.f;
+    for (int c = 0; c < BN_MAX_CH; ++c) dacc[c] = (!flat && A.d_acc && c < A.C) ? A.d_acc[ray * A.C + c] : 0.f;
     float g[BN_MAX_CPL], gw = 0.f;
 #pragma unroll
     for (int j = 0; j < BN_MAX_CPL; ++j) {
@@ -165,7 +249,8 @@ template <bool BWD> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void comp
       if (j < cpl && s < S) {
         float gg = dd * zv[j];
         if (A.d_weights) gg += A.d_weights[ray * S + s];
-        if (A.chan && A.d_acc) {
+        if (flat) gg += gs[s];
+        else if (A.chan && A.d_acc) {
           const float *ch = A.chan + (ray * S + s) * A.chan_stride;
           float *dch = A.d_chan ? A.d_chan + (ray * S + s) * A.d_chan_stride : nullptr;
 #pragma unroll
@@ -185,11 +270,25 @@ template <bool BWD> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void comp
       const int s = lane * cpl + j;
       if (j < cpl && s < S) {
         const float dalpha = g[j] * tr[j] - suffix / u[j];
-        A.d_sigma[(ray * S + s) * A.d_sigma_stride] = dalpha * dad[j];
+        if (flat && A.fused_dsigma) dsl[s] = dalpha * dad[j];
+        else A.d_sigma[(ray * S + s) * A.d_sigma_stride] = dalpha * dad[j];
         suffix += g[j] * w[j];
       }
     }
+    if (flat && A.d_chan) {
+      lds_wave_sync();
+      if (A.flat_lg == 0) comp_flat_bwd_store<0>(A, ray, lane, wl, dsl);
+      else if (A.flat_lg == 1) comp_flat_bwd_store<1>(A, ray, lane, wl, dsl);
+      else comp_flat_bwd_store<2>(A, ray, lane, wl, dsl);
+    }
   }
+}
+
+// flat channel path: dense rows of 4, 8 or 16 channels, 16-byte aligned blocks
+static int comp_flat_lg(const float *chan, int64_t chan_stride, int C, const void *p1, const void *p2) {
+  if (!chan || chan_stride != C || (C != 4 && C != 8 && C != 16)) return -1;
+  if (((uintptr_t)chan | (uintptr_t)p1 | (uintptr_t)p2) % 16 != 0) return -1;
+  return C == 4 ? 0 : (C == 8 ? 1 : 2);
 }
 
 extern "C" int bn_composite_forward(const float *z, const float *sigma, int64_t sigma_stride, const float *noise,
@@ -202,6 +301,10 @@ extern "C" int bn_composite_forward(const float *z, const float *sigma, int64_t 
   a.z = z; a.sigma = sigma; a.noise = noise; a.chan = chan; a.sigma_stride = sigma_stride; a.chan_stride = chan_stride;
   a.noise_std = noise_std; a.C = C; a.S = S; a.R = R;
   a.alphas = alphas; a.trans = trans; a.weights = weights; a.depth = depth; a.acc = acc;
+  a.flat_lg = acc ? comp_flat_lg(chan, chan_stride, C, acc, nullptr) : -1;
+#ifdef BN_NO_FLAT_COMPOSITE      // A/B switch (profiles/ab_kernels.py): the per-(sample, channel) scalar path everywhere
+  a.flat_lg = -1;
+#endif
   BnProfScope prof_(BN_K_COMPOSITE_FWD, (hipStream_t)stream);
   composite_kernel<false><<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
   BN_LAUNCH_CHECK("composite_forward");
@@ -220,6 +323,12 @@ extern "C" int bn_composite_backward(const float *z, const float *sigma, int64_t
   a.noise_std = noise_std; a.C = C; a.S = S; a.R = R;
   a.d_weights = d_weights; a.d_depth = d_depth; a.d_acc = d_acc; a.d_sigma = d_sigma; a.d_chan = d_chan;
   a.d_sigma_stride = d_sigma_stride; a.d_chan_stride = d_chan_stride;
+  // flat path: needs d_acc (the dot products) and, when channel gradients are written, dense d_chan rows as well
+  a.flat_lg = (d_acc && (!d_chan || d_chan_stride == C)) ? comp_flat_lg(chan, chan_stride, C, d_acc, d_chan) : -1;
+#ifdef BN_NO_FLAT_COMPOSITE
+  a.flat_lg = -1;
+#endif
+  a.fused_dsigma = (a.flat_lg >= 0 && d_chan && d_sigma == d_chan + 3 && d_sigma_stride == d_chan_stride) ? 1 : 0;
   BnProfScope prof_(BN_K_COMPOSITE_BWD, (hipStream_t)stream);
   composite_kernel<true><<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
   BN_LAUNCH_CHECK("composite_backward");

@@ -160,7 +160,9 @@ def test_composite_golden(S):
 def test_composite_channels_and_sizes():
     """Weighted channel sums + backward against the oracle, S from 1..192 incl. ragged (S not a multiple of 64)."""
     from brdf_nerf_amd import functions as Fn
-    for S, C, R in ((1, 4, 7), (63, 7, 33), (64, 4, 128), (130, 13, 65), (192, 16, 9)):
+    # C in {4, 8, 16} with dense rows takes the flat float4 channel path (render_kernels.hip), everything else the generic one
+    for S, C, R in ((1, 4, 7), (63, 7, 33), (64, 4, 128), (130, 13, 65), (192, 16, 9), (128, 16, 65), (128, 8, 9), (17, 8, 5),
+                    (512, 16, 3), (3, 16, 2), (128, 12, 4)):
         g = torch.Generator().manual_seed(S)
         z = torch.sort(torch.rand(R, S, generator=g) * 2, -1)[0]
         out = torch.randn(R, S, C, generator=g)
