@@ -83,6 +83,7 @@ _SIGS = {
     "bn_adam_step": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_int32, C.c_float, fptr]),
     "bn_count_nonfinite": (C.c_int, [fptr, C.c_int64, fptr, fptr]),
+    "bn_device_faults": (C.c_int, [C.POINTER(C.c_uint), fptr]),
     "bn_prof_enable": (C.c_int, [C.c_int]),
     "bn_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
 }

@@ -23,6 +23,11 @@ struct FwdArgs {
 // per output, no range-reduction multiplies.  The parity mode keeps z = W x + b and the accurate sincos.
 #define BN_INV_2PI 0.15915494309189535f
 
+// sticky fault word of the forward kernels (lost LDS hand-over in the barrier-free trunk, field_kernels.h pp_wait)
+__device__ unsigned int g_fwd_fault;
+static unsigned int *g_fwd_fault_host = nullptr;     // pinned mirror, refreshed asynchronously every 64th launch
+static unsigned int g_fwd_launches = 0;
+
 BN_PH_DEFINE_READER(bn_debug_phase_read_fwd)
 BN_CLK_DEFINE(bn_debug_clock_read_fwd)
 template <bool FAST, int ACT> __device__ __forceinline__ void act_eval(float z, float w0, float &y, float &d) {
@@ -271,8 +276,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
           T *ydst = (T *)(A.stash + A.sl.Y[l - 1]) + (size_t)m0 * F;
           NoSide none;
           BN_PH(1)
-          pp_wait(WR + 0, 4 * l);                       // half 0 of Y_{l-1} is written
-          if (grp == 1) pp_wait(RD + 0, 4 * l);         // group 0 is done with its phase 1 of this layer: the lag
+          pp_wait(WR + 0, 4 * l, &g_fwd_fault);                       // half 0 of Y_{l-1} is written
+          if (grp == 1) pp_wait(RD + 0, 4 * l, &g_fwd_fault);         // group 0 is done with its phase 1 of this layer: the lag
           BN_PH(12)
 #ifdef BN_AB_NO_Y_COPY        // ablation (results wrong): the forward without the row-major Y copies riding in the GEMMs
           if (false) {
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
           }
           BN_PH(1)
           pp_signal(RD + 0 + grp, lane);
-          pp_wait(WR + 1, 4 * l);                       // half 1
+          pp_wait(WR + 1, 4 * l, &g_fwd_fault);                       // half 1
           BN_PH(13)
 #ifdef BN_AB_NO_Y_COPY
           if (false) {
@@ -327,8 +332,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
     BN_PH(1)
     if (PING) {
       if (l > 0) {   // all eight waves have read this group's columns of Y_{l-1}
-        pp_wait(RD + 2 * grp + 0, 4 * l);
-        pp_wait(RD + 2 * grp + 1, 4 * l);
+        pp_wait(RD + 2 * grp + 0, 4 * l, &g_fwd_fault);
+        pp_wait(RD + 2 * grp + 1, 4 * l, &g_fwd_fault);
       }
     } else {
       __syncthreads();  // every wave has finished reading ACT (in-place update below)
@@ -621,9 +626,30 @@ template <typename T, int MT, int NT, int WAVES, bool KEEP> static int launch_fw
   const size_t lds = ((size_t)BM * (a.g.F + Elem<T>::kPad) + (size_t)BM * (a.g.KP + Elem<T>::kPad)) * sizeof(T) +
                      (size_t)WAVES * 3 * BM * sizeof(float);
   if (int e = bn_configure_lds((const void *)field_fwd_kernel<T, MT, NT, WAVES, KEEP>, lds, "field_fwd")) return e;
-  BnProfScope prof_(a.sigma_only ? BN_K_FWD_SIGMA : BN_K_FWD_FULL, st);
-  field_fwd_kernel<T, MT, NT, WAVES, KEEP><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
-  BN_LAUNCH_CHECK("field_fwd");
+  {
+    BnProfScope prof_(a.sigma_only ? BN_K_FWD_SIGMA : BN_K_FWD_FULL, st);
+    field_fwd_kernel<T, MT, NT, WAVES, KEEP><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
+    BN_LAUNCH_CHECK("field_fwd");
+  }
+  // mirror the device fault word to the host now and then: asynchronous, no synchronisation on the hot path
+  if ((g_fwd_launches++ & 63u) == 0u) {
+    if (!g_fwd_fault_host && hipHostMalloc((void **)&g_fwd_fault_host, sizeof(unsigned int), hipHostMallocDefault) == hipSuccess)
+      *g_fwd_fault_host = 0u;
+    if (g_fwd_fault_host) (void)hipMemcpyFromSymbolAsync(g_fwd_fault_host, HIP_SYMBOL(g_fwd_fault), sizeof(unsigned int), 0, hipMemcpyDeviceToHost, st);
+  }
+  return 0;
+}
+
+// 0: no fault seen so far (asynchronous view: what the last mirrored copy showed)
+int bn_fwd_fault_seen() { return g_fwd_fault_host && *g_fwd_fault_host != 0u; }
+
+extern "C" int bn_device_faults(unsigned int *faults, void *stream) {
+  BN_REQUIRE(faults, "device_faults: null argument");
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
+      hipMemcpyFromSymbol(faults, HIP_SYMBOL(g_fwd_fault), sizeof(unsigned int), 0, hipMemcpyDeviceToHost) != hipSuccess) {
+    bn_set_error("device_faults: cannot read the fault word");
+    return BN_ELAUNCH;
+  }
   return 0;
 }
 
@@ -631,6 +657,10 @@ int bn_field_forward_impl(const bn_field_desc *desc, const bn_field_params *para
                           const bn_points *pts, float *out, void *stash, int sigma_only, void *stream) {
   FwdArgs a;
   if (int e = bn_make_geom(desc, &a.g)) return e;
+  if (bn_fwd_fault_seen()) {
+    bn_set_error("field_forward: an earlier forward launch lost an LDS hand-over (pp_wait timed out): its results are invalid");
+    return BN_ELAUNCH;
+  }
   // desc->normal_an only reserves 3 output channels here; bn_field_normals() fills them from the stash
   BN_REQUIRE(!desc->normal_an || sigma_only || stash, "field_forward: analytic normals need the activation stash");
   BN_REQUIRE(pts && pts->n_points > 0 && (pts->xyz || (pts->rays && pts->z && pts->n_samples > 0)), "field: bad points");

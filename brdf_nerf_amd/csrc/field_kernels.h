@@ -172,9 +172,15 @@ template <typename T> struct TileCopyHalf {
 // signal is visible to whoever sees the signal.  The spin is bounded (a count that is never reached in a correct run):
 // every wave reaches its exit even if a signal were lost.
 typedef __attribute__((address_space(3))) int lds_int;
-__device__ __forceinline__ void pp_wait(int *flag, int target) {
+// A hand-over that never arrives (impossible in a correct run) must not pass silently: the waiter gives up after ~2^24
+// sleeps, records the fault in a device word (*fault, owned by the translation unit that launches the kernel) and carries on
+// to its exit; the launch wrapper mirrors that word to pinned host memory and the next library call returns BN_ELAUNCH
+// (bn_device_faults() reads it synchronously).
+__device__ __forceinline__ void pp_wait(int *flag, int target, unsigned int *fault) {
   volatile lds_int *f = (volatile lds_int *)flag;
-  for (int spin = 0; *f < target && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);
+  int spin = 0;
+  for (; *f < target && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);
+  if (spin >= (1 << 24) && (threadIdx.x & 63) == 0) atomicOr(fault, 1u);
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void pp_signal(int *flag, int lane) {

@@ -66,60 +66,93 @@ struct CompArgs {
   const float *d_weights, *d_depth, *d_acc;
   float *d_sigma, *d_chan;
   int64_t d_sigma_stride, d_chan_stride;
-  int flat_lg;     // >= 0: dense 16-byte aligned channel rows with C = 4 << flat_lg (4, 8, 16): the channel phase walks the ray's
-                   // [S][C] block as flat float4s - every wave instruction moves 1 KB of consecutive bytes - instead of one
-                   // 4-byte load per (sample, channel) per lane.  -1: generic path (any C, any stride)
+  int flat_lg;     // >= 0: dense channel rows (stride == C): the channel phase walks the ray's [S][C] block in 4-channel groups,
+                   // 2^flat_lg groups per sample, consecutive lanes on consecutive pieces - instead of one 4-byte load per
+                   // (sample, channel) per lane.  -1: generic path (strided rows)
+  int flat_vec;    // C % 4 == 0 and 16-byte aligned blocks: one float4 per group
   int fused_dsigma;  // backward, flat path: d_sigma aliases channel 3 of d_chan -> written with the d_chan rows
 };
 
-// Channel phase of the flat path.  Lane l handles float4 q = l + 64 k of the ray's block: sample q >> LG, channel group
-// l & (2^LG - 1) (the same for every k).  The per-sample weights come from the wave's LDS slice.
-template <int LG> __device__ __forceinline__ void comp_flat_fwd(const CompArgs &A, int64_t ray, int lane, const float *wl) {
+// Channel phase of the flat path.  The ray's [S][C] block is walked in 4-channel groups: lane l handles group q = l + 64 k,
+// i.e. sample q >> LG, channels 4 cg .. 4 cg + 3 with cg = l & (2^LG - 1) (the same for every k; 2^LG = groups per sample
+// = ceil(C / 4) rounded up to a power of two).  Consecutive lanes read consecutive 16-byte pieces: one wave instruction
+// moves ~1 KB of consecutive bytes.  VEC (C % 4 == 0, 16-byte aligned rows): one float4 per group; otherwise the group's
+// valid channels as scalars (the same cache lines, four instructions).  Per-sample weights come from the wave's LDS slice.
+template <bool VEC> __device__ __forceinline__ f32x4 comp_ld4(const float *p, int nv) {
+  if (VEC) return nv > 0 ? *(const f32x4 *)p : f32x4{0.f, 0.f, 0.f, 0.f};   // C = 12: the fourth group of a sample is empty
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (nv > 0) v[0] = p[0];
+  if (nv > 1) v[1] = p[1];
+  if (nv > 2) v[2] = p[2];
+  if (nv > 3) v[3] = p[3];
+  return v;
+}
+template <bool VEC> __device__ __forceinline__ void comp_st4(float *p, const f32x4 &v, int nv) {
+  if (VEC) { if (nv > 0) *(f32x4 *)p = v; return; }
+  if (nv > 0) p[0] = v[0];
+  if (nv > 1) p[1] = v[1];
+  if (nv > 2) p[2] = v[2];
+  if (nv > 3) p[3] = v[3];
+}
+template <int LG, bool VEC> __device__ __forceinline__ void comp_flat_fwd(const CompArgs &A, int64_t ray, int lane, const float *wl) {
   constexpr int LPS = 1 << LG;
-  const int nq = A.S << LG;
-  const f32x4 *src = (const f32x4 *)(A.chan + ray * A.S * A.C);
+  const int nq = A.S << LG, c0 = 4 * (lane & (LPS - 1)), nv = A.C - c0;
+  const float *src = A.chan + ray * A.S * A.C + c0;
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
   for (int q = lane; q < nq; q += 64) {
-    const float w = wl[q >> LG];
-    const f32x4 v = src[q];
-    a += w * v;
+    const int sm = q >> LG;
+    a += wl[sm] * comp_ld4<VEC>(src + (int64_t)sm * A.C, nv);
   }
 #pragma unroll
   for (int o = LPS; o < 64; o <<= 1) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) a[e] += __shfl_xor(a[e], o);
   }
-  if (lane < LPS) ((f32x4 *)(A.acc + ray * A.C))[lane] = a;
+  if (lane < LPS) comp_st4<VEC>(A.acc + ray * A.C + c0, a, nv);
 }
 // backward, part A: gs[s] = sum_c d_acc[c] chan[s][c]
-template <int LG> __device__ __forceinline__ void comp_flat_bwd_dot(const CompArgs &A, int64_t ray, int lane, float *gs) {
+template <int LG, bool VEC> __device__ __forceinline__ void comp_flat_bwd_dot(const CompArgs &A, int64_t ray, int lane, float *gs) {
   constexpr int LPS = 1 << LG;
-  const int nq = A.S << LG;
-  const f32x4 *src = (const f32x4 *)(A.chan + ray * A.S * A.C);
-  const f32x4 da = ((const f32x4 *)(A.d_acc + ray * A.C))[lane & (LPS - 1)];
+  const int nq = A.S << LG, c0 = 4 * (lane & (LPS - 1)), nv = A.C - c0;
+  const float *src = A.chan + ray * A.S * A.C + c0;
+  const f32x4 da = comp_ld4<VEC>(A.d_acc + ray * A.C + c0, nv);
   for (int q = lane; q < nq; q += 64) {
-    const f32x4 v = src[q];
+    const int sm = q >> LG;
+    const f32x4 v = comp_ld4<VEC>(src + (int64_t)sm * A.C, nv);
     float p = da[0] * v[0] + da[1] * v[1] + da[2] * v[2] + da[3] * v[3];
 #pragma unroll
     for (int o = 1; o < LPS; o <<= 1) p += __shfl_xor(p, o);
-    if ((lane & (LPS - 1)) == 0) gs[q >> LG] = p;
+    if ((lane & (LPS - 1)) == 0) gs[sm] = p;
   }
 }
 // backward, part B: d_chan[s][c] = w_s d_acc[c], channel 3 replaced by d sigma_s when the two alias
-template <int LG> __device__ __forceinline__ void comp_flat_bwd_store(const CompArgs &A, int64_t ray, int lane, const float *wl,
-                                                                      const float *dsl) {
+template <int LG, bool VEC> __device__ __forceinline__ void comp_flat_bwd_store(const CompArgs &A, int64_t ray, int lane,
+                                                                                const float *wl, const float *dsl) {
   constexpr int LPS = 1 << LG;
-  const int nq = A.S << LG;
-  f32x4 *dst = (f32x4 *)(A.d_chan + ray * A.S * A.C);
-  const f32x4 da = ((const f32x4 *)(A.d_acc + ray * A.C))[lane & (LPS - 1)];
-  const bool sig = A.fused_dsigma && (lane & (LPS - 1)) == 0;
+  const int nq = A.S << LG, c0 = 4 * (lane & (LPS - 1)), nv = A.C - c0;
+  float *dst = A.d_chan + ray * A.S * A.C + c0;
+  const f32x4 da = comp_ld4<VEC>(A.d_acc + ray * A.C + c0, nv);
+  const bool sig = A.fused_dsigma && c0 == 0;
   for (int q = lane; q < nq; q += 64) {
     const int sm = q >> LG;
     f32x4 o = wl[sm] * da;
     if (sig) o[3] = dsl[sm];
-    dst[q] = o;
+    comp_st4<VEC>(dst + (int64_t)sm * A.C, o, nv);
   }
 }
+// dispatch on (groups per sample, vector width)
+#define BN_COMP_FLAT(FN, ...)                                                     \
+  do {                                                                            \
+    if (A.flat_vec) {                                                             \
+      if (A.flat_lg == 0) FN<0, true>(__VA_ARGS__);                               \
+      else if (A.flat_lg == 1) FN<1, true>(__VA_ARGS__);                          \
+      else FN<2, true>(__VA_ARGS__);                                              \
+    } else {                                                                      \
+      if (A.flat_lg == 0) FN<0, false>(__VA_ARGS__);                              \
+      else if (A.flat_lg == 1) FN<1, false>(__VA_ARGS__);                         \
+      else FN<2, false>(__VA_ARGS__);                                             \
+    }                                                                             \
+  } while (0)
 __device__ __forceinline__ void lds_wave_sync() {   // LDS hand-over inside one wave: its DS operations execute in order
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -209,9 +242,7 @@ template <bool BWD> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void comp
         if (j < cpl && s < S) wl[s] = w[j];
       }
       lds_wave_sync();
-      if (A.flat_lg == 0) comp_flat_fwd<0>(A, ray, lane, wl);
-      else if (A.flat_lg == 1) comp_flat_fwd<1>(A, ray, lane, wl);
-      else comp_flat_fwd<2>(A, ray, lane, wl);
+      BN_COMP_FLAT(comp_flat_fwd, A, ray, lane, wl);
     } else if (A.chan && A.acc) {
       for (int c = 0; c < A.C; ++c) {
         float a = 0.f;
@@ -233,9 +264,7 @@ template <bool BWD> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void comp
         const int s = lane * cpl + j;
         if (j < cpl && s < S) wl[s] = w[j];
       }
-      if (A.flat_lg == 0) comp_flat_bwd_dot<0>(A, ray, lane, gs);
-      else if (A.flat_lg == 1) comp_flat_bwd_dot<1>(A, ray, lane, gs);
-      else comp_flat_bwd_dot<2>(A, ray, lane, gs);
+      BN_COMP_FLAT(comp_flat_bwd_dot, A, ray, lane, gs);
       lds_wave_sync();
     }
     float dacc[BN_MAX_CH];
@@ -277,18 +306,17 @@ template <bool BWD> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void comp
     }
     if (flat && A.d_chan) {
       lds_wave_sync();
-      if (A.flat_lg == 0) comp_flat_bwd_store<0>(A, ray, lane, wl, dsl);
-      else if (A.flat_lg == 1) comp_flat_bwd_store<1>(A, ray, lane, wl, dsl);
-      else comp_flat_bwd_store<2>(A, ray, lane, wl, dsl);
+      BN_COMP_FLAT(comp_flat_bwd_store, A, ray, lane, wl, dsl);
     }
   }
 }
 
-// flat channel path: dense rows of 4, 8 or 16 channels, 16-byte aligned blocks
-static int comp_flat_lg(const float *chan, int64_t chan_stride, int C, const void *p1, const void *p2) {
-  if (!chan || chan_stride != C || (C != 4 && C != 8 && C != 16)) return -1;
-  if (((uintptr_t)chan | (uintptr_t)p1 | (uintptr_t)p2) % 16 != 0) return -1;
-  return C == 4 ? 0 : (C == 8 ? 1 : 2);
+// flat channel path: dense rows (any C <= 16); float4 groups when C % 4 == 0 and every block is 16-byte aligned
+static void comp_flat_config(CompArgs &a, const float *chan, int64_t chan_stride, int C, const void *p1, const void *p2) {
+  a.flat_lg = -1; a.flat_vec = 0;
+  if (!chan || chan_stride != C || C < 1) return;
+  a.flat_lg = C <= 4 ? 0 : (C <= 8 ? 1 : 2);
+  a.flat_vec = (C % 4 == 0 && ((uintptr_t)chan | (uintptr_t)p1 | (uintptr_t)p2) % 16 == 0) ? 1 : 0;
 }
 
 extern "C" int bn_composite_forward(const float *z, const float *sigma, int64_t sigma_stride, const float *noise,
@@ -301,7 +329,8 @@ extern "C" int bn_composite_forward(const float *z, const float *sigma, int64_t 
   a.z = z; a.sigma = sigma; a.noise = noise; a.chan = chan; a.sigma_stride = sigma_stride; a.chan_stride = chan_stride;
   a.noise_std = noise_std; a.C = C; a.S = S; a.R = R;
   a.alphas = alphas; a.trans = trans; a.weights = weights; a.depth = depth; a.acc = acc;
-  a.flat_lg = acc ? comp_flat_lg(chan, chan_stride, C, acc, nullptr) : -1;
+  a.flat_lg = -1;
+  if (acc) comp_flat_config(a, chan, chan_stride, C, acc, nullptr);
 #ifdef BN_NO_FLAT_COMPOSITE      // A/B switch (profiles/ab_kernels.py): the per-(sample, channel) scalar path everywhere
   a.flat_lg = -1;
 #endif
@@ -324,7 +353,8 @@ extern "C" int bn_composite_backward(const float *z, const float *sigma, int64_t
   a.d_weights = d_weights; a.d_depth = d_depth; a.d_acc = d_acc; a.d_sigma = d_sigma; a.d_chan = d_chan;
   a.d_sigma_stride = d_sigma_stride; a.d_chan_stride = d_chan_stride;
   // flat path: needs d_acc (the dot products) and, when channel gradients are written, dense d_chan rows as well
-  a.flat_lg = (d_acc && (!d_chan || d_chan_stride == C)) ? comp_flat_lg(chan, chan_stride, C, d_acc, d_chan) : -1;
+  a.flat_lg = -1;
+  if (d_acc && (!d_chan || d_chan_stride == C)) comp_flat_config(a, chan, chan_stride, C, d_acc, d_chan);
 #ifdef BN_NO_FLAT_COMPOSITE
   a.flat_lg = -1;
 #endif

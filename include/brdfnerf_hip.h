@@ -240,6 +240,12 @@ int bn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
  * ------------------------------------------------------------------------------------------- */
 int bn_count_nonfinite(const float *x, int64_t n, unsigned long long *counts, void *stream);
 
+/* Device-side fault word of the fused kernels (bit 0: a wave of the barrier-free forward trunk gave up waiting for an LDS
+ * hand-over - never in a correct run; the affected launch's results are invalid).  The library mirrors the word to the
+ * host asynchronously and fails the NEXT bn_field_* call with BN_ELAUNCH once it is set; this call synchronises `stream`
+ * and reads it directly. */
+int bn_device_faults(unsigned int *faults, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart; the reference only has Lightning's wall-clock
  * "simple" profiler, main.py:731).  When enabled, every kernel launch of this library is

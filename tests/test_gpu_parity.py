@@ -130,6 +130,24 @@ def test_library_loads_on_gpu():
     assert _lib.lib().bn_abi_version() == 1
 
 
+def test_device_fault_word_stays_clear():
+    """The barrier-free bf16 forward trunk hands column halves over through LDS counters with bounded waits; a wait that
+    gave up would set the library's device fault word (and fail the next call with BN_ELAUNCH).  After real launches at
+    F = 512 in both 16-bit modes it must read 0."""
+    import ctypes as C
+    from brdf_nerf_amd import _lib
+    cfg = FieldConfig(funcM=1, funcF=1, funcH=1, normal="learned")
+    xyz = (torch.rand(40000, 3, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
+    for dtype in ("bf16", "fp16"):
+        model = build_model(cfg, 2, dtype)
+        with torch.no_grad():
+            model(xyz, apply_brdf=True, nr_lr_on=True)
+        model(xyz, apply_brdf=True, nr_lr_on=True).sum().backward()
+    faults = C.c_uint(123)
+    _lib.check(_lib.lib().bn_device_faults(C.byref(faults), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "bn_device_faults")
+    assert faults.value == 0
+
+
 # ------------------------------------------------------------------------------------------------ per-ray kernels
 def test_stratified_z():
     from brdf_nerf_amd import functions as Fn
@@ -1218,53 +1236,71 @@ def _learnable_table(n_rays, seed):
 
 
 PSNR_GATE = {   # name -> (model flags, steps of Lambertian pretraining, steps of the BRDF stage)
-    "lambert": (dict(), 320, 0),
-    "rpv_nan": (dict(funcM=1, funcF=1, funcH=1, normal="analystic"), 160, 160),
+    "lambert": (dict(), 400, 0),
+    "rpv_nan": (dict(funcM=1, funcF=1, funcH=1, normal="analystic"), 200, 200),
 }
+
+
+def _psnr_run(cfg, dtype, n_pre, n_brdf, train, held, draw_seed):
+    """One training run of the gate: each stage (Lambertian pretraining, then the BRDF stage: the reference trains them as
+    two runs, README.md:100-132) decays its learning rate from 5e-4 to 0 on a cosine, so the end state does not ride on the
+    slope of a still-climbing curve; returns (held-out PSNR, first-step training PSNR)."""
+    import math
+    from brdf_nerf_amd import load_model, losses
+    from brdf_nerf_amd.evaluate import render_image
+    from brdf_nerf_amd.trainer import FusedTrainer
+    args = make_args(cfg, dtype)
+    torch.manual_seed(0)
+    model = load_model(args).to(DEV)
+    tr = FusedTrainer(model, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+    train.load_state_dict({"gen": torch.Generator(device=DEV).manual_seed(5).get_state(), "perm": None, "cursor": 0, "epoch": 0})
+    torch.manual_seed(draw_seed)
+    first = None
+    for i in range(n_pre + n_brdf):
+        on = i >= n_pre
+        j, n = (i - n_pre, n_brdf) if on else (i, n_pre)
+        tr.lr = 5e-4 * math.cos(0.5 * math.pi * j / n) ** 2
+        b = train.next_batch(1024)
+        loss, rgb = tr.step(b["rays"], b["rgbs"], valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"],
+                            near_far=(0.0, 2.2), apply_brdf=on, apply_theta=on, cos_irra_on=on)
+        if i == 0:
+            first = float(losses.psnr(rgb, b["rgbs"]))
+    torch.manual_seed(2)
+    on = n_brdf > 0
+    res = render_image({"coarse": model}, args, held.data["rays"], held.data["rgbs"], keys=("rgb",), chunk=2048,
+                       apply_brdf=on, apply_theta=on, cos_irra_on=on)
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters()), dtype
+    return float(res["psnr"]), first
 
 
 @pytest.mark.parametrize("name", list(PSNR_GATE))
 def test_reduced_precision_heldout_psnr_tracks_fp32(name):
     """north_star: PSNR within 0.05 dB of the reference.  The fp32 mode is held to the reference by the golden tests; here
     the bf16 and fp16 throughput modes are trained beside it on a LEARNABLE scene - same initialisation, same batches,
-    same random draws, 320 fused steps of 1024 rays x (64 + 64) samples at F = 512 - and the PSNR of 8192 HELD-OUT rays
-    (never trained on) must agree with fp32's within 0.05 dB.  The run-to-run spread of fp32 itself (its fp32 atomics
-    are order dependent) is measured by a second fp32 run and reported."""
-    from brdf_nerf_amd import load_model, losses
-    from brdf_nerf_amd.evaluate import render_image
-    from brdf_nerf_amd.trainer import FusedTrainer
+    same random draws, 400 fused steps of 1024 rays x (64 + 64) samples at F = 512 - and the PSNR of 8192 HELD-OUT rays
+    (never trained on) must agree with fp32's within 0.05 dB.  Training amplifies rounding differences (the fp32 atomics of
+    the 16-bit pipelines are order dependent: the same binary differs from itself run to run), so every mode is run
+    BN_PSNR_REPEATS times (default 2, different sampling draws) and the MEANS are compared; the run-to-run spread of each
+    mode is reported beside them."""
     kw, n_pre, n_brdf = PSNR_GATE[name]
     cfg = FieldConfig(n_samples=64, guided_samples=64, **kw)
     train, held = _learnable_table(1024 * 64, 3), _learnable_table(8192, 11)
-    psnr, first = {}, {}
-    for run in ("fp32", "bf16", "fp16", "fp32_again"):
-        dtype = run.split("_")[0]
-        args = make_args(cfg, dtype)
-        torch.manual_seed(0)
-        model = load_model(args).to(DEV)
-        tr = FusedTrainer(model, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
-        train.load_state_dict({"gen": torch.Generator(device=DEV).manual_seed(5).get_state(), "perm": None, "cursor": 0, "epoch": 0})
-        torch.manual_seed(1)
-        for i in range(n_pre + n_brdf):
-            b = train.next_batch(1024)
-            on = i >= n_pre
-            loss, rgb = tr.step(b["rays"], b["rgbs"], valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"],
-                                near_far=(0.0, 2.2), apply_brdf=on, apply_theta=on, cos_irra_on=on)
-            if i == 0:
-                first[run] = float(losses.psnr(rgb, b["rgbs"]))
-        torch.manual_seed(2)
-        on = n_brdf > 0
-        res = render_image({"coarse": model}, args, held.data["rays"], held.data["rgbs"], keys=("rgb",), chunk=2048,
-                           apply_brdf=on, apply_theta=on, cos_irra_on=on)
-        psnr[run] = float(res["psnr"])
-        assert all(bool(torch.isfinite(p).all()) for p in model.parameters()), run
-    diag(f"held-out PSNR {name} after {n_pre}+{n_brdf} steps (first-step train PSNR {first['fp32']:.2f} dB): "
-         + ", ".join(f"{k} {v:.4f} dB" for k, v in psnr.items())
-         + f"; |bf16-fp32| {abs(psnr['bf16'] - psnr['fp32']):.4f}, |fp16-fp32| {abs(psnr['fp16'] - psnr['fp32']):.4f}, "
-           f"fp32 run-to-run {abs(psnr['fp32_again'] - psnr['fp32']):.4f}")
-    assert psnr["fp32"] > first["fp32"] + 3.0, (psnr, first)          # the scene was learned, the gate is not vacuous
-    assert abs(psnr["bf16"] - psnr["fp32"]) <= 0.05, psnr
-    assert abs(psnr["fp16"] - psnr["fp32"]) <= 0.05, psnr
+    reps = int(os.environ.get("BN_PSNR_REPEATS", "2"))
+    psnr, first = {}, None
+    for dtype in ("fp32", "bf16", "fp16"):
+        runs = []
+        for r in range(reps):
+            p, f = _psnr_run(cfg, dtype, n_pre, n_brdf, train, held, draw_seed=1 + r)
+            runs.append(p)
+            first = f if first is None else first
+        psnr[dtype] = runs
+    mean = {k: sum(v) / len(v) for k, v in psnr.items()}
+    diag(f"held-out PSNR {name} after {n_pre}+{n_brdf} steps (first-step train PSNR {first:.2f} dB), {reps} runs per mode: "
+         + ", ".join(f"{k} {mean[k]:.4f} dB (runs {' '.join(f'{x:.4f}' for x in v)})" for k, v in psnr.items())
+         + f"; |bf16-fp32| {abs(mean['bf16'] - mean['fp32']):.4f}, |fp16-fp32| {abs(mean['fp16'] - mean['fp32']):.4f}")
+    assert mean["fp32"] > first + 3.0, (psnr, first)          # the scene was learned, the gate is not vacuous
+    assert abs(mean["bf16"] - mean["fp32"]) <= 0.05, psnr
+    assert abs(mean["fp16"] - mean["fp32"]) <= 0.05, psnr
 
 
 @pytest.mark.parametrize("name", ["lambert", "rpv_nan"])
