@@ -61,3 +61,10 @@ def normal_loss(weights, normal_gt, normal_pred, lambda_nr_spv, keyword="an_lr",
     sel = valid_depth > 0
     tw = target_weight[sel].unsqueeze(-1)
     return lambda_nr_spv * torch.mean((tw * normal_gt[sel] - tw * pred[sel]).abs())
+
+
+def psnr(image_pred, image_gt):
+    """metrics.py:292-325 (mse / psnr_ / psnr with valid_mask=None, reduction='mean', scl=False): the squared error is
+    normalised by max(image_gt)^2 before the mean; returns the first element of the reference's (psnr, psnr_scl) pair."""
+    value = (image_pred - image_gt) ** 2 / (torch.max(image_gt) ** 2)
+    return -10.0 * torch.log10(torch.mean(value))

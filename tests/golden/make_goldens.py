@@ -452,9 +452,44 @@ def gen_regularisers(ref):
          d_normal_an=n_an.grad, d_normal_lr=n_lr.grad)
 
 
+INIT_CONFIGS = {
+    "lambert": dict(),
+    "rpv111_anlr": dict(funcM=1, funcF=1, funcH=1, normal="analystic_learned"),
+    "hapke_bct_nlr": dict(b=1, c=1, theta=1, normal="learned"),
+    "microfacet_nlr": dict(roughness=True, normal="learned"),
+    "relu_rpvM": dict(siren=False, funcM=1),
+    "nomap": dict(mapping=False),
+}
+
+
+def gen_init(ref):
+    """state_dict of the reference's load_model(args) under torch.manual_seed(7) (models/__init__.py:6-17; inits
+    models/spsbrdfnerf.py:537-539, models/nerf.py:9-21): the FULL state_dict for the RPV + both-normals model (every layer
+    type), and per-tensor fingerprints (float64 sum, sum of |.|, first / last 8 elements) for the other head sets.  Pins
+    the drop-in module's "same seed -> same weights" contract: layer construction order and init calls consume the RNG
+    stream exactly like upstream."""
+    out = {}
+    for name, kw in INIT_CONFIGS.items():
+        cfg = mini(**kw)
+        torch.manual_seed(7)
+        model = quiet(ref["models"].load_model, ref_args(cfg))
+        sd = model.state_dict()
+        out[f"{name}/keys"] = np.array("\n".join(sd.keys()))
+        for k, v in sd.items():
+            f = v.detach().double().flatten()
+            if name == "rpv111_anlr":
+                out[f"{name}/full/{k}"] = v.detach().numpy()
+            out[f"{name}/fp/{k}"] = np.concatenate([[float(f.sum()), float(f.abs().sum()), float(f.numel())],
+                                                    f[:8].numpy(), f[-8:].numpy()])
+    save("init_state_dicts", seed=7, **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     ref = import_reference()
+    if "--only-init" in sys.argv:
+        gen_init(ref)
+        sys.exit(0)
     if "--only-field-variants" in sys.argv:
         gen_field_variants(ref)
         sys.exit(0)
@@ -475,3 +510,4 @@ if __name__ == "__main__":
     gen_render(ref)
     gen_loss(ref)
     gen_regularisers(ref)
+    gen_init(ref)

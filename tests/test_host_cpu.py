@@ -94,6 +94,30 @@ def test_init_ranges_follow_reference():
     assert float(model.sigma_from_xyz[0].weight.abs().max()) <= 1 / np.sqrt(128) + 1e-6   # nn.Linear default
 
 
+def test_init_is_rng_order_identical_to_reference():
+    """tests/golden/init_state_dicts.npz: state_dict of the REFERENCE's load_model(args) under torch.manual_seed(7) (rows
+    a4 / a21 of SURVEY section 8).  The drop-in module built under the same seed must hold the same bits: same keys in
+    the same order, every tensor of the RPV + both-normals model equal, and the fingerprints (sum, sum |.|, size, first /
+    last 8 elements) of every tensor of the other head sets."""
+    from brdf_nerf_amd import load_model
+    g = load_golden("init_state_dicts")
+    seed = int(g["seed"])
+    kinds = {"lambert": dict(), "rpv111_anlr": dict(funcM=1, funcF=1, funcH=1, normal="analystic_learned"),
+             "hapke_bct_nlr": dict(b=1, c=1, theta=1, normal="learned"), "microfacet_nlr": dict(roughness=True, normal="learned"),
+             "relu_rpvM": dict(siren=False, funcM=1), "nomap": dict(mapping=False)}
+    for name, kw in kinds.items():
+        cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16, **kw)
+        torch.manual_seed(seed)
+        sd = load_model(make_args(cfg)).state_dict()
+        assert list(sd) == str(g[f"{name}/keys"]).split("\n"), name
+        for k, v in sd.items():
+            f = v.detach().double().flatten()
+            fp = np.concatenate([[float(f.sum()), float(f.abs().sum()), float(f.numel())], f[:8].numpy(), f[-8:].numpy()])
+            assert np.array_equal(fp, g[f"{name}/fp/{k}"]), (name, k)
+            if name == "rpv111_anlr":
+                assert np.array_equal(v.numpy(), g[f"{name}/full/{k}"]), (name, k)
+
+
 def test_unsupported_flags_raise():
     from brdf_nerf_amd import load_model
     for over in (dict(beta=True), dict(sun_v="learned"), dict(input_viewdir=1), dict(indirect_light=True)):

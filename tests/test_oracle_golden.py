@@ -220,6 +220,7 @@ def test_losses():
     (l_rgb + l_ds).backward()
     assert_close(rgb.grad, g["drgb"], 1e-6, 1e-9, "drgb")
     assert_close(depth.grad, g["ddepth"], 1e-6, 1e-9, "ddepth")
+    assert_close(L.psnr(t["rgb"], t["tgt"]), g["psnr"], 1e-6, 1e-6, "psnr")
 
 
 @pytest.mark.parametrize("tag,extra,gs", [("rpv111_nlr_multibrdf", dict(MultiBRDF=True), False), ("rpv111_nlr_gsamonly", dict(), True)])
