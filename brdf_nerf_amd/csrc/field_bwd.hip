@@ -256,6 +256,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
       const size_t off = (l == g.L ? A.pl.bwd_feats : A.pl.bwd_trunk[l]) + (size_t)(ncol0 / 32) * KSF * 512;
       // the row-major stash copy of the tile this GEMM reads (dFeats, then dZ_l) rides inside the GEMM
       if (folded_top) {
+#ifdef BN_AB_BWD_NATIVE_DZ   // ablation (weight gradients wrong): no riding row-major dZ copy; dZ is stored in accumulator order
+      } else if (true) {     // from the epilogue's registers instead - what a native-order dZ stash would cost the chain
+        gemm_seg<T, MT, NT>(acc, packed + off, KSF, ACT, LDA, lane);
+#endif
       } else if (ride) {
         TileCopyExact<T> zcopy(ACT, LDA, zdst, F, F, tid, WAVES * 64);
         gemm_seg<T, MT, NT>(acc, packed + off, KSF, ACT, LDA, lane, zcopy);
@@ -311,6 +315,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
             }
             *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), v[0], v[1], v[2], v[3]);
             *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), v[4], v[5], v[6], v[7]);
+#ifdef BN_AB_BWD_NATIVE_DZ
+            st8((T *)(A.stash + A.sl.dZ[lo]) + (size_t)tile * BM * F + native_off8<MT, NT>(wave, nt, mt, gp, lane), v);
+#endif
           }
         }
     }
@@ -318,7 +325,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
     __syncthreads();
     BN_PH(12)
   }
+#ifndef BN_AB_BWD_NATIVE_DZ
   tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dZ[0]) + (size_t)m0 * F, F, BM, F);
+#endif
   BN_PH(13)
 #ifndef BN_PHASE_TIMING_WGRAD
   BN_PH_FLUSH

@@ -202,7 +202,12 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
     if args.model != "spsbrdf-nerf":
         raise ValueError("brdf_nerf_amd.render_rays serves --model spsbrdf-nerf only")
     if args.n_importance > 0:
-        raise NotImplementedError("fine pass (n_importance > 0) is an optional extension (SURVEY.md section 8f rank 4)")
+        # rendering.py:294-332 calls `inference(models['fine'], ...)` through its generic `else:` branch for this model and then
+        # iterates `result.keys()` - but spsbrdfnerf.inference returns a (dict, brdf_type) TUPLE: the reference raises
+        # AttributeError("'tuple' object has no attribute 'keys'") for every spsbrdf-nerf run with --n_importance > 0
+        # (probed in the build container).  There is no upstream behaviour to reproduce.
+        raise NotImplementedError("n_importance > 0: the reference itself raises AttributeError in its fine pass for --model "
+                                  "spsbrdf-nerf (rendering.py:327-330: spsbrdfnerf.inference returns a tuple); nothing to mirror")
     if rows is not None or cols is not None:
         raise NotImplementedError("ref_sphere visualisation is out of the hot-path scope")
     model = models["coarse"]

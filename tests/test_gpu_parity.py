@@ -777,6 +777,46 @@ def test_field_backward_through_analytic_normals_only_normal_loss_F512():
         assert err <= 2e-3 * scale + 1e-6 * gscale, f"{k}: err {err:.3e} scale {scale:.3e} (global {gscale:.3e})"
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("which", ["all_channels", "normals_only"])
+def test_field_backward_through_analytic_normals_half(which, dtype):
+    """The double backward in the 16-bit modes at F = 512 against the fp32 oracle's autograd: cosine per parameter tensor.
+    'normals_only' isolates the adjoint-chain backward (in fp16: its own loss scale, the zbar hand-over to the primal chain
+    at a third scale); 'all_channels' mixes it with the primal seeds."""
+    cfg = FieldConfig(funcM=1, funcF=1, funcH=1, normal="analystic")
+    flags = dict(apply_brdf=True, apply_theta=True, nr_an_on=True)
+    model = build_model(cfg, 6, dtype)
+    p = tparams(cfg, 6)
+    for v in p.values():
+        v.requires_grad_(True)
+    g = torch.Generator().manual_seed(78)
+    B = 1500
+    xyz = torch.rand(B, 3, generator=g) * 2 - 1
+    ref = OF.field_forward(p, cfg, xyz, **flags)
+    coef = torch.randn(ref.shape, generator=g)
+    if which == "normals_only":
+        coef[:, :4] = 0
+        coef[:, 7:] = 0
+    (ref * coef).sum().backward()
+    out = model(xyz.to(DEV), **flags)
+    (out * coef.to(DEV)).sum().backward()
+    worst, bound = 1.0, (0.97 if dtype == "bf16" else 0.995)
+    for k, v in model.named_parameters():
+        want = p[k].grad
+        if want is None or float(want.abs().max()) == 0.0:
+            continue
+        got = v.grad.cpu().flatten()
+        assert bool(torch.isfinite(got).all()), k
+        want = want.flatten()
+        if float(want.norm()) < 1e-6 * max(float(x.grad.norm()) for x in p.values() if x.grad is not None):
+            continue                                   # sums of cancelling per-point terms (sigma bias): direction undefined
+        cos = float((want * got).sum() / (want.norm() * got.norm() + 1e-30))
+        ratio = float(got.norm() / (want.norm() + 1e-30))
+        diag(f"{dtype} field backward through analytic normals ({which}) {k}: cosine {cos:.6f}, norm ratio {ratio:.4f}")
+        worst = min(worst, cos)
+        assert cos > bound and 0.9 < ratio < 1.1, f"{k}: cosine {cos}, norm ratio {ratio}"
+
+
 @pytest.mark.parametrize("name", list(CONFIGS_AN))
 def test_render_rays_train_analytic_normal_golden_fp32(name):
     """End-to-end training step gradients with --normal analystic (BASELINE config 3 shape of graph) vs the reference."""
@@ -803,14 +843,17 @@ def test_render_rays_train_analytic_normal_golden_fp32(name):
 
 
 # ------------------------------------------------------------------------------------------------ fused trainer
-@pytest.mark.parametrize("name,with_depth", [("lambert", False), ("lambert", True), ("rpv111_nlr", True), ("rpv111_nan", False)])
+@pytest.mark.parametrize("name,with_depth", [("lambert", False), ("lambert", True), ("rpv111_nlr", True), ("rpv111_nan", False),
+                                             ("rpv111_nlr_multibrdf", False), ("hapke_bct_multibrdf", True)])
 def test_fused_trainer_matches_autograd_path(name, with_depth):
     """FusedTrainer.step (the path bench.py times) == render_rays + losses + loss.backward() + torch.optim.Adam, same draws.
     With depth priors the reference's quirk 7 (target_std == 0) is used, so the ground-truth-guided rows do not depend on
     their uniform draws (the trainer draws (R,G) instead of (n_valid,G) to avoid a host sync)."""
     from brdf_nerf_amd import render_rays, losses
     from brdf_nerf_amd.trainer import FusedTrainer
-    allc = dict(CONFIGS, **CONFIGS_AN)
+    # --MultiBRDF: one BRDF per SAMPLE (spsbrdfnerf.py:289-307,350-352): the loss reads per-sample field outputs directly
+    allc = dict(CONFIGS, **CONFIGS_AN, rpv111_nlr_multibrdf=dict(CONFIGS["rpv111_nlr"], MultiBRDF=True),
+                hapke_bct_multibrdf=dict(CONFIGS["hapke_bct"], MultiBRDF=True))
     cfg = mini(**allc[name])
     args = make_args(cfg)
     g = torch.Generator().manual_seed(3)
@@ -1181,7 +1224,11 @@ def test_render_image_against_oracle():
         img = render_image({"coarse": model}, args, rays.to(DEV), tgt.to(DEV), keys=("rgb", "depth"), chunk=chunk, **flags)
     assert set(img) == {"rgb", "depth", "psnr"}
     want_rgb, want_depth = torch.cat(want_rgb), torch.cat(want_depth)
-    assert_close(img["rgb"], want_rgb, 2e-4, 2e-5, "rgb")
+    diag(f"render_image vs oracle: max |rgb err| {float((img['rgb'].cpu() - want_rgb).abs().max()):.3e}, "
+         f"max |depth err| {float((img['depth'].cpu() - want_depth).abs().max()):.3e}")
+    # RPV shading of a two-pass render: pass-1 differences of 1e-6 in depth reach the guided samples through the 2^9 PE
+    # octave (same bound as the end-to-end golden tests of the BRDF variants)
+    assert_close(img["rgb"], want_rgb, 5e-4, 5e-5, "rgb")
     assert_close(img["depth"], want_depth, 1e-4, 2e-5, "depth")
     assert_close(img["psnr"], OL.psnr(want_rgb, tgt), 1e-4, 1e-4, "psnr")
 
@@ -1368,7 +1415,8 @@ def _learnable_table(n_rays, seed):
 
 PSNR_GATE = {   # name -> (model flags, steps of Lambertian pretraining, steps of the BRDF stage)
     "lambert": (dict(), 400, 0),
-    "rpv_nan": (dict(funcM=1, funcF=1, funcH=1, normal="analystic"), 200, int(os.environ.get("BN_PSNR_BRDF_STEPS", "600"))),
+    "rpv_nan": (dict(funcM=1, funcF=1, funcH=1, normal="analystic"), int(os.environ.get("BN_PSNR_PRE_STEPS", "200")),
+                int(os.environ.get("BN_PSNR_BRDF_STEPS", "600"))),
 }
 
 
