@@ -3,6 +3,12 @@
 //
 // Forward adjoint (field_adjoint.hip):  a_L = s' w_sigma ; delta_l = a_{l+1} (.) D_l ; [g_PE ; a_l] += W_l^T delta_l ;
 //                                        g = J_PE(x)^T g_PE ; n = -g / |g|.
+// The forward chain runs, and stashes, the s'-free quantities a' = a / s', delta' = delta / s' (s' = sigmoid(sigma_raw) is a
+// per-point scalar).  Everything below is bilinear in (forward, backward) quantities, so this kernel runs on
+// gbar' = s' gbar, abar' = s' abar, dbar' = s' dbar and every product it forms is the true one:
+//   zbar_l = -w0^2 y_l dbar_l a_{l+1} = -w0^2 y_l dbar'_l a'_{l+1};  dW_l += delta_l^T [..] = delta'_l^T [gbar'_PE ; abar'_l];
+//   dw_sigma += s'^T abar_L = 1^T abar'_L;  sbar = (w_sigma . abar_L) s'(1 - s') = (w_sigma . abar'_L)(1 - s').
+// The seed s' gbar = -s' (dn - n (n . dn)) / |g| has |g| = s' |g'|: the tiny factor cancels there too.
 // Given dL/dn this kernel walks the chain the other way, which has the shape of a FORWARD pass of the field:
 //   gbar_PE = J_PE(x) gbar ;   for l = 0 .. L-1:  dbar_l = W_l [gbar_PE ; abar_l]      (same packed weights as the forward)
 //                                                  abar_{l+1} = dbar_l (.) D_l
@@ -59,7 +65,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       const float gd = gx[0] * dn[0] + gx[1] * dn[1] + gx[2] * dn[2];
       const float k = n2 > eps ? gd * inv * inv * inv : 0.f;     // n = -g * inv
 #pragma unroll
-      for (int c = 0; c < 3; ++c) gb[c] = -(dn[c] * inv - gx[c] * k) * gs;
+      const float spm = ((const float *)(A.stash + A.sl.sprime))[gm];       // gbar' = s' gbar
+      for (int c = 0; c < 3; ++c) gb[c] = -(dn[c] * inv - gx[c] * k) * spm * gs;
       if (A.pts.xyz) {
         x[0] = A.pts.xyz[gm * 3]; x[1] = A.pts.xyz[gm * 3 + 1]; x[2] = A.pts.xyz[gm * 3 + 2];
       } else {
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
     for (int o = 1; o < TPR; o <<= 1) ds += __shfl_xor(ds, o);
     if (q == 0) {
       const float sp = ((const float *)(A.stash + A.sl.sprime))[m0 + m];
-      ((float *)(A.stash + A.sl.sbar))[m0 + m] = ds * sp * (1.f - sp) / gs;
+      ((float *)(A.stash + A.sl.sbar))[m0 + m] = ds * (1.f - sp) / gs;      // ds = w_sigma . abar'_L
     }
   }
 }

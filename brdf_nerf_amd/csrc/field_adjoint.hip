@@ -3,6 +3,11 @@
 // section 8 row a8, validated against autograd in fp64 by the oracle tests):
 //   a_L = sigmoid(sigma_raw) * w_sigma ;  for l = L-1 .. 0:  delta_l = a_{l+1} (.) D_l ,  [g_PE ; a_l] += W_l^T delta_l
 //   d sigma/d x_c = sum_k f_k ( cos(f_k x_c) g_PE[sin,k,c] - sin(f_k x_c) g_PE[cos,k,c] ),  f_k = 2^k
+// The chain is linear in s' = sigmoid(sigma_raw), a per-point scalar that reaches 1e-5 and below in empty space: it is
+// carried OUTSIDE the 16-bit chain (the chain runs on a'_l = a_l / s', i.e. seeds with w_sigma alone; the fp32 epilogue
+// multiplies the finished gradient by s').  Same function; the 16-bit operands keep their precision wherever the density
+// is low (fp16 would otherwise work on subnormals there), and the backward of this chain (field_adjbwd.hip) scales its
+// seeds by s' instead - which cancels the 1/|g| of the normalisation, so its operands lose the tiny factor as well.
 // It reuses the backward-chain tiling: delta tiles live in LDS, W_l^T streams from L2 in packed fragment order, D_l
 // comes from the forward's stash.  The two PE-part products (l = skip and l = 0; 64 x BM outputs) are spread over all
 // 8 waves (one 32x32 tile each) and accumulated in an fp32 LDS image.
@@ -45,9 +50,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
   // delta_{L-1} = (sigmoid(s_raw) w_sigma) (.) D_{L-1}
   if (wave_on) {
     const T *Ds = (const T *)(A.stash + A.sl.D[g.L - 1]) + (size_t)tile * BM * F;
-    float sp[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) sp[mt] = sigmoid_f(sraw[m0 + mt * 32 + r]);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
           const int m = mt * 32 + r;
           float av[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { av[e] = wa[e] * sp[mt]; av[4 + e] = wb[e] * sp[mt]; }
+          for (int e = 0; e < 4; ++e) { av[e] = wa[e]; av[4 + e] = wb[e]; }      // a'_L = w_sigma (s' is applied at the end)
           if (keep) st8((T *)(wstash + A.sl.adj_a[g.L - 1]) + (size_t)tile * BM * F + native_off8<MT, NT>(wave, nt, mt, gp, lane), av);
           *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), av[0] * dv[0], av[1] * dv[1], av[2] * dv[2], av[3] * dv[3]);
           *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), av[4] * dv[4], av[5] * dv[5], av[6] * dv[6], av[7] * dv[7]);
@@ -176,6 +178,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
       } else {
         gx[0] = gp[0]; gx[1] = gp[1]; gx[2] = gp[2];
       }
+      const float spm = sigmoid_f(sraw[gm]);      // the chain ran on a' = a / s': back to d sigma / d xyz
+      gx[0] *= spm; gx[1] *= spm; gx[2] *= spm;
       if (A.grad_x) { A.grad_x[gm * 3] = gx[0]; A.grad_x[gm * 3 + 1] = gx[1]; A.grad_x[gm * 3 + 2] = gx[2]; }
       if (keep) { float *gs = (float *)(wstash + A.sl.gradx) + gm * 4; gs[0] = gx[0]; gs[1] = gx[1]; gs[2] = gx[2]; gs[3] = 0.f; }
       const float inv = -1.f / sqrtf(fmaxf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2], 1.1920928955078125e-07f));

@@ -101,7 +101,9 @@ template <int WHICH> __global__ __launch_bounds__(256) void grad_amax_kernel(con
       const float k = n2 > eps ? gd * inv * inv * inv : 0.f;
       const float fmx = g.pe_freqs > 0 ? (float)(1 << (g.pe_freqs - 1)) : 1.f;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { const float a = fabsf(dn[c] * inv - gx[c] * k) * fmx; mx = (a < 3.0e38f && a > mx) ? a : mx; }
+      const float spm = ((const float *)(A.stash + A.sl.sprime))[gm];       // the chain's seeds are s' gbar (field_adjbwd.hip)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { const float a = fabsf(dn[c] * inv - gx[c] * k) * spm * fmx; mx = (a < 3.0e38f && a > mx) ? a : mx; }
     }
   }
 #pragma unroll
@@ -704,6 +706,7 @@ struct SkinnyJob {
   float *out[4];       // row c of the gradient: out[c][k], k < K
   float *bias[4];      // scalar bias gradient of row c (nullable)
   int scale_sel;       // fp16 loss scaling carried by X (see WgradJob.scale_sel; the fp32 dpre columns are never scaled)
+  int unit_dpre;       // 1: dpre == 1 for every point (column sums of X)
 };
 #define BN_MAX_SKINNY_JOBS 8
 struct SkinnyArgs {
@@ -803,7 +806,7 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
       const float *dp = J.dpre + m * J.ldp + J.p_col0;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float d = dp[c];
+        const float d = J.unit_dpre ? 1.f : dp[c];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[c][e] += d * x[e];
         bs[c] += d;
@@ -963,7 +966,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   }
   SkinnyArgs s;
   s.n_jobs = 0; s.Mpad = sl.Mpad; s.amax = amax;
-  for (int i = 0; i < BN_MAX_SKINNY_JOBS; ++i) s.job[i].scale_sel = 0;   // X = forward activations unless noted
+  for (int i = 0; i < BN_MAX_SKINNY_JOBS; ++i) { s.job[i].scale_sel = 0; s.job[i].unit_dpre = 0; }   // X = forward activations unless noted
   {
     SkinnyJob &j = s.job[s.n_jobs];
     j.X = S + sl.Y[g.L - 1]; j.ldx = F; j.x_col0 = 0; j.K = F; j.dpre = (const float *)(S + sl.dpre_trunk); j.ldp = 4; j.p_col0 = 0;
@@ -976,8 +979,9 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     }
     if (j.out[0]) ++s.n_jobs;
   }
-  if (a.an && G->sigma_w) {  // dw_sigma += sum_m s'(m) abar_L[m][:]
+  if (a.an && G->sigma_w) {  // dw_sigma += sum_m s'(m) abar_L[m][:] = sum_m abar'_L[m][:]  (the stash holds abar' = s' abar)
     SkinnyJob &j = s.job[s.n_jobs++];
+    j.unit_dpre = 1;
     j.scale_sel = 2;   // abar_L carries the adjoint chain's loss scale
     j.X = S + sl.adj_abar[g.L]; j.ldx = F; j.x_col0 = 0; j.K = F; j.dpre = (const float *)(S + sl.sprime); j.ldp = 1; j.p_col0 = 0; j.nc = 1; j.native = 0;
     for (int c = 0; c < 4; ++c) { j.out[c] = nullptr; j.bias[c] = nullptr; }
