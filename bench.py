@@ -227,6 +227,11 @@ def main():
     if a.gpus > 1 and not under_launcher:
         spawn_ranks(a)
         return
+    # stdout carries ONE JSON line and nothing else: libraries that chat on fd 1 (gloo's "[Gloo] Rank 0 is connected ...",
+    # RCCL with NCCL_DEBUG set) are sent to stderr for the whole run; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -400,7 +405,8 @@ def main():
     }
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
-    print(json.dumps(line), flush=True)
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
