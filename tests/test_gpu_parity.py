@@ -1545,6 +1545,38 @@ def test_two_rank_step_matches_one_rank(name):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
 
 
+def test_ray_table_on_device_feeds_the_fused_step():
+    """the ray table lives in HBM, batches are gathers by a device permutation (no host round trip):
+    every row exactly once per epoch, rank shards partition each global batch, the generator state resumes the stream, and
+    a batch goes straight into the fused step."""
+    from brdf_nerf_amd import load_model
+    from brdf_nerf_amd.raytable import synthetic_table
+    from brdf_nerf_amd.trainer import FusedTrainer
+    t = synthetic_table(1000, device=DEV, seed=3)
+    assert all(v.is_cuda for v in t.data.values()) and t.data["rays"].shape == (1000, 11)
+    tag = torch.arange(1000.0, device=DEV)
+    t.data["rgbs"][:, 0] = tag
+    seen = torch.cat([t.next_batch(96)["rgbs"][:, 0] for _ in range(11)])          # 10 x 96 + 40
+    assert seen.numel() == 1000 and bool((torch.sort(seen)[0] == tag).all()) and t.epoch == 0
+    state = t.state_dict()
+    nxt = t.next_batch(96)["rgbs"][:, 0].clone()
+    assert t.epoch == 1
+    shards = [synthetic_table(1000, device=DEV, seed=3) for _ in range(3)]
+    for s_ in shards:
+        s_.data["rgbs"][:, 0] = tag
+        s_.load_state_dict(state)
+    parts = [s_.next_batch(96, rank=r, world=3)["rgbs"][:, 0] for r, s_ in enumerate(shards)]
+    assert torch.equal(torch.cat(parts), nxt)                                         # shards partition the global batch, in order
+    cfg = mini()
+    args = make_args(cfg)
+    torch.manual_seed(0)
+    tr = FusedTrainer(load_model(args).to(DEV), args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+    t.data["rgbs"][:, 0] = 0.5
+    b = t.next_batch(64)
+    loss, rgb = tr.step(b["rays"], b["rgbs"], valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"])
+    assert rgb.shape == (64, 3) and bool(torch.isfinite(loss)) and bool(torch.isfinite(tr.flat_grad).all())
+
+
 def test_count_nonfinite_hook():
     """Sync-free replacement of check_nan (train_utils.py:14-25): NaN and Inf counters accumulate on the device."""
     from brdf_nerf_amd import functions as Fn
