@@ -53,6 +53,10 @@ template <> struct Elem<bf16> {
   typedef bf16x8 frag;
   typedef bf16x4 vec4;
   typedef bf16 wide;                // storage type of element-wise stashes that need fp32's exponent range
+  // Y_l (the layer outputs the weight gradient multiplies by) is stashed in accumulator-native order, written straight from
+  // the forward epilogue's registers: no row-major copy riding in the next GEMM.  The weight-gradient kernel stages native
+  // chunks (field_bwd.hip, w2_body<.., BNAT>); the fp32 parity mode keeps the row-major stash.
+  static constexpr bool kNativeY = true;
   static constexpr int kBM = 128;   // points per workgroup tile
   static constexpr int kPad = 8;    // LDS row pad (elements) = 16 B
   static constexpr int kU = 2;      // k-steps per prefetch block
@@ -65,6 +69,7 @@ template <> struct Elem<f16> {
   typedef f16x8 frag;
   typedef f16x4 vec4;
   typedef bf16 wide;
+  static constexpr bool kNativeY = true;
   static constexpr int kBM = 128;
   static constexpr int kPad = 8;
   static constexpr int kU = 2;
@@ -74,6 +79,7 @@ template <> struct Elem<float> {
   typedef f32x8 frag;
   typedef f32x4 vec4;
   typedef float wide;
+  static constexpr bool kNativeY = false;
   static constexpr int kBM = 64;
   static constexpr int kPad = 4;
   static constexpr int kU = 2;

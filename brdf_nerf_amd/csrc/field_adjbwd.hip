@@ -37,6 +37,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
   constexpr int PADE = Elem<T>::kPad;
+  constexpr bool NATY = Elem<T>::kNativeY;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const FieldGeom &g = A.g;
   const int F = g.F, LDA = F + PADE, KP = g.KP, LDP = KP + PADE, P = g.P;
@@ -64,8 +65,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       const float inv = 1.f / sqrtf(fmaxf(n2, eps));
       const float gd = gx[0] * dn[0] + gx[1] * dn[1] + gx[2] * dn[2];
       const float k = n2 > eps ? gd * inv * inv * inv : 0.f;     // n = -g * inv
-#pragma unroll
       const float spm = ((const float *)(A.stash + A.sl.sprime))[gm];       // gbar' = s' gbar
+#pragma unroll
       for (int c = 0; c < 3; ++c) gb[c] = -(dn[c] * inv - gx[c] * k) * spm * gs;
       if (A.pts.xyz) {
         x[0] = A.pts.xyz[gm * 3]; x[1] = A.pts.xyz[gm * 3 + 1]; x[2] = A.pts.xyz[gm * 3 + 2];
@@ -120,10 +121,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       }
     }
     __syncthreads();
-    // y_l is stashed row-major (for the weight-gradient GEMMs): stage the tile through ACT, which the GEMM has finished
-    // reading, with coalesced 16-byte loads, instead of 8-byte reads scattered over 32 rows per wave instruction.  Each
-    // lane then reads the values at exactly the positions it overwrites with abar_{l+1}.
-    {
+    // fp32 mode: y_l is stashed row-major (for the weight-gradient GEMMs): stage the tile through ACT, which the GEMM has
+    // finished reading, with coalesced 16-byte loads, instead of 8-byte reads scattered over 32 rows per wave instruction.
+    // Each lane then reads the values at exactly the positions it overwrites with abar_{l+1}.  16-bit modes: y_l is stashed
+    // in accumulator order and read straight into registers in the epilogue below - no staging, no extra barrier.
+    if (!NATY) {
       constexpr int EPC = 16 / sizeof(T);
       const int cpr = F / EPC, rpp = (WAVES * 64) / cpr, row0 = tid / cpr, cc = (tid % cpr) * EPC;
       const int passes = BM / rpp;
@@ -140,14 +142,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
         for (int i = 0; i < passes; ++i)
           *(u32x4 *)(ACT + (size_t)(row0 + i * rpp) * LDA + cc) = stash_load((const u32x4 *)(Yg + (size_t)(row0 + i * rpp) * F + cc));
       }
+      __syncthreads();
     }
-    __syncthreads();
     if (wave_on) {
       const float w0 = (l == 0) ? 30.f : 1.f;
       const float unscale = A.prescaled ? 6.283185307179586f / w0 : 1.f;
       const float e2 = g.act == BN_ACT_SIN ? -w0 * w0 : 0.f;      // dD/dz = -w0^2 sin(w0 z) = -w0^2 y (0 for ReLU)
       const T *Ds = (const T *)(A.stash + A.sl.D[l]) + (size_t)tile * BM * F;
       const T *As = (const T *)(A.stash + A.sl.adj_a[l]) + (size_t)tile * BM * F;
+      const T *Yn = (const T *)(A.stash + A.sl.Y[l]) + (size_t)tile * BM * F;        // native-order y_l (16-bit modes)
       typename Elem<T>::wide *Zs = (typename Elem<T>::wide *)(A.stash + A.sl.adj_zbar[l]) + (size_t)tile * BM * F;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
@@ -157,17 +160,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const int m = mt * 32 + r;
-            float dv[8], av[8], zb[8], db[8];
+            float dv[8], av[8], zb[8], db[8], yv[8];
             ld8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dv);
             ld8(As + native_off8<MT, NT>(wave, nt, mt, gp, lane), av);
-            const vec4 ya = *(const vec4 *)(ACT + (size_t)m * LDA + n0), yb = *(const vec4 *)(ACT + (size_t)m * LDA + n0 + 8);
+            if (NATY) {
+              ld8(Yn + native_off8<MT, NT>(wave, nt, mt, gp, lane), yv);
+            } else {
+              const vec4 ya = *(const vec4 *)(ACT + (size_t)m * LDA + n0), yb = *(const vec4 *)(ACT + (size_t)m * LDA + n0 + 8);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { yv[e] = (float)ya[e]; yv[4 + e] = (float)yb[e]; }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) db[e] = acc[nt][mt][8 * gp + e] * unscale;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              zb[e] = e2 * (float)ya[e] * db[e] * av[e];
-              zb[4 + e] = e2 * (float)yb[e] * db[4 + e] * av[4 + e];
-            }
+            for (int e = 0; e < 8; ++e) zb[e] = e2 * yv[e] * db[e] * av[e];
             if (TRACK) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) { const float az = fabsf(zb[e]); zmax = (az < 3.0e38f && az > zmax) ? az : zmax; }

@@ -100,7 +100,6 @@ template <int WHICH> __global__ __launch_bounds__(256) void grad_amax_kernel(con
       const float gd = gx[0] * dn[0] + gx[1] * dn[1] + gx[2] * dn[2];
       const float k = n2 > eps ? gd * inv * inv * inv : 0.f;
       const float fmx = g.pe_freqs > 0 ? (float)(1 << (g.pe_freqs - 1)) : 1.f;
-#pragma unroll
       const float spm = ((const float *)(A.stash + A.sl.sprime))[gm];       // the chain's seeds are s' gbar (field_adjbwd.hip)
 #pragma unroll
       for (int c = 0; c < 3; ++c) { const float a = fabsf(dn[c] * inv - gx[c] * k) * spm * fmx; mx = (a < 3.0e38f && a > mx) ? a : mx; }
@@ -349,6 +348,9 @@ struct WgradJob {
   int a_col0, b_col0;  // first column used in A / B
   int N, K;            // valid output extents (rows of C, cols of C)
   int scale_sel;       // fp16 loss scaling carried by A: 0 none, 1 the primal chain's (amax[0]), 2 the adjoint chain's (amax[1])
+  int b_native;        // 16-bit modes: B is a layer-output stash in accumulator-native order (tiles of b_bm points, F columns:
+  int b_bm, b_F;       // chunk (col/32, point/32 % (bm/32), (col%32)/16) = 64 lanes x 16 B, see native_off8); else row-major [Mpad][ldb]
+  int b_bm_shift;      // log2(b_bm)
 };
 // 1 / (scale carried by the job's gradient operand): multiplies the fp32 sums before they are accumulated
 __device__ __forceinline__ float wg_unscale(const float *amax, int sel) {
@@ -475,12 +477,24 @@ __device__ __attribute__((aligned(16))) unsigned short w2_zeros[8];   // zero-in
 #define W2_LD (256 + 32)       // 576-byte rows: the 4 rows of a tr-read block fall on disjoint bank groups
 #define W2_BK 64               // points per stage (one barrier per stage; 2 stages x 2 operands = 144 KB of LDS)
 #define W2_STAGE (W2_BK * W2_LD)
+// The stage tiles are [point row][column] with 576-byte rows; the 8-byte column slots of a row are XOR-swizzled by the row:
+//   slot' = slot ^ w2_swz(row),  w2_swz(row) = 2 ((row >> 1) & 3) | 8 ((row >> 3) & 1)     (even: 16-byte pairs stay together)
+// so that (a) a transposing fragment read - 4 rows x 8 slots per 32 lanes - still covers 64 distinct banks (the XOR permutes
+// slots inside an aligned block of 16, the rows' 64-byte bank offsets stay disjoint), and (b) a NATIVE-order chunk - 32 lanes
+// writing the same two slots of 32 consecutive rows - spreads over all banks instead of two.  mm is a multiple of 16, so a
+// lane's swizzle is a constant of the kernel.
+__device__ __forceinline__ int w2_swz(int row) { return (((row >> 1) & 3) << 1) | (((row >> 3) & 1) << 3); }
 template <typename T> __device__ __forceinline__ typename Elem<T>::frag w2_frag(const T *tile, int mm, int col0, int lane) {
   const int h = lane >> 5, grp = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
-  const T *a = tile + (size_t)(mm + 8 * h + q) * W2_LD + col0 + 16 * grp + 4 * p;
+  // lane part of the address (a constant of the kernel): row 8 h + q, swizzled slot 4 grp + p of the 32-column block; col0 is
+  // a multiple of 32 columns = 8 slots and the XOR stays inside an aligned block of 16 slots, so the block offset just adds.
+  // The second read takes row + 4: its swizzle differs in the slot's bit 2 only, i.e. +-4 slots from the first, lane constant.
+  const int s_lo = (4 * grp + p) ^ w2_swz(8 * h + q);
+  const int d_hi = 4 * W2_LD + ((((s_lo ^ 4) - s_lo)) << 2);
+  const T *a = tile + (size_t)(mm + 8 * h + q) * W2_LD + ((((col0 >> 2) & ~15) + (((col0 >> 2) & 8) ^ s_lo)) << 2);
   typedef __attribute__((address_space(3))) s16x4 lds_v4;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)a);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a + 4 * W2_LD));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a + d_hi));
   union { s16x4 s[2]; typename Elem<T>::frag b; } u;   // the transposing read moves 16-bit lanes: element type agnostic
   u.s[0] = lo; u.s[1] = hi;
   return u.b;
@@ -505,7 +519,7 @@ template <typename T> __device__ __forceinline__ typename Elem<T>::frag w2_frag(
 // One 256 x 256 output tile over the points [mb, me).  NBV = 32-column accumulator tiles this WAVE multiplies (4 for a
 // full tile; the 60-column positional-encoding operand only has columns for two tiles of the wc = 0 waves - the other
 // waves of such a block just take part in staging and barriers).
-template <typename T, int NBV>
+template <typename T, int NBV, bool BNAT>
 __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64_t mb, int64_t me, T *sA, T *sB, float osc) {
   typedef typename Elem<T>::frag frag_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
@@ -514,51 +528,70 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   // W2_BK rows x 32 chunks (16 B) per operand: NC per thread
   constexpr int RPP = W2_WAVES * 2;                          // rows per pass of the workgroup
   constexpr int NC = W2_BK / RPP;
-  const int row0 = tid >> 5, cc = (tid & 31) * 8;            // rows row0 + RPP c
+  const int row0 = tid >> 5, cc = (tid & 31) * 8;            // row-major operands: rows row0 + RPP c, columns cc .. cc+7
   const bool a_ok = n0 + cc < J.N, b_ok = k0 + cc < J.K;
+  const int scol = (((cc >> 2) ^ w2_swz(row0)) << 2);        // swizzled column of the thread's 16-byte piece (w2_frag)
+  // Native-order B (BNAT; layer-output stashes of the 16-bit modes): wave-instruction c of wave w moves chunk q = NC w + c of
+  // the stage = 64 lanes x 16 B of consecutive bytes: 32-point block q & 1, column half (q >> 1) & 1, 32-column block q >> 2
+  // of this workgroup's 256 columns; lane (r, h) holds point r, columns 4 h + {0..3} and 8 + 4 h + {0..3} of the half.
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  const int nr = lane & 31, nh = lane >> 5, nswz = w2_swz(nr);
+  static_assert(W2_BK / (W2_WAVES * 2) == 4, "native staging: 4 wave-instructions per wave and stage");
+  // chunk q = 4 w + c: 32-point block c & 1, column half (c >> 1) & 1, 32-column block w (one per wave): everything but the
+  // wave / lane part of the addresses is a compile-time constant of c
+  const int mtn = BNAT ? J.b_bm / 32 : 1, ncb = BNAT ? J.b_F / 32 : 1;
+  int cbg = (k0 >> 5) + wave;
+  cbg = cbg < ncb ? cbg : ncb - 1;                           // beyond the operand: any valid block (those output columns are never stored)
+  const int boff0 = (cbg * mtn * 2 * 64 + lane) * 8;         // + ((c & 1) * 2 + ((c >> 1) & 1)) * 512 elements
+  const int lslot0 = 8 * wave + nh;                          // + 4 ((c >> 1) & 1); LDS row = 32 (c & 1) + nr
+  const int64_t tile_elems = (int64_t)J.b_bm * J.b_F;
   // Stage pipeline with ONE register set: while stage s is multiplied, the registers (stage s+1, loaded during stage
   // s-1) are written to the other LDS buffer a chunk pair per 16-point step and re-filled at once with stage s+2 -
   // every global load has a whole stage of MFMAs to arrive, every LDS buffer one barrier between its last read and its
   // next write.
   u32x4 ra[NC], rb[NC];
   [[maybe_unused]] int64_t m_dbg = mb;   // diagnostic variants only
-  auto gload = [&](int64_t m) {
+  // columns beyond a row-major operand's extent read one 16-byte block of zeros with row stride 0: the stage loop has no
+  // branch (an exec-masked load per chunk split its basic block and cost 6 % of the kernel: profiles/r01_ablation.txt)
+  const T *pa = a_ok ? gA + cc : (const T *)w2_zeros, *pb = b_ok ? gB + cc : (const T *)w2_zeros;
+  const int64_t sa = a_ok ? J.lda : 0, sb = b_ok ? J.ldb : 0;
+  auto gload1 = [&](int64_t m, int c) {
     m = m < me ? m : me - W2_BK;   // the two prefetches past the end re-read the last stage: no branch in the stage loop
-#ifdef W2_SKIP_GLOAD   // diagnostic variant (profiles/ab_bench.sh): compute side only
-    if (m > mb + W2_BK) return;
-#endif
-    // columns beyond the operand's extent read one 16-byte block of zeros with row stride 0: the stage loop has no branch
-    // (an exec-masked load per chunk split its basic block and cost 6 % of the kernel: profiles/r01_ablation.txt)
-    const T *pa = a_ok ? gA + cc : (const T *)w2_zeros, *pb = b_ok ? gB + cc : (const T *)w2_zeros;
-    const int64_t sa = a_ok ? J.lda : 0, sb = b_ok ? J.ldb : 0;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int64_t row = m + row0 + RPP * c;
-      ra[c] = *(const u32x4 *)(pa + row * sa);
+    const int64_t row = m + row0 + RPP * c;
+    ra[c] = *(const u32x4 *)(pa + row * sa);
+    if (BNAT) {
+      // tile = m >> log2(bm); first 32-point block of the stage inside its tile = (m mod bm) / 32; a tile image is bm x F elements
+      const int64_t tile_off = (m >> J.b_bm_shift) * tile_elems;
+      const int mt0 = ((int)m & (J.b_bm - 1)) >> 5;
+      rb[c] = *(const u32x4 *)((const T *)J.B + tile_off + mt0 * 1024 + boff0 + ((c & 1) * 2 + ((c >> 1) & 1)) * 512);
+    } else {
       rb[c] = *(const u32x4 *)(pb + row * sb);
     }
   };
-  auto gload1 = [&](int64_t m, int c) {
-    m = m < me ? m : me - W2_BK;
-    const T *pa = a_ok ? gA + cc : (const T *)w2_zeros, *pb = b_ok ? gB + cc : (const T *)w2_zeros;
-    const int64_t sa = a_ok ? J.lda : 0, sb = b_ok ? J.ldb : 0;
-    const int64_t row = m + row0 + RPP * c;
-    ra[c] = *(const u32x4 *)(pa + row * sa);
-    rb[c] = *(const u32x4 *)(pb + row * sb);
+  auto gload = [&](int64_t m) {
+#ifdef W2_SKIP_GLOAD   // diagnostic variant (profiles/ab_bench.sh): compute side only
+    if (m > mb + W2_BK) return;
+#endif
+#pragma unroll
+    for (int c = 0; c < NC; ++c) gload1(m, c);
   };
   auto sstore1 = [&](int buf, int c) {
-    *(u32x4 *)(sA + buf * W2_STAGE + (row0 + RPP * c) * W2_LD + cc) = ra[c];
-    *(u32x4 *)(sB + buf * W2_STAGE + (row0 + RPP * c) * W2_LD + cc) = rb[c];
+    *(u32x4 *)(sA + buf * W2_STAGE + (row0 + RPP * c) * W2_LD + scol) = ra[c];
+    if (BNAT) {
+      T *rowp = sB + buf * W2_STAGE + (32 * (c & 1) + nr) * W2_LD;
+      const int sl0 = lslot0 + 4 * ((c >> 1) & 1);
+      *(u32x2 *)(rowp + ((sl0 ^ nswz) << 2)) = u32x2{rb[c][0], rb[c][1]};
+      *(u32x2 *)(rowp + (((sl0 + 2) ^ nswz) << 2)) = u32x2{rb[c][2], rb[c][3]};
+    } else {
+      *(u32x4 *)(sB + buf * W2_STAGE + (row0 + RPP * c) * W2_LD + scol) = rb[c];
+    }
   };
   auto sstore = [&](int buf) {
 #ifdef W2_SKIP_SSTORE
     if (m_dbg > mb) return;
 #endif
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      *(u32x4 *)(sA + buf * W2_STAGE + (row0 + RPP * c) * W2_LD + cc) = ra[c];
-      *(u32x4 *)(sB + buf * W2_STAGE + (row0 + RPP * c) * W2_LD + cc) = rb[c];
-    }
+    for (int c = 0; c < NC; ++c) sstore1(buf, c);
   };
   f32x16 acc[W2_RA][4];
 #pragma unroll
@@ -688,10 +721,14 @@ __global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256
 #ifdef BN_CLOCK_STAMP_WGRAD
   BN_CLK_BEGIN
 #endif
-  if (cols >= 65) w2_body<T, 4>(J, n0, k0, mb, me, sA, sB, osc);
-  else if (cols >= 33) w2_body<T, 2>(J, n0, k0, mb, me, sA, sB, osc);
-  else if (cols >= 1) w2_body<T, 1>(J, n0, k0, mb, me, sA, sB, osc);
-  else w2_body<T, 0>(J, n0, k0, mb, me, sA, sB, osc);
+  if (J.b_native) {     // layer-output operand in native order: full-width column blocks only (F is a multiple of 64)
+    if (cols >= 65) w2_body<T, 4, true>(J, n0, k0, mb, me, sA, sB, osc);
+    else if (cols >= 33) w2_body<T, 2, true>(J, n0, k0, mb, me, sA, sB, osc);
+    else w2_body<T, 0, true>(J, n0, k0, mb, me, sA, sB, osc);
+  } else if (cols >= 65) w2_body<T, 4, false>(J, n0, k0, mb, me, sA, sB, osc);
+  else if (cols >= 33) w2_body<T, 2, false>(J, n0, k0, mb, me, sA, sB, osc);
+  else if (cols >= 1) w2_body<T, 1, false>(J, n0, k0, mb, me, sA, sB, osc);
+  else w2_body<T, 0, false>(J, n0, k0, mb, me, sA, sB, osc);
 #ifdef BN_CLOCK_STAMP_WGRAD
   BN_CLK_END
 #endif
@@ -891,23 +928,33 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   WgradArgs w;
   w.n_jobs = 0; w.Mpad = sl.Mpad; w.tile0[0] = 0; w.amax = amax;
   int scale_sel = 1;   // gradient operand of the jobs added next: 1 = primal chain (dZ_l, dG), 2 = adjoint chain (gbar_PE, abar_l)
+  int b_native = 0;    // B operand of the jobs added next: a native-order layer-output stash (16-bit modes) or a row-major array
   auto add = [&](const void *A_, int lda, int a0, const void *B_, int ldb, int b0, float *C, int ldc, float *bias, int N, int K) {
     if (!C) return;
     WgradJob &j = w.job[w.n_jobs];
     j.scale_sel = scale_sel;
+    j.b_native = b_native; j.b_bm = BM; j.b_F = F; j.b_bm_shift = BM == 128 ? 7 : 6;
     j.A = A_; j.B = B_; j.C = C; j.bias = bias; j.lda = lda; j.ldb = ldb; j.ldc = ldc; j.a_col0 = a0; j.b_col0 = b0; j.N = N; j.K = K;
     w.tile0[w.n_jobs + 1] = w.tile0[w.n_jobs] + ((N + 127) / 128) * ((K + 127) / 128);
     ++w.n_jobs;
   };
+  const int naty = bf ? 1 : 0;   // Elem<T>::kNativeY: the Y_l stashes of the 16-bit modes are in native order
   for (int l = 0; l < g.L; ++l) {
     const void *dZ = S + sl.dZ[l];
+    b_native = 0;
     if (l == 0) add(dZ, F, 0, S + sl.pe, g.KP, 0, G->trunk_w[l], P0, G->trunk_b[l], F, P0);
     else if (l == g.skip) {
       add(dZ, F, 0, S + sl.pe, g.KP, 0, G->trunk_w[l], F + P0, G->trunk_b[l], F, P0);
+      b_native = naty;
       add(dZ, F, 0, S + sl.Y[l - 1], F, 0, G->trunk_w[l] ? G->trunk_w[l] + P0 : nullptr, F + P0, nullptr, F, F);
-    } else add(dZ, F, 0, S + sl.Y[l - 1], F, 0, G->trunk_w[l], F, G->trunk_b[l], F, F);
+    } else {
+      b_native = naty;
+      add(dZ, F, 0, S + sl.Y[l - 1], F, 0, G->trunk_w[l], F, G->trunk_b[l], F, F);
+    }
   }
+  b_native = naty;
   if (!g.fold) add(S + sl.dfeats, F, 0, S + sl.Y[g.L - 1], F, 0, G->feats_w, F, G->feats_b, F, F);
+  b_native = 0;
   if (a.an) {  // dW_l += delta_l^T [gbar_PE ; abar_l]  (delta_l is a forward quantity: the scale rides on gbar_PE / abar_l)
     scale_sel = 2;
     for (int l = 0; l < g.L; ++l) {
@@ -923,6 +970,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   for (int hd = 0; hd < g.n_heads; ++hd) {
     const int p = hd / 2, hl = hd % 2;
     // folded: the head's first layer reads Y_{L-1}; the gradient is that of the folded matrix (bn_field_desc.fold_feats)
+    b_native = g.fold ? naty : 0;         // (unfolded: B = the row-major feats stash)
     add(S + sl.dG[p], g.pass_N[p], hl * g.H2, S + (g.fold ? sl.Y[g.L - 1] : sl.feats), F, 0, G->head_w1[hd], F, G->head_b1[hd], g.H2, F);
   }
   BN_REQUIRE(w.n_jobs <= BN_MAX_WGRAD_JOBS, "field_backward: too many wgrad jobs");
@@ -971,6 +1019,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     SkinnyJob &j = s.job[s.n_jobs];
     j.X = S + sl.Y[g.L - 1]; j.ldx = F; j.x_col0 = 0; j.K = F; j.dpre = (const float *)(S + sl.dpre_trunk); j.ldp = 4; j.p_col0 = 0;
     j.nc = g.ch_normal_lr >= 0 ? 4 : 1; j.native = 0;
+    if (naty) { j.native = 1; j.bm = BM; j.ntw = g.NT; j.tstride = BM * F; }     // Y_{L-1} in accumulator order (16-bit modes)
     for (int c = 0; c < 4; ++c) { j.out[c] = nullptr; j.bias[c] = nullptr; }
     j.out[0] = G->sigma_w; j.bias[0] = G->sigma_b;
     if (g.ch_normal_lr >= 0) {

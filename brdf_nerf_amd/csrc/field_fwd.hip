@@ -183,6 +183,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
   constexpr int BM = MT * 32;
   constexpr int PADE = Elem<T>::kPad;
   constexpr bool FAST = Elem<T>::kFastMath;
+  constexpr bool NATY = Elem<T>::kNativeY;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const FieldGeom &g = A.g;
   const int F = g.F, LDA = F + PADE, KP = g.KP, LDP = KP + PADE;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
   const int grp = wave >> 2;
   for (int l = 0; l < g.L; ++l) {
     zero_acc<MT, NT>(acc);
-    if (keep && !ride && l > 0) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[l - 1]) + (size_t)m0 * F, F, BM, F);
+    if (keep && !NATY && !ride && l > 0) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[l - 1]) + (size_t)m0 * F, F, BM, F);
     if (wave_on) {
       const size_t t0 = (size_t)(ncol0 / 32);
       const T *w_pe = packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
 #ifdef BN_AB_NO_Y_COPY        // ablation (results wrong): the forward without the row-major Y copies riding in the GEMMs
           if (false) {
 #else
-          if (keep && grp == 0) {                       // a group's half of the stash copy rides in the phase that reads it
+          if (keep && !NATY && grp == 0) {              // (row-major Y stash only) a group's half of the copy rides in the phase that reads it
 #endif
             TileCopyHalf<T> ycopy(ACT, LDA, ydst, F, 0, F / 2, tid & 255);
             gemm_range<T, MT, NT>(acc, w_h, KSF, 0, half, ACT, LDA, lane, ycopy);
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
 #ifdef BN_AB_NO_Y_COPY
           if (false) {
 #else
-          if (keep && grp == 1) {
+          if (keep && !NATY && grp == 1) {
 #endif
             TileCopyHalf<T> ycopy(ACT, LDA, ydst, F, F / 2, F / 2, tid & 255);
             gemm_range<T, MT, NT>(acc, w_h, KSF, half, half, ACT, LDA, lane, ycopy);
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
             gemm_range<T, MT, NT>(acc, w_h, KSF, half, half, ACT, LDA, lane, none);
           }
           pp_signal(RD + 2 + grp, lane);
-        } else if (keep && ride) {
+        } else if (keep && !NATY && ride) {
           // the row-major stash copy of Y_{l-1} (the tile this GEMM reads) rides inside the GEMM when the shape fits
           TileCopyExact<T> ycopy(ACT, LDA, (T *)(A.stash + A.sl.Y[l - 1]) + (size_t)m0 * F, F, F, tid, WAVES * 64);
           gemm_seg<T, MT, NT>(acc, w_h, KSF, ACT, LDA, lane, ycopy);
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
     BN_PH(2)
     if (wave_on) {
       T *Ds = keep ? (T *)(A.stash + A.sl.D[l]) + (size_t)tile * BM * F : nullptr;
+      T *Ys = keep ? (T *)(A.stash + A.sl.Y[l]) + (size_t)tile * BM * F : nullptr;   // native order (16-bit modes)
       auto epilogue = [&](auto act_tag) {
         constexpr int ACTK = decltype(act_tag)::value;
 #pragma unroll
@@ -358,8 +360,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
                 act_eval<FAST, ACTK>(acc[nt][mt][8 * gp + 4 + e] + bb[e], w0, y[4 + e], dd[4 + e]);
               }
               const int m = mt * 32 + r;
-              *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), y[0], y[1], y[2], y[3]);
-              *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), y[4], y[5], y[6], y[7]);
+              if (NATY) {     // one conversion serves the LDS tile (next layer's operand) and the native Y stash
+                const typename Elem<T>::frag yq = cvt8(T(), y);
+                *(vec4 *)(ACT + (size_t)m * LDA + n0) = __builtin_shufflevector(yq, yq, 0, 1, 2, 3);
+                *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = __builtin_shufflevector(yq, yq, 4, 5, 6, 7);
+                if (keep) st_frag(Ys + native_off8<MT, NT>(wave, nt, mt, gp, lane), yq);
+              } else {
+                *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), y[0], y[1], y[2], y[3]);
+                *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), y[4], y[5], y[6], y[7]);
+              }
 #ifndef BN_AB_NO_D_STASH     // ablation (results wrong): the forward without its D stash stores
               if (keep) st8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dd);
 #endif
@@ -435,13 +444,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
   // ---------------------------------------------------------------- feats = Wf h8 + bf (linear)
   // With fold_feats the caller has multiplied the feats layer into the heads' first layers: the heads read h8 directly.
   if (g.fold) {
-    if (keep) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[g.L - 1]) + (size_t)m0 * F, F, BM, F);
+    if (keep && !NATY) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[g.L - 1]) + (size_t)m0 * F, F, BM, F);
   } else {
   zero_acc<MT, NT>(acc);
-  if (keep && !ride) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[g.L - 1]) + (size_t)m0 * F, F, BM, F);
+  if (keep && !NATY && !ride) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[g.L - 1]) + (size_t)m0 * F, F, BM, F);
   if (wave_on) {
     const T *w_f = packed + A.pl.fwd_feats + (size_t)(ncol0 / 32) * KSF * 512;
-    if (keep && ride) {
+    if (keep && !NATY && ride) {
       TileCopyExact<T> ycopy(ACT, LDA, (T *)(A.stash + A.sl.Y[g.L - 1]) + (size_t)m0 * F, F, F, tid, WAVES * 64);
       gemm_seg<T, MT, NT>(acc, w_f, KSF, ACT, LDA, lane, ycopy);
     } else {
