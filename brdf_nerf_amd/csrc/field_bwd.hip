@@ -478,20 +478,21 @@ __device__ __attribute__((aligned(16))) unsigned short w2_zeros[8];   // zero-in
 #define W2_BK 64               // points per stage (one barrier per stage; 2 stages x 2 operands = 144 KB of LDS)
 #define W2_STAGE (W2_BK * W2_LD)
 // The stage tiles are [point row][column] with 576-byte rows; the 8-byte column slots of a row are XOR-swizzled by the row:
-//   slot' = slot ^ w2_swz(row),  w2_swz(row) = 2 ((row >> 1) & 3) | 8 ((row >> 3) & 1)     (even: 16-byte pairs stay together)
+//   slot' = slot ^ w2_swz(row),  w2_swz(row) = 2 ((row >> 1) & 3)        (even: the two slots of a 16-byte piece stay together)
 // so that (a) a transposing fragment read - 4 rows x 8 slots per 32 lanes - still covers 64 distinct banks (the XOR permutes
-// slots inside an aligned block of 16, the rows' 64-byte bank offsets stay disjoint), and (b) a NATIVE-order chunk - 32 lanes
-// writing the same two slots of 32 consecutive rows - spreads over all banks instead of two.  mm is a multiple of 16, so a
-// lane's swizzle is a constant of the kernel.
-__device__ __forceinline__ int w2_swz(int row) { return (((row >> 1) & 3) << 1) | (((row >> 3) & 1) << 3); }
+// slots inside an aligned block of 8, the rows' 64-byte bank offsets stay disjoint), and (b) a NATIVE-order chunk - the 8
+// lanes of a ds_write_b128 group writing the same 16-byte piece of 8 consecutive rows - spreads over all 32 banks
+// (row & 1 moves a row by 16 banks, the XOR by 4, 8 or 12) instead of two.  mm is a multiple of 16, so a lane's swizzle is a
+// constant of the kernel.
+__device__ __forceinline__ int w2_swz(int row) { return ((row >> 1) & 3) << 1; }
 template <typename T> __device__ __forceinline__ typename Elem<T>::frag w2_frag(const T *tile, int mm, int col0, int lane) {
   const int h = lane >> 5, grp = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
   // lane part of the address (a constant of the kernel): row 8 h + q, swizzled slot 4 grp + p of the 32-column block; col0 is
-  // a multiple of 32 columns = 8 slots and the XOR stays inside an aligned block of 16 slots, so the block offset just adds.
+  // a multiple of 32 columns = 8 slots and the XOR stays inside an aligned block of 8 slots, so the block offset just adds.
   // The second read takes row + 4: its swizzle differs in the slot's bit 2 only, i.e. +-4 slots from the first, lane constant.
   const int s_lo = (4 * grp + p) ^ w2_swz(8 * h + q);
   const int d_hi = 4 * W2_LD + ((((s_lo ^ 4) - s_lo)) << 2);
-  const T *a = tile + (size_t)(mm + 8 * h + q) * W2_LD + ((((col0 >> 2) & ~15) + (((col0 >> 2) & 8) ^ s_lo)) << 2);
+  const T *a = tile + (size_t)(mm + 8 * h + q) * W2_LD + (((col0 >> 2) + s_lo) << 2);
   typedef __attribute__((address_space(3))) s16x4 lds_v4;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)a);
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4 *)(a + d_hi));
@@ -534,7 +535,9 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   // Native-order B (BNAT; layer-output stashes of the 16-bit modes): wave-instruction c of wave w moves chunk q = NC w + c of
   // the stage = 64 lanes x 16 B of consecutive bytes: 32-point block q & 1, column half (q >> 1) & 1, 32-column block q >> 2
   // of this workgroup's 256 columns; lane (r, h) holds point r, columns 4 h + {0..3} and 8 + 4 h + {0..3} of the half.
-  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  // Before the LDS write the two lanes of a point trade one run (v_permlane32_swap: lanes 32-63 of the first operand with
+  // lanes 0-31 of the second), so that lane (r, h) holds the 8 CONSECUTIVE columns 8 h .. 8 h + 7 = one 16-byte piece, written
+  // with one ds_write_b128 like a row-major piece.
   const int nr = lane & 31, nh = lane >> 5, nswz = w2_swz(nr);
   static_assert(W2_BK / (W2_WAVES * 2) == 4, "native staging: 4 wave-instructions per wave and stage");
   // chunk q = 4 w + c: 32-point block c & 1, column half (c >> 1) & 1, 32-column block w (one per wave): everything but the
@@ -543,7 +546,7 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   int cbg = (k0 >> 5) + wave;
   cbg = cbg < ncb ? cbg : ncb - 1;                           // beyond the operand: any valid block (those output columns are never stored)
   const int boff0 = (cbg * mtn * 2 * 64 + lane) * 8;         // + ((c & 1) * 2 + ((c >> 1) & 1)) * 512 elements
-  const int lslot0 = 8 * wave + nh;                          // + 4 ((c >> 1) & 1); LDS row = 32 (c & 1) + nr
+  const int lslot0 = 8 * wave + 2 * nh;                      // + 4 ((c >> 1) & 1); LDS row = 32 (c & 1) + nr
   const int64_t tile_elems = (int64_t)J.b_bm * J.b_F;
   // Stage pipeline with ONE register set: while stage s is multiplied, the registers (stage s+1, loaded during stage
   // s-1) are written to the other LDS buffer a chunk pair per 16-point step and re-filled at once with stage s+2 -
@@ -580,8 +583,9 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
     if (BNAT) {
       T *rowp = sB + buf * W2_STAGE + (32 * (c & 1) + nr) * W2_LD;
       const int sl0 = lslot0 + 4 * ((c >> 1) & 1);
-      *(u32x2 *)(rowp + ((sl0 ^ nswz) << 2)) = u32x2{rb[c][0], rb[c][1]};
-      *(u32x2 *)(rowp + (((sl0 + 2) ^ nswz) << 2)) = u32x2{rb[c][2], rb[c][3]};
+      const auto s02 = __builtin_amdgcn_permlane32_swap(rb[c][0], rb[c][2], false, false);   // (run 0, run 1) dword 0
+      const auto s13 = __builtin_amdgcn_permlane32_swap(rb[c][1], rb[c][3], false, false);   // dword 1
+      *(u32x4 *)(rowp + ((sl0 ^ nswz) << 2)) = u32x4{s02[0], s13[0], s02[1], s13[1]};
     } else {
       *(u32x4 *)(sB + buf * W2_STAGE + (row0 + RPP * c) * W2_LD + scol) = rb[c];
     }
