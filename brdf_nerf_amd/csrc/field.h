@@ -87,6 +87,7 @@ static inline int bn_make_geom(const bn_field_desc *d, FieldGeom *g) {
 struct PackedLayout {
   size_t fwd_trunk[BN_MAX_LAYERS][2];  // [l][0]: PE part (l==0, l==skip) or h part; [l][1]: h part of the skip layer
   size_t fwd_feats, fwd_head[BN_MAX_PASS];
+  size_t fwd_sigma, fwd_nlr;           // one 32-row tile each over K = F: row 0 = w_sigma / rows 0..2 = grad_from_xyz (rest zero)
   size_t bwd_trunk[BN_MAX_LAYERS];     // W_l^T restricted to the h inputs, l >= 1
   size_t bwd_feats, bwd_head[BN_MAX_PASS];
   size_t bwd_pe[2];                    // (W_l[:, :P])^T for l = 0 and l = skip: [KP rows][F k], analytic-normal adjoint only
@@ -106,6 +107,8 @@ static inline void bn_make_packed_layout(const FieldGeom &g, PackedLayout *pl) {
   }
   pl->fwd_feats = g.fold ? 0 : take(g.F, g.F);
   for (int p = 0; p < g.n_pass; ++p) pl->fwd_head[p] = take(g.pass_N[p], g.F);
+  pl->fwd_sigma = take(32, g.F);
+  pl->fwd_nlr = g.ch_normal_lr >= 0 ? take(32, g.F) : 0;
   for (int l = 0; l < g.L; ++l) pl->bwd_trunk[l] = l >= 1 ? take(g.F, g.F) : 0;
   pl->bwd_feats = g.fold ? 0 : take(g.F, g.F);
   for (int p = 0; p < g.n_pass; ++p) pl->bwd_head[p] = take(g.F, g.pass_N[p]);

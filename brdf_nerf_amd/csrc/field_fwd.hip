@@ -385,8 +385,61 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
   }
   if (PING) __syncthreads();   // both halves of the last layer are in LDS (every wave signalled before arriving here)
 
-  // ---------------------------------------------------------------- sigma (+ learned normal): VALU dots over h8
-  {
+  // ---------------------------------------------------------------- sigma (+ learned normal) heads on the matrix pipe
+  // The one-row (three-row) heads are 32-row MFMA tiles with zero rows, split over K: wave w multiplies k-steps
+  // [w KSF/8, (w+1) KSF/8) for all BM points (4 k-steps x 4 point tiles = 16 MFMAs per wave at F = 512), the 8 partial sums
+  // of rows 0..3 meet in LDS (the encoding tile is free after the trunk).  Replaces per-thread VALU dots over the LDS tile
+  // (9.7 % of the inference kernel's wave cycles for 0.03 % of its FLOPs, round 1).  16-bit modes only: the fp32 parity mode
+  // keeps the fp32 dot products below (same summation order as the validated round-1 kernel).
+  if constexpr (FAST) {
+    const bool nlr = g.ch_normal_lr >= 0 && !A.sigma_only;
+    float *SRED = (float *)PE;                         // [WAVES][BM][4]: sigma_raw, normal_raw xyz partial sums
+    const int nks = KSF >= WAVES ? KSF / WAVES : 1, ks0 = wave * nks;
+    const bool kon = ks0 < KSF;
+    f32x16 sacc[1][MT], nacc[1][MT];
+    zero_acc<MT, 1>(sacc);
+    zero_acc<MT, 1>(nacc);
+    if (kon) {
+      NoSide none;
+      gemm_range<T, MT, 1>(sacc, packed + A.pl.fwd_sigma, KSF, ks0, nks, ACT, LDA, lane, none);
+      if (nlr) gemm_range<T, MT, 1>(nacc, packed + A.pl.fwd_nlr, KSF, ks0, nks, ACT, LDA, lane, none);
+    }
+    if (h == 0) {                                      // accumulator rows 0..3 live in registers 0..3 of lanes 0-31
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        *(f32x4 *)(SRED + ((size_t)wave * BM + mt * 32 + r) * 4) = f32x4{sacc[0][mt][0], nacc[0][mt][0], nacc[0][mt][1], nacc[0][mt][2]};
+    }
+    __syncthreads();
+    if (tid < BM) {
+      const int m = tid;
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < WAVES; ++w)
+        if (w * nks < KSF) sum += *(const f32x4 *)(SRED + ((size_t)w * BM + m) * 4);
+      const int64_t gm = m0 + m;
+      const float sraw = sum[0] + A.p.sigma_b[0];
+      const float sig = softplus_f(sraw);
+      if (keep) ((float *)(A.stash + A.sl.sraw))[gm] = sraw;
+      if (gm < M) {
+        if (A.sigma_only) A.out[gm] = sig;
+        else A.out[gm * g.C + 3] = sig;
+      }
+      if (nlr) {
+        const float v0 = sum[1] + A.p.normal_b[0], v1 = sum[2] + A.p.normal_b[1], v2 = sum[3] + A.p.normal_b[2];
+        if (keep) {
+          float *nr = (float *)(A.stash + A.sl.nraw) + gm * 4;
+          nr[0] = v0; nr[1] = v1; nr[2] = v2; nr[3] = 0.f;
+        }
+        if (gm < M) {
+          const float inv = -1.f / sqrtf(fmaxf(v0 * v0 + v1 * v1 + v2 * v2, 1.1920928955078125e-07f));
+          float *o = A.out + gm * g.C + g.ch_normal_lr;
+          o[0] = v0 * inv; o[1] = v1 * inv; o[2] = v2 * inv;
+        }
+      }
+    }
+    __syncthreads();                                   // the head passes reuse the encoding tile for their parameters
+  }
+  // fp32 parity mode: VALU dots over h8
+  else {
     constexpr int TPR = (WAVES * 64) / BM;  // threads per point
     const int m = tid / TPR, q = tid % TPR;
     const bool nlr = g.ch_normal_lr >= 0;
@@ -591,6 +644,13 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
     BN_REQUIRE(P->feats_w && P->feats_b, "pack: feats layer missing");
     add(P->feats_w, pl.fwd_feats, F, F, F, 0, 0, 0);
     add(P->feats_w, pl.bwd_feats, F, F, F, 0, 0, 1);
+  }
+  // the one-row sigma head and the three-row learned-normal head as 32-row MFMA tiles (rows beyond the head's are zero)
+  BN_REQUIRE(P->sigma_w, "pack: sigma head missing");
+  add(P->sigma_w, pl.fwd_sigma, F, 1, F, 0, 0, 0);
+  if (g.ch_normal_lr >= 0) {
+    BN_REQUIRE(P->normal_w, "pack: learned-normal head missing");
+    add(P->normal_w, pl.fwd_nlr, F, 3, F, 0, 0, 0);
   }
   // (W_l[:, :P])^T for the analytic-normal adjoint: packed[row p][k n] = W_l[n][p]
   add(P->trunk_w[0], pl.bwd_pe[0], P0, P0, F, 0, 0, 1);
