@@ -1403,13 +1403,25 @@ def test_full_size_render_and_train_step_properties(name):
 
 
 def _learnable_table(n_rays, seed):
-    """Djibouti-shaped synthetic table whose colours are a smooth function of the ray origin (something to learn):
-    training rays and held-out rays are different draws (seeds) of the same scene."""
+    """Djibouti-shaped synthetic table of ONE consistent scene (something to learn, geometry included): a smooth height field
+    z = h(x, y) seen from the table's near-nadir cameras.  Colours are a smooth function of the point the ray hits, the
+    depth priors are the (first-order) hit depths with weight 1 on every ray - unlike raytable.synthetic_table's random
+    colours and random depths, which supervise no geometry at all and leave the density field, and with it the analytic
+    normals, to chance.  Training rays and held-out rays are different draws (seeds) of the same scene."""
     from brdf_nerf_amd.raytable import synthetic_table
     t = synthetic_table(n_rays, device=DEV, seed=seed)
-    o = t.data["rays"][:, :3]
-    t.data["rgbs"] = torch.stack([0.5 + 0.4 * torch.sin(3 * o[:, 0]), 0.5 + 0.4 * torch.cos(2 * o[:, 1]),
-                                  0.5 + 0.3 * torch.sin(2 * o[:, 0] + o[:, 1])], -1).contiguous()
+    rays = t.data["rays"]
+    o, d = rays[:, :3], rays[:, 3:6]
+    height = lambda x, y: 0.12 * torch.sin(2.0 * x) * torch.cos(2.0 * y)
+    depth = (o[:, 2] - height(o[:, 0], o[:, 1])) / (-d[:, 2])
+    hit = o + d * depth.unsqueeze(-1)
+    depth = depth + (hit[:, 2] - height(hit[:, 0], hit[:, 1])) / (-d[:, 2])          # one fixed-point refinement
+    hit = o + d * depth.unsqueeze(-1)
+    t.data["rgbs"] = torch.stack([0.5 + 0.4 * torch.sin(3 * hit[:, 0]), 0.5 + 0.4 * torch.cos(2 * hit[:, 1]),
+                                  0.5 + 0.3 * torch.sin(2 * hit[:, 0] + hit[:, 1])], -1).contiguous()
+    t.data["depths"] = torch.stack([depth, torch.ones_like(depth)], -1).contiguous()
+    t.data["valid_depth"] = torch.ones_like(depth)
+    t.data["depth_std"] = torch.zeros_like(depth)
     return t
 
 
