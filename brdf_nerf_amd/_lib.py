@@ -25,7 +25,8 @@ class FieldDesc(C.Structure):
     _fields_ = [("feat", C.c_int32), ("layers", C.c_int32), ("skip", C.c_int32), ("pe_freqs", C.c_int32),
                 ("act", C.c_int32), ("dtype", C.c_int32), ("n_heads", C.c_int32),
                 ("head_out", C.c_int32 * BN_MAX_HEADS), ("head_kind", C.c_int32 * BN_MAX_HEADS),
-                ("normal_lr", C.c_int32), ("normal_an", C.c_int32), ("out_channels", C.c_int32), ("fold_feats", C.c_int32)]
+                ("normal_lr", C.c_int32), ("normal_an", C.c_int32), ("out_channels", C.c_int32), ("fold_feats", C.c_int32),
+                ("dir_dim", C.c_int32), ("dir_freqs", C.c_int32)]
 
 
 class FieldParams(C.Structure):
@@ -33,7 +34,7 @@ class FieldParams(C.Structure):
                 ("sigma_w", fptr), ("sigma_b", fptr), ("feats_w", fptr), ("feats_b", fptr),
                 ("head_w1", fptr * BN_MAX_HEADS), ("head_b1", fptr * BN_MAX_HEADS),
                 ("head_w2", fptr * BN_MAX_HEADS), ("head_b2", fptr * BN_MAX_HEADS),
-                ("normal_w", fptr), ("normal_b", fptr)]
+                ("normal_w", fptr), ("normal_b", fptr), ("head0_wdir", fptr), ("head0_wdir_ld", C.c_int64)]
 
 
 FieldGrads = FieldParams  # identical shape (writable pointers)
@@ -41,7 +42,7 @@ FieldGrads = FieldParams  # identical shape (writable pointers)
 
 class Points(C.Structure):
     _fields_ = [("xyz", fptr), ("rays", fptr), ("z", fptr), ("ray_stride", C.c_int32), ("n_samples", C.c_int32),
-                ("n_points", C.c_int64)]
+                ("n_points", C.c_int64), ("dirs", fptr)]
 
 
 class LibraryMissing(RuntimeError):
@@ -118,7 +119,7 @@ def load(path):
     for name, (res, args) in _SIGS.items():
         fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if L.bn_abi_version() != 1:
+    if L.bn_abi_version() != 2:
         raise LibraryMissing(f"{path}: ABI version mismatch; rebuild")
     return L
 

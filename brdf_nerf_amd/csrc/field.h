@@ -27,6 +27,7 @@ struct FieldGeom {
   int C;                        // out channels
   int ch_normal_an, ch_normal_lr;  // channel index or -1
   int fold;                        // feats layer folded into the heads' first layers (bn_field_desc.fold_feats)
+  int DD, KD, dir_freqs;           // view-direction input of the rgb head: valid width (0: none), width padded to 16, octaves
 };
 
 // Tile configuration of the fused chain kernels: 8 waves per workgroup, one workgroup per CU (2 waves per SIMD);
@@ -56,6 +57,11 @@ static inline int bn_make_geom(const bn_field_desc *d, FieldGeom *g) {
   }
   g->H2 = d->feat / 2;
   g->fold = d->fold_feats != 0;
+  g->DD = d->dir_dim; g->dir_freqs = d->dir_freqs;
+  g->KD = (d->dir_dim + 15) / 16 * 16;
+  BN_REQUIRE(d->dir_dim == 0 || (d->dir_dim == (d->dir_freqs > 0 ? 6 * d->dir_freqs : 3) && d->dir_dim <= 32 && g->fold),
+             "field: dir_dim=%d dir_freqs=%d fold=%d unsupported (input_viewdir needs fold_feats and at most 5 octaves)", d->dir_dim,
+             d->dir_freqs, g->fold);
   g->n_heads = d->n_heads;
   g->n_pass = (d->n_heads + 1) / 2;
   int c = 4;
@@ -88,6 +94,7 @@ struct PackedLayout {
   size_t fwd_trunk[BN_MAX_LAYERS][2];  // [l][0]: PE part (l==0, l==skip) or h part; [l][1]: h part of the skip layer
   size_t fwd_feats, fwd_head[BN_MAX_PASS];
   size_t fwd_sigma, fwd_nlr;           // one 32-row tile each over K = F: row 0 = w_sigma / rows 0..2 = grad_from_xyz (rest zero)
+  size_t fwd_dir;                      // [pass_N[0] rows][KD]: the rgb head's view-direction columns (rows of a second head: zero)
   size_t bwd_trunk[BN_MAX_LAYERS];     // W_l^T restricted to the h inputs, l >= 1
   size_t bwd_feats, bwd_head[BN_MAX_PASS];
   size_t bwd_pe[2];                    // (W_l[:, :P])^T for l = 0 and l = skip: [KP rows][F k], analytic-normal adjoint only
@@ -109,6 +116,7 @@ static inline void bn_make_packed_layout(const FieldGeom &g, PackedLayout *pl) {
   for (int p = 0; p < g.n_pass; ++p) pl->fwd_head[p] = take(g.pass_N[p], g.F);
   pl->fwd_sigma = take(32, g.F);
   pl->fwd_nlr = g.ch_normal_lr >= 0 ? take(32, g.F) : 0;
+  pl->fwd_dir = g.DD > 0 ? take(g.pass_N[0], g.KD) : 0;
   for (int l = 0; l < g.L; ++l) pl->bwd_trunk[l] = l >= 1 ? take(g.F, g.F) : 0;
   pl->bwd_feats = g.fold ? 0 : take(g.F, g.F);
   for (int p = 0; p < g.n_pass; ++p) pl->bwd_head[p] = take(g.F, g.pass_N[p]);
@@ -128,6 +136,7 @@ struct StashLayout {
   size_t dpre_trunk;              // fp32 [Mpad][4]  (d sigma_raw, d normal_raw xyz)      (bwd-produced)
   size_t dpre_head;               // fp32 [Mpad][12] (per head, 3 each)                   (bwd-produced)
   size_t pe;                      // T [Mpad][KP]
+  size_t dirpe;                   // T [Mpad][KD]  encoded view direction (input_viewdir only)
   size_t Y[BN_MAX_LAYERS];        // T [Mpad][F]  output of trunk layer l
   size_t D[BN_MAX_LAYERS];        // T native     d act / d z of trunk layer l
   size_t feats;                   // T [Mpad][F]
@@ -160,6 +169,7 @@ static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, in
   s->dpre_trunk = take((size_t)Mpad * 16);
   s->dpre_head = take((size_t)Mpad * 48);
   s->pe = take((size_t)Mpad * g.KP * esz);
+  s->dirpe = g.DD > 0 ? take((size_t)Mpad * g.KD * esz) : 0;
   for (int l = 0; l < g.L; ++l) s->Y[l] = take((size_t)Mpad * g.F * esz);
   for (int l = 0; l < g.L; ++l) s->D[l] = take((size_t)Mpad * g.F * esz);
   s->feats = take((size_t)Mpad * g.F * esz);

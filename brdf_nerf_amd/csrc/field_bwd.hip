@@ -977,6 +977,10 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     b_native = g.fold ? naty : 0;         // (unfolded: B = the row-major feats stash)
     add(S + sl.dG[p], g.pass_N[p], hl * g.H2, S + (g.fold ? sl.Y[g.L - 1] : sl.feats), F, 0, G->head_w1[hd], F, G->head_b1[hd], g.H2, F);
   }
+  if (g.DD > 0 && G->head0_wdir) {   // d/d rgb_from_xyzdir.0.weight[:, F:] = dG_rgb^T [encoded view direction]
+    b_native = 0; scale_sel = 1;
+    add(S + sl.dG[0], g.pass_N[0], 0, S + sl.dirpe, g.KD, 0, G->head0_wdir, (int)G->head0_wdir_ld, nullptr, g.H2, g.DD);
+  }
   BN_REQUIRE(w.n_jobs <= BN_MAX_WGRAD_JOBS, "field_backward: too many wgrad jobs");
   if (bf && w.n_jobs > 0) {
     // 256 x 256 tiles, one 8-wave workgroup per CU: size the point splits for ~4 workgroups per CU in total

@@ -48,12 +48,44 @@ template <bool FAST> __device__ __forceinline__ float act_prescale(int act, floa
   return (FAST && act == BN_ACT_SIN) ? w0 * BN_INV_2PI : 1.f;
 }
 
+// --input_viewdir: one row of the direction tile = mapping[1](view direction of the point) (spsbrdfnerf.py:689-692), zero
+// beyond its valid width.
+template <typename T>
+__device__ __forceinline__ void fill_dir_row(const FwdArgs &A, int64_t gm, T *row) {
+  constexpr bool FAST = Elem<T>::kFastMath;
+  const FieldGeom &g = A.g;
+  float dv[3] = {0.f, 0.f, 0.f};
+  if (gm < A.pts.n_points) {
+    if (A.pts.xyz) {
+      if (A.pts.dirs) { dv[0] = A.pts.dirs[gm * 3]; dv[1] = A.pts.dirs[gm * 3 + 1]; dv[2] = A.pts.dirs[gm * 3 + 2]; }
+    } else {
+      const float *rr = A.pts.rays + (gm / A.pts.n_samples) * A.pts.ray_stride;
+      dv[0] = rr[3]; dv[1] = rr[4]; dv[2] = rr[5];
+    }
+  }
+  if (g.dir_freqs > 0) {
+    for (int k = 0; k < g.dir_freqs; ++k) {
+      const float f = (float)(1 << k);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float sn, co;
+        sincos_t<FAST>(f * dv[c], sn, co);
+        row[6 * k + c] = (T)sn;
+        row[6 * k + 3 + c] = (T)co;
+      }
+    }
+    for (int k = g.DD; k < g.KD; ++k) row[k] = (T)0.f;
+  } else {
+    for (int k = 0; k < g.KD; ++k) row[k] = (T)(k < 3 ? dv[k] : 0.f);
+  }
+}
+
 // One pass over up to two heads: hidden = act(W1 feats + b1) kept in registers, second layer (<= 3 outputs)
 // as per-lane partial dots reduced through LDS.  NTW = 32-column tiles per wave in this pass.
 // The pass's first-layer biases and second-layer weights are staged in LDS (PRM, the positional-encoding buffer,
 // free by now) ahead of the GEMM: the epilogue then reads them without queueing behind its own stash stores.
 // The hidden activations G are stashed in accumulator order like DG (one coalesced 16-byte store per lane).
-template <typename T, int MT, int NTW, int WAVES, bool KEEP>
+template <typename T, int MT, int NTW, int WAVES, bool KEEP, bool DIR>
 __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT, float *PRM, float *RED, int64_t m0, int64_t tile
 #ifdef BN_PHASE_TIMING
                                           , unsigned long long (&ph_)[BN_PH_N], unsigned long long &pt_
@@ -77,11 +109,28 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
 #pragma unroll
     for (int c = 0; c < 3; ++c) PRM[(1 + c) * N + n] = c < nout ? A.p.head_w2[hdn][(size_t)c * g.H2 + nl] : 0.f;
   }
+  // --input_viewdir: the encoded view direction of every point, an extra K segment of the rgb head's first layer (like the
+  // positional-encoding segment of the skip layer).  The tile lives behind the staged parameters in the (free) encoding buffer.
+  // DIR is a template parameter: compiled into the one kernel, the segment costs the hot head pass registers (2 - 3 % of the
+  // forward with no direction input at all: profiles/r02_ablation.txt)
+  const bool dir_on = DIR && p == 0;
+  T *DIRT = (T *)((char *)PRM + 8192);
+  const int LDD = g.KD + Elem<T>::kPad;
+  if constexpr (DIR) {
+    if (dir_on && tid < BM) fill_dir_row<T>(A, m0 + tid, DIRT + (size_t)tid * LDD);
+  }
   f32x16 acc[NTW][MT];
   zero_acc<MT, NTW>(acc);
   if (on) gemm_seg<T, MT, NTW>(acc, (const T *)A.packed + A.pl.fwd_head[p] + (size_t)(pc0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
   BN_PH(9)
-  __syncthreads();   // PRM filled
+  __syncthreads();   // PRM (and the direction tile) filled
+  if constexpr (DIR) {
+    if (dir_on) {
+      const int KSD = g.KD / 16;
+      if (keep) tile_to_global<T>(DIRT, LDD, (T *)(A.stash + A.sl.dirpe) + (size_t)m0 * g.KD, g.KD, BM, g.KD);
+      if (on) gemm_seg<T, MT, NTW>(acc, (const T *)A.packed + A.pl.fwd_dir + (size_t)(pc0 / 32) * KSD * 512, KSD, DIRT, LDD, lane);
+    }
+  }
   if (on) {
     T *Gs = keep ? (T *)(A.stash + A.sl.G[p]) + (size_t)tile * BM * F : nullptr;
     T *DGs = keep ? (T *)(A.stash + A.sl.DG[p]) + (size_t)tile * BM * F : nullptr;
@@ -176,8 +225,7 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
 #else
 #define BN_PH_ARGS
 #endif
-
-template <typename T, int MT, int NT, int WAVES, bool KEEP>
+template <typename T, int MT, int NT, int WAVES, bool KEEP, bool DIR>
 __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs A) {
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
@@ -534,8 +582,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
 
   // ---------------------------------------------------------------- two-layer sigmoid heads, up to 2 per pass
   for (int p = 0; p < g.n_pass; ++p) {
-    if (g.pass_heads[p] == 2) head_pass<T, MT, NT, WAVES, KEEP>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
-    else head_pass<T, MT, BN_SINGLE_HEAD_NTW(NT), WAVES, KEEP>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
+    if (g.pass_heads[p] == 2) head_pass<T, MT, NT, WAVES, KEEP, DIR>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
+    else head_pass<T, MT, BN_SINGLE_HEAD_NTW(NT), WAVES, KEEP, DIR>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
   }
   BN_PH_FLUSH
   BN_CLK_END
@@ -667,6 +715,13 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
       add(P->head_w1[hd], pl.fwd_head[p] + (size_t)hl * g.H2 * F, F, g.H2, F, 0, 0, 0);
       fwd_scale(1, 1.f);
     }
+  if (g.DD > 0) {   // view-direction columns of the rgb head's first layer: rows of head 0 inside pass 0, the rest zero
+    BN_REQUIRE(P->head0_wdir && P->head0_wdir_ld >= g.DD, "pack: head0_wdir missing (input_viewdir)");
+    add(P->head0_wdir, pl.fwd_dir, (int)P->head0_wdir_ld, g.H2, g.DD, 0, 0, 0);
+    a.job[a.n_jobs - 1].rows_pad = g.pass_N[0];
+    a.job[a.n_jobs - 1].K_pad = g.KD;
+    fwd_scale(1, 1.f);
+  }
   // transposed head-1 weights: packed[row j][k = column in pass] = W1_hd[k - hl*H2][j]; the heads of a pass
   // interleave along k, so each head fills its own k range of the shared packed matrix (masked job).
   for (int p = 0; p < g.n_pass; ++p)
@@ -686,18 +741,20 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
   return 0;
 }
 
-template <typename T, int MT, int NT, int WAVES, bool KEEP> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st);
+template <typename T, int MT, int NT, int WAVES, bool KEEP, bool DIR> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st);
 template <typename T, int MT, int NT, int WAVES> static int launch_fwd(const FwdArgs &a, int64_t tiles, hipStream_t st) {
-  return a.stash ? launch_fwd_k<T, MT, NT, WAVES, true>(a, tiles, st) : launch_fwd_k<T, MT, NT, WAVES, false>(a, tiles, st);
+  if (a.g.DD > 0 && !a.sigma_only)      // --input_viewdir: the variant with the direction segment in the rgb head
+    return a.stash ? launch_fwd_k<T, MT, NT, WAVES, true, true>(a, tiles, st) : launch_fwd_k<T, MT, NT, WAVES, false, true>(a, tiles, st);
+  return a.stash ? launch_fwd_k<T, MT, NT, WAVES, true, false>(a, tiles, st) : launch_fwd_k<T, MT, NT, WAVES, false, false>(a, tiles, st);
 }
-template <typename T, int MT, int NT, int WAVES, bool KEEP> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st) {
+template <typename T, int MT, int NT, int WAVES, bool KEEP, bool DIR> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = ((size_t)BM * (a.g.F + Elem<T>::kPad) + (size_t)BM * (a.g.KP + Elem<T>::kPad)) * sizeof(T) +
                      (size_t)WAVES * 3 * BM * sizeof(float);
-  if (int e = bn_configure_lds((const void *)field_fwd_kernel<T, MT, NT, WAVES, KEEP>, lds, "field_fwd")) return e;
+  if (int e = bn_configure_lds((const void *)field_fwd_kernel<T, MT, NT, WAVES, KEEP, DIR>, lds, "field_fwd")) return e;
   {
     BnProfScope prof_(a.sigma_only ? BN_K_FWD_SIGMA : BN_K_FWD_FULL, st);
-    field_fwd_kernel<T, MT, NT, WAVES, KEEP><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
+    field_fwd_kernel<T, MT, NT, WAVES, KEEP, DIR><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
     BN_LAUNCH_CHECK("field_fwd");
   }
   // mirror the device fault word to the host now and then: asynchronous, no synchronisation on the hot path
@@ -733,6 +790,8 @@ int bn_field_forward_impl(const bn_field_desc *desc, const bn_field_params *para
   // desc->normal_an only reserves 3 output channels here; bn_field_normals() fills them from the stash
   BN_REQUIRE(!desc->normal_an || sigma_only || stash, "field_forward: analytic normals need the activation stash");
   BN_REQUIRE(pts && pts->n_points > 0 && (pts->xyz || (pts->rays && pts->z && pts->n_samples > 0)), "field: bad points");
+  BN_REQUIRE(!desc->dir_dim || sigma_only || !pts->xyz || pts->dirs, "field: input_viewdir needs pts.dirs with the xyz point form");
+  BN_REQUIRE(!desc->dir_dim || pts->xyz || pts->ray_stride >= 6, "field: input_viewdir needs rays with directions");
   BN_REQUIRE(packed && out, "field: null buffer");
   a.d = *desc; a.p = *params; a.packed = packed; a.pts = *pts; a.out = out; a.stash = (char *)stash;
   a.sigma_only = sigma_only;

@@ -54,12 +54,10 @@ class SpSBRDFNeRF(nn.Module):
             raise NotImplementedError(_UNSUPPORTED + f"--sun_v {sun_v} (reference quirk 3: NameError upstream)")
         if indirect_light:
             raise NotImplementedError(_UNSUPPORTED + "--indirect_light (needs sun_v)")
-        if getattr(args, "input_viewdir", 0):
-            raise NotImplementedError(_UNSUPPORTED + "--input_viewdir")
         if len(skips) > 1:
             raise NotImplementedError(_UNSUPPORTED + "more than one skip layer")
         self.layers, self.skips, self.t_embedding_dims = layers, list(skips), t_embedding_dims
-        self.input_sizes = [3, 0]
+        self.input_sizes = [3, 3] if getattr(args, "input_viewdir", 0) == True else [3, 0]  # noqa: E712 (spsbrdfnerf.py:458)
         self.rgb_padding = 0.001
         self.beta, self.roughness, self.sun_v, self.indirect_light = beta, roughness, sun_v, indirect_light
         self.normal, self.glossy_scale, self.MultiBRDF, self.args = normal, glossy_scale, bool(MultiBRDF), args
@@ -88,10 +86,14 @@ class SpSBRDFNeRF(nn.Module):
         self.sigma_from_xyz = nn.Sequential(nn.Linear(feat, 1), nn.Softplus())
         self.feats_from_xyz = nn.Linear(feat, feat)
 
-        def head(n_out):
-            return nn.Sequential(nn.Linear(feat, feat // 2), nl, nn.Linear(feat // 2, n_out), nn.Sigmoid())
+        def head(n_out, extra_in=0):
+            return nn.Sequential(nn.Linear(feat + extra_in, feat // 2), nl, nn.Linear(feat // 2, n_out), nn.Sigmoid())
 
-        self.rgb_from_xyzdir = head(3)
+        # --input_viewdir: the rgb head also reads the view direction, encoded with mapping_sizes[1] octaves when --mapping
+        # (spsbrdfnerf.py:506-510,534,689-692)
+        self.dir_freqs = (mapping_sizes[1] if mapping else 0) if self.input_sizes[1] else 0
+        self.dir_dim = (2 * mapping_sizes[1] * 3 if mapping else 3) if self.input_sizes[1] else 0
+        self.rgb_from_xyzdir = head(3, self.dir_dim)
         if siren:
             self.fc_net.apply(_sine_init)
             self.fc_net[0].apply(_first_layer_sine_init)
@@ -174,7 +176,8 @@ class SpSBRDFNeRF(nn.Module):
             skip = self.skips[0] if self.skips and 0 < self.skips[0] < self.layers else -1   # --fc_layers <= 4: no skip layer
             self._specs[key] = Fn.FieldSpec(self.feat, self.layers, skip, self.pe_freqs,
                                             L.BN_ACT_SIN if self.siren_on else L.BN_ACT_RELU, dtype,
-                                            self.head_list(apply_brdf, apply_theta), nr_lr_on, nr_an_on)
+                                            self.head_list(apply_brdf, apply_theta), nr_lr_on, nr_an_on,
+                                            dir_dim=self.dir_dim, dir_freqs=self.dir_freqs)
         return self._specs[key]
 
     def named(self):
@@ -198,12 +201,17 @@ class SpSBRDFNeRF(nn.Module):
         xyz = input_xyz_.detach().float().contiguous()
         if sigma_only:
             return Fn.field_sigma(spec, self.named(), packed, xyz=xyz).unsqueeze(-1)
-        return self.evaluate(spec, packed, xyz=xyz)
+        dirs = None
+        if self.dir_dim:
+            if input_dir is None:
+                raise ValueError("--input_viewdir: forward() needs input_dir (B,3)")
+            dirs = input_dir.detach().float().contiguous()
+        return self.evaluate(spec, packed, xyz=xyz, dirs=dirs)
 
-    def evaluate(self, spec, packed, xyz=None, rays=None, z=None):
+    def evaluate(self, spec, packed, xyz=None, rays=None, z=None, dirs=None):
         names = spec.used_param_names()
         named = self.named()
-        return Fn.FieldFunction.apply(spec, packed, xyz, rays, z, (names, torch.is_grad_enabled()), *[named[n] for n in names])
+        return Fn.FieldFunction.apply(spec, packed, xyz, rays, z, (names, torch.is_grad_enabled(), dirs), *[named[n] for n in names])
 
 
 def load_model(args, compute_dtype=None):

@@ -30,7 +30,8 @@ def _f32(t):
 class FieldSpec:
     """Host-side description of one evaluation of the field: which heads, which dtype."""
 
-    def __init__(self, feat, layers, skip, pe_freqs, act, dtype, heads, normal_lr, normal_an=False, fold_feats=None):
+    def __init__(self, feat, layers, skip, pe_freqs, act, dtype, heads, normal_lr, normal_an=False, fold_feats=None,
+                 dir_dim=0, dir_freqs=0):
         # heads: list of (name, n_out, kind); heads[0] must be ("rgb_from_xyzdir", 3, PLAIN)
         self.feat, self.layers, self.skip, self.pe_freqs, self.act, self.dtype = feat, layers, skip, pe_freqs, act, dtype
         self.heads, self.normal_lr, self.normal_an = list(heads), bool(normal_lr), bool(normal_an)
@@ -41,10 +42,15 @@ class FieldSpec:
         if fold_feats is None:
             fold_feats = os.environ.get("BRDFNERF_FOLD_FEATS", "1") != "0"
         self.fold_feats = bool(fold_feats)
+        # --input_viewdir: the rgb head's first layer also reads the (encoded) view direction, dir_dim extra input columns
+        self.dir_dim, self.dir_freqs = int(dir_dim), int(dir_freqs)
+        if self.dir_dim and not self.fold_feats:
+            raise NotImplementedError("--input_viewdir needs the folded feats layer (BRDFNERF_FOLD_FEATS=1, the default)")
         self.folded, self.fold_grads = {}, {}
         d = L.FieldDesc()
         d.feat, d.layers, d.skip, d.pe_freqs, d.act, d.dtype = feat, layers, skip, pe_freqs, act, dtype
         d.fold_feats = int(self.fold_feats)
+        d.dir_dim, d.dir_freqs = self.dir_dim, self.dir_freqs
         d.n_heads = len(self.heads)
         c = 4 + (3 if normal_an else 0) + (3 if normal_lr else 0)
         self.head_cols = []
@@ -66,7 +72,7 @@ class FieldSpec:
 
     def key(self):
         return (self.feat, self.layers, self.skip, self.pe_freqs, self.act, self.dtype, tuple(self.heads), self.normal_lr,
-                self.normal_an, self.fold_feats)
+                self.normal_an, self.fold_feats, self.dir_dim, self.dir_freqs)
 
     def params_struct(self, named, grads=False):
         """named: dict state_dict-key -> tensor (parameters, or same-shaped gradient buffers)."""
@@ -86,7 +92,8 @@ class FieldSpec:
                     w1 = named[f"{name}.0.weight"]
                     ent = self.fold_grads.get(name)
                     if ent is None or ent[0].device != w1.device:
-                        ent = (torch.zeros_like(w1), torch.zeros(w1.shape[0], dtype=torch.float32, device=w1.device))
+                        ent = (torch.zeros(w1.shape[0], self.feat, dtype=torch.float32, device=w1.device),
+                               torch.zeros(w1.shape[0], dtype=torch.float32, device=w1.device))
                         self.fold_grads[name] = ent
                     s.head_w1[i], s.head_b1[i] = ent[0].data_ptr(), ent[1].data_ptr()
             else:
@@ -96,6 +103,10 @@ class FieldSpec:
                     s.head_w1[i], s.head_b1[i] = self.folded[name][0].data_ptr(), self.folded[name][1].data_ptr()
         if self.normal_lr:
             s.normal_w, s.normal_b = named["grad_from_xyz.weight"].data_ptr(), named["grad_from_xyz.bias"].data_ptr()
+        if self.dir_dim:        # direction columns of the rgb head's first layer (parameters, or their gradient buffer)
+            w = named[f"{self.heads[0][0]}.0.weight"]
+            assert w.shape[1] == self.feat + self.dir_dim and w.is_contiguous()
+            s.head0_wdir, s.head0_wdir_ld = w.data_ptr() + 4 * self.feat, w.shape[1]
         return s
 
     @torch.no_grad()
@@ -103,10 +114,10 @@ class FieldSpec:
         """(W1 Wf, W1 bf + b1) per head, refreshed whenever the weights are re-packed."""
         wf, bf = named["feats_from_xyz.weight"].detach(), named["feats_from_xyz.bias"].detach()
         for name, _, _ in self.heads:
-            w1, b1 = named[f"{name}.0.weight"].detach(), named[f"{name}.0.bias"].detach()
+            w1, b1 = named[f"{name}.0.weight"].detach()[:, :self.feat], named[f"{name}.0.bias"].detach()
             ent = self.folded.get(name)
             if ent is None or ent[0].device != w1.device:
-                ent = (torch.empty_like(w1), torch.empty_like(b1))
+                ent = (torch.empty(w1.shape[0], self.feat, dtype=torch.float32, device=w1.device), torch.empty_like(b1))
                 self.folded[name] = ent
             torch.matmul(w1, wf, out=ent[0])
             torch.addmv(b1, w1, bf, out=ent[1])
@@ -122,8 +133,8 @@ class FieldSpec:
             if ent is None:
                 continue
             m, sv = ent
-            w1 = named[f"{name}.0.weight"].detach()
-            dw1, db1 = named_grads[f"{name}.0.weight"], named_grads[f"{name}.0.bias"]
+            w1 = named[f"{name}.0.weight"].detach()[:, :self.feat]
+            dw1, db1 = named_grads[f"{name}.0.weight"][:, :self.feat], named_grads[f"{name}.0.bias"]
             dw1.addmm_(m, wf.t())
             dw1.addr_(sv, bf)
             db1.add_(sv)
@@ -144,11 +155,15 @@ class FieldSpec:
         return names
 
 
-def make_points(xyz=None, rays=None, z=None):
+def make_points(xyz=None, rays=None, z=None, dirs=None):
     pts = L.Points()
+    pts.dirs = None
     if xyz is not None:
         pts.xyz, pts.rays, pts.z = xyz.data_ptr(), None, None
         pts.ray_stride, pts.n_samples, pts.n_points = 0, 0, xyz.shape[0]
+        if dirs is not None:
+            assert dirs.shape == xyz.shape and dirs.is_contiguous() and dirs.dtype == torch.float32
+            pts.dirs = dirs.data_ptr()
     else:
         pts.xyz, pts.rays, pts.z = None, rays.data_ptr(), z.data_ptr()
         pts.ray_stride, pts.n_samples, pts.n_points = rays.shape[1], z.shape[1], z.shape[0] * z.shape[1]
@@ -183,9 +198,9 @@ class FieldFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, packed, xyz, rays, z, names_grad, *params):
-        names, grad_enabled = names_grad            # grad mode is always off inside Function.forward: passed in
+        names, grad_enabled, dirs = names_grad      # grad mode is always off inside Function.forward: passed in
         named = dict(zip(names, params))
-        pts = make_points(xyz, rays, z)
+        pts = make_points(xyz, rays, z, dirs)
         ref = xyz if xyz is not None else z
         out = torch.empty(pts.n_points, spec.out_channels, dtype=torch.float32, device=ref.device)
         need_grad = grad_enabled and any(p.requires_grad for p in params)
@@ -202,7 +217,7 @@ class FieldFunction(torch.autograd.Function):
             if not need_grad:
                 stash = None
         ctx.spec, ctx.packed, ctx.names, ctx.stash = spec, packed, names, stash
-        ctx.pts_t = (xyz, rays, z)
+        ctx.pts_t = (xyz, rays, z, dirs)
         ctx.save_for_backward(out, *params)
         return out
 
@@ -223,8 +238,8 @@ class FieldFunction(torch.autograd.Function):
         named_grads = dict(zip(names, grads))
         gs = spec.params_struct(named_grads, grads=True)
         ps = spec.params_struct(named)
-        xyz, rays, z = ctx.pts_t
-        pts = make_points(xyz, rays, z)
+        xyz, rays, z, dirs = ctx.pts_t
+        pts = make_points(xyz, rays, z, dirs)
         d_out = _f32(d_out)
         L.check(L.lib().bn_field_backward(C.byref(spec.desc), C.byref(ps), _p(ctx.packed), C.byref(pts), _p(out),
                                           _p(d_out), _p(ctx.stash), C.byref(gs), _stream()), "bn_field_backward")

@@ -77,7 +77,10 @@ def inference(model, args, rays_xyz, z_vals, rays_d=None, sun_d=None, rays_t=Non
         return {"sigmas": sig.unsqueeze(-1), "depth": d, "alphas": a, "weights": w, "transparency": T,
                 "z_vals": z_vals}, "Lambertian"
 
-    out = model.evaluate(spec, packed, xyz=xyz, rays=_rays, z=None if _rays is None else z_vals).view(R, S, spec.out_channels)
+    dirs = None
+    if _rays is None and getattr(model, "dir_dim", 0):       # --input_viewdir with explicit points: rays_d per sample (:96,121)
+        dirs = torch.repeat_interleave(rays_d.float(), S, dim=0).contiguous()
+    out = model.evaluate(spec, packed, xyz=xyz, rays=_rays, z=None if _rays is None else z_vals, dirs=dirs).view(R, S, spec.out_channels)
     if S == 1:
         raise NotImplementedError("single-sample pass 2 is undefined in the reference (SURVEY quirk 4)")
     alphas, transparency, weights, depth, acc = Fn.composite(z_vals, out, noise_arg, args.noise_std)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BN_ABI_VERSION 1
+#define BN_ABI_VERSION 2
 #define BN_MAX_LAYERS 12
 #define BN_MAX_HEADS 4 /* rgb + up to 3 BRDF heads evaluated together */
 
@@ -81,6 +81,11 @@ typedef struct bn_field_desc {
                                           (chain rule back to the three factors: brdf_nerf_amd/functions.py, unfold_grads).
                                           Same function, one F x F product less per point in forward, backward and
                                           weight gradient.                                           */
+  int32_t dir_dim;                     /* --input_viewdir 1 (spsbrdfnerf.py:458,689-692): width of the (encoded) view direction the
+                                          rgb head's first layer reads beside the features: 0 (off), 3 (raw, no --mapping) or
+                                          6 * dir_freqs.  Needs fold_feats = 1: params.head_w1[0] is the folded [F/2][F] matrix and
+                                          params.head0_wdir the direction columns of <rgb head>.0.weight                        */
+  int32_t dir_freqs;                   /* octaves of the direction encoding (mapping_sizes[1] = 4), 0 = raw direction              */
 } bn_field_desc;
 
 /* fp32 parameter tensors in PyTorch nn.Linear layout (weight [out][in], row-major). */
@@ -92,6 +97,8 @@ typedef struct bn_field_params {
   const float *head_w1[BN_MAX_HEADS], *head_b1[BN_MAX_HEADS]; /* <head>.0                      */
   const float *head_w2[BN_MAX_HEADS], *head_b2[BN_MAX_HEADS]; /* <head>.2                      */
   const float *normal_w, *normal_b;    /* grad_from_xyz (may be NULL)                          */
+  const float *head0_wdir;             /* rgb_from_xyzdir.0.weight[:, F:]  ([F/2][dir_dim], row stride head0_wdir_ld); NULL when dir_dim == 0 */
+  int64_t head0_wdir_ld;
 } bn_field_params;
 
 /* Same shape as bn_field_params but writable: gradient accumulators (fp32, += semantics). */
@@ -100,6 +107,8 @@ typedef struct bn_field_grads {
   float *sigma_w, *sigma_b, *feats_w, *feats_b;
   float *head_w1[BN_MAX_HEADS], *head_b1[BN_MAX_HEADS], *head_w2[BN_MAX_HEADS], *head_b2[BN_MAX_HEADS];
   float *normal_w, *normal_b;
+  float *head0_wdir;                   /* += d/d rgb_from_xyzdir.0.weight[:, F:]  (row stride head0_wdir_ld) */
+  int64_t head0_wdir_ld;
 } bn_field_grads;
 
 /* Bytes of the packed weight buffer (forward + transposed copies) for `desc`. */
@@ -118,6 +127,8 @@ typedef struct bn_points {
   const float *z;
   int32_t ray_stride, n_samples;
   int64_t n_points;
+  const float *dirs;                   /* xyz form with desc.dir_dim > 0: view direction per point [n_points][3] (the rays form reads
+                                          rays[ray][3:6], as inference() repeats rays_d per sample, spsbrdfnerf.py:96,121)       */
 } bn_points;
 
 /* sigma-only forward (forward(sigma_only=True), spsbrdfnerf.py:684): sigma[n_points]. */

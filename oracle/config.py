@@ -39,6 +39,8 @@ class FieldConfig:
     noise_std: float = 0.0
     data: str = "sat"
     sun_v: str = "none"                # none | analystic (sun-visibility pass, rendering.py:244-259; no parameters)
+    input_viewdir: int = 0             # 1: the encoded view direction joins the rgb head's input (spsbrdfnerf.py:458,689-692)
+    dir_freqs: int = 4                 # mapping_sizes[1], spsbrdfnerf.py:445
 
     @property
     def RPV(self):
@@ -47,6 +49,13 @@ class FieldConfig:
     @property
     def in_dim(self):
         return 2 * self.pe_freqs * 3 if self.mapping else 3
+
+    @property
+    def dir_dim(self):
+        """in_size[1] (spsbrdfnerf.py:506-510): 0 without --input_viewdir, else the (encoded) direction width."""
+        if self.input_viewdir != 1:
+            return 0
+        return 2 * self.dir_freqs * 3 if self.mapping else 3
 
     def param_shapes(self):
         """Ordered [(state_dict key, shape, init kind)] - registration order of the reference."""
@@ -61,7 +70,11 @@ class FieldConfig:
         out.append(("sigma_from_xyz.0.bias", (1,), "bias%d" % F))
         out.append(("feats_from_xyz.weight", (F, F), "linear"))
         out.append(("feats_from_xyz.bias", (F,), "bias%d" % F))
-        out += self._head("rgb_from_xyzdir", 3)
+        rgb = self._head("rgb_from_xyzdir", 3)
+        if self.dir_dim:      # Linear(feat + in_size[1], feat // 2), spsbrdfnerf.py:534
+            rgb[0] = ("rgb_from_xyzdir.0.weight", (F // 2, F + self.dir_dim), "linear")
+            rgb[1] = ("rgb_from_xyzdir.0.bias", (F // 2,), "bias%d" % (F + self.dir_dim))
+        out += rgb
         if self.normal in ("learned", "analystic_learned"):
             out.append(("grad_from_xyz.weight", (3, F), "linear"))
             out.append(("grad_from_xyz.bias", (3,), "bias%d" % F))

@@ -75,9 +75,10 @@ def _tile3(v):
 
 
 def field_forward(params, cfg, xyz, sigma_only=False, apply_brdf=False, apply_theta=False,
-                  nr_an_on=False, nr_lr_on=False):
-    """SpSBRDFNeRF.forward (spsbrdfnerf.py:662-757) for sun_v='none', beta=False,
-    indirect_light=False, input_viewdir=0 (the configurations in SURVEY.md section 8).
+                  nr_an_on=False, nr_lr_on=False, dirs=None):
+    """SpSBRDFNeRF.forward (spsbrdfnerf.py:662-757) for sun_v='none', beta=False, indirect_light=False.
+    `dirs` (B,3): per-point view directions, used only with cfg.input_viewdir == 1 (spsbrdfnerf.py:689-692: the rgb head
+    reads cat([xyz_features, mapping[1](input_dir)])).
 
     Channel order: [rgb3, sigma1, (normal_an3), (normal_lr3), (rough1 | k3,theta3,rhoc3 | b3,c3,theta1)].
     """
@@ -87,7 +88,10 @@ def field_forward(params, cfg, xyz, sigma_only=False, apply_brdf=False, apply_th
     if sigma_only:
         return sigma
     feats = torch.nn.functional.linear(h, params["feats_from_xyz.weight"], params["feats_from_xyz.bias"])
-    rgb = _head(params, cfg, "rgb_from_xyzdir", feats)
+    rgb_in = feats
+    if cfg.dir_dim:
+        rgb_in = torch.cat([feats, positional_encoding(dirs, cfg.dir_freqs) if cfg.mapping else dirs], -1)
+    rgb = _head(params, cfg, "rgb_from_xyzdir", rgb_in)
     out = [rgb, sigma]
     if nr_an_on:
         out.append(-l2_normalize(sigma_grad(params, cfg, xyz, create_graph=True)))

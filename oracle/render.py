@@ -133,8 +133,9 @@ def inference(params, cfg, xyz, z, rays_d, sun_d, rnd, sigma_only=False, apply_b
     pts = xyz.reshape(-1, 3)
     nr_an = cfg.normal in ("analystic", "analystic_learned") or bTestNormal
     nr_lr = cfg.normal in ("learned", "analystic_learned")
+    dirs = torch.repeat_interleave(rays_d, S, dim=0) if cfg.dir_dim else None      # spsbrdfnerf.py:96,121
     out = field_forward(params, cfg, pts, sigma_only=sigma_only, apply_brdf=apply_brdf,
-                        apply_theta=apply_theta, nr_an_on=nr_an, nr_lr_on=nr_lr)
+                        apply_theta=apply_theta, nr_an_on=nr_an, nr_lr_on=nr_lr, dirs=dirs)
     noise = rnd.randn((R, S), z.dtype)
     if sigma_only:
         sig = out.view(R, S)

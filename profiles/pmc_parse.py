@@ -9,7 +9,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-NAMES = [("field_fwd_kernel", "Lb1", "field_fwd_full"), ("field_fwd_kernel", "Lb0", "field_fwd_sigma"), ("field_bwd_kernel", "", "field_bwd_chain"),
+# field_fwd_kernel<T, MT, NT, WAVES = 8, KEEP, DIR>: KEEP (the stash-writing training forward) follows the 8
+NAMES = [("field_fwd_kernel", "Li8ELb1", "field_fwd_full"), ("field_fwd_kernel", "Li8ELb0", "field_fwd_sigma"), ("field_bwd_kernel", "", "field_bwd_chain"),
          ("wgrad256_kernel", "", "wgrad"), ("skinny_wgrad_kernel", "", "skinny_wgrad"), ("field_adjoint_kernel", "", "field_adjoint"),
          ("field_adjbwd_kernel", "", "field_adjoint_bwd"), ("composite_kernel", "Lb0", "composite_fwd"), ("composite_kernel", "Lb1", "composite_bwd"),
          ("guided_kernel", "", "guided_samples"), ("adam_kernel", "", "adam")]
@@ -17,7 +18,7 @@ NAMES = [("field_fwd_kernel", "Lb1", "field_fwd_full"), ("field_fwd_kernel", "Lb
 
 def classify(kernel_name):
     for sub, tag, out in NAMES:
-        if sub in kernel_name and (not tag or tag in kernel_name or tag.replace("Lb1", "true").replace("Lb0", "false") in kernel_name):
+        if sub in kernel_name and (not tag or tag in kernel_name or tag.replace("Li8E", "8, ").replace("Lb1", "true").replace("Lb0", "false") in kernel_name):
             return out
     return None
 

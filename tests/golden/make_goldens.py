@@ -48,7 +48,8 @@ def ref_args(cfg: FieldConfig):
     return argparse.Namespace(
         model="spsbrdf-nerf", fc_layers=cfg.layers, fc_feat=cfg.feat, mapping=cfg.mapping, siren=int(cfg.siren),
         t_embbeding_tau=4, beta=False, roughness=cfg.roughness, normal=cfg.normal, indirect_light=False,
-        glossy_scale=1.0, sun_v=cfg.sun_v, MultiBRDF=int(cfg.MultiBRDF), dim_RPV=cfg.dim_RPV, input_viewdir=0,
+        glossy_scale=1.0, sun_v=cfg.sun_v, MultiBRDF=int(cfg.MultiBRDF), dim_RPV=cfg.dim_RPV,
+        input_viewdir=int(getattr(cfg, "input_viewdir", 0)),
         funcM=cfg.funcM, funcF=cfg.funcF, funcH=cfg.funcH, b=cfg.b, c=cfg.c, theta=cfg.theta, B0=0, h=0,
         shell_hapke=cfg.shell_hapke, hpk_scl=cfg.hpk_scl, guided_samples=cfg.guided_samples,
         n_samples=cfg.n_samples, n_importance=0, std_range=cfg.std_range, data=cfg.data, sc_lambda=0.0,
@@ -452,6 +453,38 @@ def gen_regularisers(ref):
          d_normal_an=n_an.grad, d_normal_lr=n_lr.grad)
 
 
+def gen_viewdir(ref):
+    """--input_viewdir 1 (spsbrdfnerf.py:458,689-692): the rgb head reads cat([xyz_features, mapping[1](view dir)]).
+    Field forward with per-point directions + parameter gradients of a random linear functional (with and without --mapping),
+    and the full render_rays dict (train mode, RPV + learned normals)."""
+    for tag, kw in (("viewdir", dict(input_viewdir=1, funcM=1, funcF=1, funcH=1, normal="learned")),
+                    ("viewdir_nomap", dict(input_viewdir=1, mapping=False))):
+        cfg = mini(**kw)
+        model, csum = build_ref_model(ref, cfg, seed=14)
+        g = torch.Generator().manual_seed(10)
+        xyz = torch.rand(203, 3, generator=g) * 2 - 1
+        dirs = torch.nn.functional.normalize(torch.randn(203, 3, generator=g), dim=-1)
+        nlr = cfg.normal in ("learned", "analystic_learned")
+        out = quiet(model, xyz.clone(), input_dir=dirs, apply_brdf=True, apply_theta=True, nr_an_on=False, nr_lr_on=nlr)
+        coef = torch.randn(out.shape, generator=g)
+        (out * coef).sum().backward()
+        grads = {f"grad/{k}": (p_.grad if p_.grad is not None else torch.zeros_like(p_)) for k, p_ in model.named_parameters()}
+        save(f"field_{tag}_F64", xyz=xyz, dirs=dirs, out_brdf=out, coef=coef, param_checksum=csum, param_seed=14, **grads)
+    cfg = mini(input_viewdir=1, funcM=1, funcF=1, funcH=1, normal="learned")
+    model, csum = build_ref_model(ref, cfg, seed=11)
+    rays = sat_rays(64, 21)
+    rays[32:, 3:6] = torch.nn.functional.normalize(torch.tensor([-0.2, 0.1, -0.95]), dim=0)      # a second view direction
+    res, bt, rlog = run_render(ref, cfg, model, rays, "train", dict(apply_brdf=True, apply_theta=True, cos_irra_on=True))
+    tgt = torch.rand(64, 3, generator=torch.Generator().manual_seed(5))
+    loss = ((res["rgb_coarse"] - tgt) ** 2).mean() + 0.01 * res["depth_coarse"].mean()
+    loss.backward()
+    arrays = {f"out/{k}": v for k, v in res.items()}
+    arrays.update({f"rand{i}": t for i, t in enumerate(rlog)})
+    arrays.update({f"grad/{k}": (p_.grad if p_.grad is not None else torch.zeros_like(p_)) for k, p_ in model.named_parameters()})
+    save("render_viewdir_train", rays=rays, targets=tgt, loss=loss, brdf_type=np.array(bt), param_checksum=csum, param_seed=11,
+         **arrays)
+
+
 INIT_CONFIGS = {
     "lambert": dict(),
     "rpv111_anlr": dict(funcM=1, funcF=1, funcH=1, normal="analystic_learned"),
@@ -459,6 +492,7 @@ INIT_CONFIGS = {
     "microfacet_nlr": dict(roughness=True, normal="learned"),
     "relu_rpvM": dict(siren=False, funcM=1),
     "nomap": dict(mapping=False),
+    "viewdir": dict(input_viewdir=1),
 }
 
 
@@ -490,6 +524,9 @@ if __name__ == "__main__":
     if "--only-init" in sys.argv:
         gen_init(ref)
         sys.exit(0)
+    if "--only-viewdir" in sys.argv:
+        gen_viewdir(ref)
+        sys.exit(0)
     if "--only-field-variants" in sys.argv:
         gen_field_variants(ref)
         sys.exit(0)
@@ -511,3 +548,4 @@ if __name__ == "__main__":
     gen_loss(ref)
     gen_regularisers(ref)
     gen_init(ref)
+    gen_viewdir(ref)

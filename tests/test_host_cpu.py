@@ -29,7 +29,7 @@ def make_args(cfg, **over):
     a = argparse.Namespace(
         model="spsbrdf-nerf", fc_layers=cfg.layers, fc_feat=cfg.feat, mapping=cfg.mapping, siren=int(cfg.siren),
         t_embbeding_tau=4, beta=False, roughness=cfg.roughness, normal=cfg.normal, indirect_light=False, glossy_scale=1.0,
-        sun_v="none", MultiBRDF=0, dim_RPV=cfg.dim_RPV, input_viewdir=0, funcM=cfg.funcM, funcF=cfg.funcF, funcH=cfg.funcH,
+        sun_v="none", MultiBRDF=0, dim_RPV=cfg.dim_RPV, input_viewdir=int(cfg.input_viewdir), funcM=cfg.funcM, funcF=cfg.funcF, funcH=cfg.funcH,
         b=cfg.b, c=cfg.c, theta=cfg.theta, shell_hapke=0, hpk_scl=4.0, guided_samples=64, n_samples=64, n_importance=0,
         std_range=3.0, data="sat", sc_lambda=0.0, chunk=5120, noise_std=0.0, margin=1e-4, stdscale=1, fresnel_f0=0.04)
     for k, v in over.items():
@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(bn_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
     L = _lib.lib()                       # dlopen; resolves every symbol or raises
-    assert L.bn_abi_version() == 1
+    assert L.bn_abi_version() == 2
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
@@ -104,7 +104,8 @@ def test_init_is_rng_order_identical_to_reference():
     seed = int(g["seed"])
     kinds = {"lambert": dict(), "rpv111_anlr": dict(funcM=1, funcF=1, funcH=1, normal="analystic_learned"),
              "hapke_bct_nlr": dict(b=1, c=1, theta=1, normal="learned"), "microfacet_nlr": dict(roughness=True, normal="learned"),
-             "relu_rpvM": dict(siren=False, funcM=1), "nomap": dict(mapping=False)}
+             "relu_rpvM": dict(siren=False, funcM=1), "nomap": dict(mapping=False),
+             "viewdir": dict(input_viewdir=1)}
     for name, kw in kinds.items():
         cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16, **kw)
         torch.manual_seed(seed)
@@ -120,7 +121,7 @@ def test_init_is_rng_order_identical_to_reference():
 
 def test_unsupported_flags_raise():
     from brdf_nerf_amd import load_model
-    for over in (dict(beta=True), dict(sun_v="learned"), dict(input_viewdir=1), dict(indirect_light=True)):
+    for over in (dict(beta=True), dict(sun_v="learned"), dict(indirect_light=True)):
         with pytest.raises(NotImplementedError):
             load_model(make_args(FieldConfig(feat=64), **over))
     with pytest.raises(ValueError):
@@ -135,13 +136,15 @@ def test_packed_and_stash_sizes():
     spec = model.spec(False, False, False)
     F, P = 512, 64
     fold = spec.fold_feats                                    # feats layer folded into the heads: no F x F feats blocks
-    fwd = F * P + 6 * F * F + (F * P + F * F) + (0 if fold else F * F) + 256 * F
+    fwd = F * P + 6 * F * F + (F * P + F * F) + (0 if fold else F * F) + 256 * F + 32 * F     # + the sigma head's 32-row tile
     bwd = 7 * F * F + (0 if fold else F * F) + F * 256 + 2 * P * F   # + (W_0[:, :P])^T and (W_skip[:, :P])^T for the normals adjoint
     assert spec.packed_bytes == (fwd + bwd) * 4                      # fp32 parity mode
     n = Fn.field_stash_bytes(spec, 1000)
     assert n > 1024 * F * 4 * 16 and n % 256 == 0
     model.compute_dtype = "bf16"
     assert model.spec(False, False, False).packed_bytes == (fwd + bwd) * 2
+    vd = load_model(make_args(FieldConfig(input_viewdir=1), compute_dtype="bf16"))         # + [256 rows][32] direction columns
+    assert vd.spec(False, False, False).packed_bytes == (fwd + bwd + 256 * 32) * 2
 
 
 def test_losses_match_golden():

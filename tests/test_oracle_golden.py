@@ -289,6 +289,52 @@ def test_field_relu_and_no_mapping(tag, kw):
         assert float((got - torch.from_numpy(ref)).abs().max()) <= 1e-4 * scale + 1e-9, k
 
 
+@pytest.mark.parametrize("tag,kw", [("viewdir", dict(input_viewdir=1, funcM=1, funcF=1, funcH=1, normal="learned")),
+                                    ("viewdir_nomap", dict(input_viewdir=1, mapping=False))])
+def test_field_input_viewdir(tag, kw):
+    """--input_viewdir 1 (spsbrdfnerf.py:458,689-692): the rgb head reads the encoded view direction; forward with per-point
+    directions and parameter gradients against the reference."""
+    g = load_golden(f"field_{tag}_F64")
+    cfg = mini(**kw)
+    p = tparams(cfg, 14)
+    for v in p.values():
+        v.requires_grad_(True)
+    out = F.field_forward(p, cfg, torch.from_numpy(g["xyz"]), apply_brdf=True, apply_theta=True, nr_lr_on=cfg.normal == "learned",
+                          dirs=torch.from_numpy(g["dirs"]))
+    assert_close(out, g["out_brdf"], 1e-5, 1e-6, "out")
+    (out * torch.from_numpy(g["coef"])).sum().backward()
+    for k, v in p.items():
+        ref = g[f"grad/{k}"]
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        got = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert float((got - torch.from_numpy(ref)).abs().max()) <= 1e-4 * scale + 1e-9, k
+
+
+def test_render_rays_input_viewdir():
+    """render_rays with --input_viewdir 1 (two view directions in the batch), train mode, RPV + learned normals."""
+    g = load_golden("render_viewdir_train")
+    cfg = mini(input_viewdir=1, funcM=1, funcF=1, funcH=1, normal="learned")
+    p = tparams(cfg, 11)
+    for v in p.values():
+        v.requires_grad_(True)
+    res, bt = RD.render_rays(p, cfg, torch.from_numpy(g["rays"]), RD.Randoms(replay=replay_list(g)), mode="train",
+                             apply_brdf=True, apply_theta=True, cos_irra_on=True)
+    assert bt == str(g["brdf_type"])
+    for k in sorted(k[4:] for k in g if k.startswith("out/")):
+        if k == "sort_idx_coarse":
+            assert (res[k].numpy() == g["out/" + k]).all()
+        else:
+            assert_close(res[k], g["out/" + k], 2e-5, 2e-6, k)
+    loss = ((res["rgb_coarse"] - torch.from_numpy(g["targets"])) ** 2).mean() + 0.01 * res["depth_coarse"].mean()
+    assert_close(loss, g["loss"], 1e-5, 1e-7, "loss")
+    loss.backward()
+    for k, v in p.items():
+        ref = g[f"grad/{k}"]
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        got = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert float((got - torch.from_numpy(ref)).abs().max()) <= 2e-4 * scale + 1e-9, k
+
+
 def test_regulariser_losses():
     g = load_golden("loss_regularisers")
     t = {k: torch.from_numpy(v) for k, v in g.items()}
