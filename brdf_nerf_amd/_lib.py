@@ -11,11 +11,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BRDFNERF_HIP_LIB") or os.path.join(HERE, "libbrdfnerf_hip.so")
 
 BN_MAX_LAYERS = 12
-BN_MAX_HEADS = 4
+BN_MAX_HEADS = 6
 BN_F32, BN_BF16, BN_F16 = 0, 1, 2
 DTYPES = {"fp32": BN_F32, "bf16": BN_BF16, "fp16": BN_F16}
 BN_ACT_SIN, BN_ACT_RELU = 0, 1
-BN_HEAD_PLAIN, BN_HEAD_RPV_K, BN_HEAD_RPV_THETA, BN_HEAD_HAPKE_THETA, BN_HEAD_TILE3 = 0, 1, 2, 3, 4
+BN_HEAD_PLAIN, BN_HEAD_RPV_K, BN_HEAD_RPV_THETA, BN_HEAD_HAPKE_THETA, BN_HEAD_TILE3, BN_HEAD_BETA = 0, 1, 2, 3, 4, 5
 BN_BRDF_AUX = 16
 
 fptr = C.c_void_p
@@ -26,23 +26,28 @@ class FieldDesc(C.Structure):
                 ("act", C.c_int32), ("dtype", C.c_int32), ("n_heads", C.c_int32),
                 ("head_out", C.c_int32 * BN_MAX_HEADS), ("head_kind", C.c_int32 * BN_MAX_HEADS),
                 ("normal_lr", C.c_int32), ("normal_an", C.c_int32), ("out_channels", C.c_int32), ("fold_feats", C.c_int32),
-                ("dir_dim", C.c_int32), ("dir_freqs", C.c_int32)]
+                ("dir_dim", C.c_int32), ("dir_freqs", C.c_int32), ("t_dim", C.c_int32)]
+
+
+_PARAM_FIELDS = [("trunk_w", fptr * BN_MAX_LAYERS), ("trunk_b", fptr * BN_MAX_LAYERS),
+                 ("sigma_w", fptr), ("sigma_b", fptr), ("feats_w", fptr), ("feats_b", fptr),
+                 ("head_w1", fptr * BN_MAX_HEADS), ("head_b1", fptr * BN_MAX_HEADS),
+                 ("head_w2", fptr * BN_MAX_HEADS), ("head_b2", fptr * BN_MAX_HEADS),
+                 ("normal_w", fptr), ("normal_b", fptr), ("head0_wdir", fptr), ("head0_wdir_ld", C.c_int64),
+                 ("head1_wt", fptr), ("head1_wt_ld", C.c_int64)]
 
 
 class FieldParams(C.Structure):
-    _fields_ = [("trunk_w", fptr * BN_MAX_LAYERS), ("trunk_b", fptr * BN_MAX_LAYERS),
-                ("sigma_w", fptr), ("sigma_b", fptr), ("feats_w", fptr), ("feats_b", fptr),
-                ("head_w1", fptr * BN_MAX_HEADS), ("head_b1", fptr * BN_MAX_HEADS),
-                ("head_w2", fptr * BN_MAX_HEADS), ("head_b2", fptr * BN_MAX_HEADS),
-                ("normal_w", fptr), ("normal_b", fptr), ("head0_wdir", fptr), ("head0_wdir_ld", C.c_int64)]
+    _fields_ = list(_PARAM_FIELDS)
 
 
-FieldGrads = FieldParams  # identical shape (writable pointers)
+class FieldGrads(C.Structure):      # the same members, writable, + the gradient of the embedding input
+    _fields_ = list(_PARAM_FIELDS) + [("d_t_embed", fptr)]
 
 
 class Points(C.Structure):
     _fields_ = [("xyz", fptr), ("rays", fptr), ("z", fptr), ("ray_stride", C.c_int32), ("n_samples", C.c_int32),
-                ("n_points", C.c_int64), ("dirs", fptr)]
+                ("n_points", C.c_int64), ("dirs", fptr), ("t_embed", fptr)]
 
 
 class LibraryMissing(RuntimeError):
@@ -119,7 +124,7 @@ def load(path):
     for name, (res, args) in _SIGS.items():
         fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if L.bn_abi_version() != 2:
+    if L.bn_abi_version() != 3:
         raise LibraryMissing(f"{path}: ABI version mismatch; rebuild")
     return L
 

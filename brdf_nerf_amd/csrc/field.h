@@ -3,7 +3,10 @@
 #pragma once
 #include "common.h"
 
-#define BN_MAX_PASS 2
+#define BN_MAX_PASS 3
+#ifndef BN_DPH                    // (an A/B build may pin 12 = the four-head layout of ABI <= 2: profiles/r02_ablation.txt)
+#define BN_DPH (3 * BN_MAX_HEADS)   // pre-activation gradients of the heads' (<= 3) outputs kept per point
+#endif
 // 32-column tiles per wave in a single-head pass (N = F/2 columns): NT/2 spreads the pass over all eight waves; NT keeps
 // half of them idle but halves the LDS fragment reads per MFMA (BN_HEAD_WIDE, A/B switch).
 #ifdef BN_HEAD_WIDE
@@ -27,7 +30,10 @@ struct FieldGeom {
   int C;                        // out channels
   int ch_normal_an, ch_normal_lr;  // channel index or -1
   int fold;                        // feats layer folded into the heads' first layers (bn_field_desc.fold_feats)
-  int DD, KD, dir_freqs;           // view-direction input of the rgb head: valid width (0: none), width padded to 16, octaves
+  // Extra inputs of pass 0's first layers, one LDS tile / stash row of KD columns (KD = 0: none, else 16 or 32):
+  //   [0, DD)        the (encoded) view direction, read by head 0 (--input_viewdir; dir_freqs octaves, 0 = raw)
+  //   [KT0, KT0+TD)  the per-image embedding, read by head 1 of kind BN_HEAD_BETA (--beta);  KT0 = round_up(DD, 8)
+  int DD, KD, dir_freqs, TD, KT0;
 };
 
 // Tile configuration of the fused chain kernels: 8 waves per workgroup, one workgroup per CU (2 waves per SIMD);
@@ -57,20 +63,30 @@ static inline int bn_make_geom(const bn_field_desc *d, FieldGeom *g) {
   }
   g->H2 = d->feat / 2;
   g->fold = d->fold_feats != 0;
-  g->DD = d->dir_dim; g->dir_freqs = d->dir_freqs;
-  g->KD = (d->dir_dim + 15) / 16 * 16;
+  g->DD = d->dir_dim; g->dir_freqs = d->dir_freqs; g->TD = d->t_dim;
+  g->KT0 = (d->dir_dim + 7) / 8 * 8;
+  g->KD = (g->KT0 + d->t_dim + 15) / 16 * 16;
   BN_REQUIRE(d->dir_dim == 0 || (d->dir_dim == (d->dir_freqs > 0 ? 6 * d->dir_freqs : 3) && d->dir_dim <= 32 && g->fold),
              "field: dir_dim=%d dir_freqs=%d fold=%d unsupported (input_viewdir needs fold_feats and at most 5 octaves)", d->dir_dim,
              d->dir_freqs, g->fold);
+  {
+    const bool beta = d->n_heads >= 2 && d->head_kind[1] == BN_HEAD_BETA;
+    BN_REQUIRE(beta == (d->t_dim > 0) && d->t_dim >= 0 && d->t_dim <= 16 && (!beta || (g->fold && d->head_out[1] == 1)),
+               "field: t_dim=%d needs exactly a 1-wide head 1 of kind BN_HEAD_BETA (and fold_feats)", d->t_dim);
+    for (int i = 0; i < d->n_heads; ++i)
+      BN_REQUIRE(i == 1 || d->head_kind[i] != BN_HEAD_BETA, "field: BN_HEAD_BETA is head 1 only (head %d)", i);
+    BN_REQUIRE(g->KD <= 32, "field: dir_dim=%d + t_dim=%d do not fit the 32-column extra-input tile", d->dir_dim, d->t_dim);
+  }
   g->n_heads = d->n_heads;
   g->n_pass = (d->n_heads + 1) / 2;
-  int c = 4;
+  int c = d->t_dim > 0 ? 5 : 4;          // [rgb3, sigma, (beta)]
   g->ch_normal_an = g->ch_normal_lr = -1;
   if (d->normal_an) { g->ch_normal_an = c; c += 3; }
   if (d->normal_lr) { g->ch_normal_lr = c; c += 3; }
   g->head_col[0] = 0;
   for (int i = 1; i < d->n_heads; ++i) {
     BN_REQUIRE(d->head_out[i] == 1 || d->head_out[i] == 3, "field: head_out[%d]=%d", i, d->head_out[i]);
+    if (d->head_kind[i] == BN_HEAD_BETA) { g->head_col[i] = 4; continue; }
     g->head_col[i] = c;
     // 1-wide heads are tiled x3 in the output except roughness / Hapke theta (spsbrdfnerf.py:726,731,755)
     c += (d->head_kind[i] == BN_HEAD_PLAIN || d->head_kind[i] == BN_HEAD_HAPKE_THETA) ? d->head_out[i] : 3;
@@ -94,7 +110,7 @@ struct PackedLayout {
   size_t fwd_trunk[BN_MAX_LAYERS][2];  // [l][0]: PE part (l==0, l==skip) or h part; [l][1]: h part of the skip layer
   size_t fwd_feats, fwd_head[BN_MAX_PASS];
   size_t fwd_sigma, fwd_nlr;           // one 32-row tile each over K = F: row 0 = w_sigma / rows 0..2 = grad_from_xyz (rest zero)
-  size_t fwd_dir;                      // [pass_N[0] rows][KD]: the rgb head's view-direction columns (rows of a second head: zero)
+  size_t fwd_dir;                      // [pass_N[0] rows][KD]: the extra-input columns of pass 0's first layers (FieldGeom.KD)
   size_t bwd_trunk[BN_MAX_LAYERS];     // W_l^T restricted to the h inputs, l >= 1
   size_t bwd_feats, bwd_head[BN_MAX_PASS];
   size_t bwd_pe[2];                    // (W_l[:, :P])^T for l = 0 and l = skip: [KP rows][F k], analytic-normal adjoint only
@@ -116,7 +132,7 @@ static inline void bn_make_packed_layout(const FieldGeom &g, PackedLayout *pl) {
   for (int p = 0; p < g.n_pass; ++p) pl->fwd_head[p] = take(g.pass_N[p], g.F);
   pl->fwd_sigma = take(32, g.F);
   pl->fwd_nlr = g.ch_normal_lr >= 0 ? take(32, g.F) : 0;
-  pl->fwd_dir = g.DD > 0 ? take(g.pass_N[0], g.KD) : 0;
+  pl->fwd_dir = g.KD > 0 ? take(g.pass_N[0], g.KD) : 0;
   for (int l = 0; l < g.L; ++l) pl->bwd_trunk[l] = l >= 1 ? take(g.F, g.F) : 0;
   pl->bwd_feats = g.fold ? 0 : take(g.F, g.F);
   for (int p = 0; p < g.n_pass; ++p) pl->bwd_head[p] = take(g.F, g.pass_N[p]);
@@ -134,9 +150,9 @@ struct StashLayout {
   size_t sraw;                    // fp32 [Mpad]  pre-softplus sigma
   size_t nraw;                    // fp32 [Mpad][4] learned-normal pre-normalisation vector
   size_t dpre_trunk;              // fp32 [Mpad][4]  (d sigma_raw, d normal_raw xyz)      (bwd-produced)
-  size_t dpre_head;               // fp32 [Mpad][12] (per head, 3 each)                   (bwd-produced)
+  size_t dpre_head;               // fp32 [Mpad][BN_DPH] (per head, 3 each)                   (bwd-produced)
   size_t pe;                      // T [Mpad][KP]
-  size_t dirpe;                   // T [Mpad][KD]  encoded view direction (input_viewdir only)
+  size_t dirpe;                   // T [Mpad][KD]  extra-input tile rows: encoded view direction, image embedding (FieldGeom.KD)
   size_t Y[BN_MAX_LAYERS];        // T [Mpad][F]  output of trunk layer l
   size_t D[BN_MAX_LAYERS];        // T native     d act / d z of trunk layer l
   size_t feats;                   // T [Mpad][F]
@@ -167,9 +183,9 @@ static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, in
   s->sraw = take((size_t)Mpad * 4);
   s->nraw = take((size_t)Mpad * 16);
   s->dpre_trunk = take((size_t)Mpad * 16);
-  s->dpre_head = take((size_t)Mpad * 48);
+  s->dpre_head = take((size_t)Mpad * BN_DPH * 4);
   s->pe = take((size_t)Mpad * g.KP * esz);
-  s->dirpe = g.DD > 0 ? take((size_t)Mpad * g.KD * esz) : 0;
+  s->dirpe = g.KD > 0 ? take((size_t)Mpad * g.KD * esz) : 0;
   for (int l = 0; l < g.L; ++l) s->Y[l] = take((size_t)Mpad * g.F * esz);
   for (int l = 0; l < g.L; ++l) s->D[l] = take((size_t)Mpad * g.F * esz);
   s->feats = take((size_t)Mpad * g.F * esz);

@@ -29,9 +29,9 @@ struct BwdArgs {
   const float *amax;   // fp16 mode: [0] max |d pre-activation|, [1] max |gbar_PE|, [2] max |zbar_l| (loss scaling, common.h); else nullptr
 };
 
-// sigmoid output y and dL/dy of head `hd`, channel c, recovered from the forward's rescaled output.
+// sigmoid (BN_HEAD_BETA: softplus) output y and dL/dy of head `hd`, channel c, recovered from the forward's rescaled output.
 __device__ __forceinline__ void head_y_dy(int kind, int nout, const float *o, const float *dgo, int c, float &y, float &dy) {
-  if (kind == BN_HEAD_PLAIN) { y = o[c]; dy = dgo[c]; }
+  if (kind == BN_HEAD_PLAIN || kind == BN_HEAD_BETA) { y = o[c]; dy = dgo[c]; }
   else if (kind == BN_HEAD_HAPKE_THETA) { y = o[0] * (1.f / 0.52359877559829887f); dy = dgo[0] * 0.52359877559829887f; }
   else {
     const float ov = nout == 1 ? o[0] : o[c];
@@ -44,10 +44,10 @@ __device__ __forceinline__ void head_y_dy(int kind, int nout, const float *o, co
 
 // d L / d (pre-activation) of the small outputs of point gm: the <= 3 pre-sigmoid values of every head, sigma_raw and
 // the learned-normal vector (shared by the chain kernel's prologue and the fp16 loss-scale reduction).
-__device__ __forceinline__ void bwd_dpre(const BwdArgs &A, int64_t gm, float (&dph)[12], float (&dpt)[4]) {
+__device__ __forceinline__ void bwd_dpre(const BwdArgs &A, int64_t gm, float (&dph)[BN_DPH], float (&dpt)[4]) {
   const FieldGeom &g = A.g;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) dph[i] = 0.f;
+  for (int i = 0; i < BN_DPH; ++i) dph[i] = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) dpt[i] = 0.f;
   if (gm >= A.M) return;
@@ -57,7 +57,8 @@ __device__ __forceinline__ void bwd_dpre(const BwdArgs &A, int64_t gm, float (&d
     for (int c = 0; c < nout; ++c) {
       float y, dy;
       head_y_dy(kind, nout, o + g.head_col[hd], dgo + g.head_col[hd], c, y, dy);
-      dph[hd * 3 + c] = dy * y * (1.f - y);
+      // d sigmoid = y (1 - y);  d softplus(x) = sigmoid(x) = 1 - exp(-softplus(x))
+      dph[hd * 3 + c] = kind == BN_HEAD_BETA ? dy * -expm1f(-y) : dy * y * (1.f - y);
     }
   }
   const float sraw = ((const float *)(A.stash + A.sl.sraw))[gm];
@@ -85,10 +86,10 @@ template <int WHICH> __global__ __launch_bounds__(256) void grad_amax_kernel(con
   float mx = 0.f;
   for (int64_t gm = (int64_t)blockIdx.x * 256 + threadIdx.x; gm < A.M; gm += (int64_t)gridDim.x * 256) {
     if (WHICH == 0) {
-      float dph[12], dpt[4];
+      float dph[BN_DPH], dpt[4];
       bwd_dpre(A, gm, dph, dpt);
 #pragma unroll
-      for (int i = 0; i < 12; ++i) { const float a = fabsf(dph[i]); mx = (a < 3.0e38f && a > mx) ? a : mx; }
+      for (int i = 0; i < BN_DPH; ++i) { const float a = fabsf(dph[i]); mx = (a < 3.0e38f && a > mx) ? a : mx; }
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const float a = fabsf(dpt[i]); mx = (a < 3.0e38f && a > mx) ? a : mx; }
     } else {
@@ -108,6 +109,40 @@ template <int WHICH> __global__ __launch_bounds__(256) void grad_amax_kernel(con
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax((unsigned int *)amax + WHICH, __float_as_uint(mx));
+}
+
+// --beta: d loss / d t_embed of every point = dG_beta[m][:] W_t  (W_t = beta_from_xyz.0.weight[:, F:], [H2][TD] fp32).
+// One wave per point over the H2 hidden columns of head 1 inside pass 0's dG rows; HBM-bound on M x H2 elements.
+template <typename T>
+__global__ __launch_bounds__(256) void head_xin_grad_kernel(const T *__restrict__ dG, int ldg, int col0, int H2, const float *__restrict__ Wt,
+                                                            int64_t ldw, int TD, int64_t M, const float *amax, float *__restrict__ d_t) {
+  __shared__ float W[256 * 16];
+  for (int i = threadIdx.x; i < H2 * 16; i += 256) W[i] = (i & 15) < TD ? Wt[(int64_t)(i >> 4) * ldw + (i & 15)] : 0.f;
+  __syncthreads();
+  const float osc = 1.f / chain_scale(amax);           // fp16 loss scaling carried by dG (1 in the other modes)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t gm = (int64_t)blockIdx.x * 4 + wave; gm < M; gm += (int64_t)gridDim.x * 4) {
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    const T *row = dG + gm * ldg + col0;
+    for (int j = lane; j < H2; j += 64) {
+      const float d = (float)row[j];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc[c] += d * W[j * 16 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+    }
+    if (lane < TD) {
+      float v = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) v = lane == c ? acc[c] : v;
+      d_t[gm * TD + lane] = v * osc;
+    }
+  }
 }
 
 template <typename T, int MT, int NTW>
@@ -139,7 +174,7 @@ __device__ __forceinline__ void bwd_head_dG(const BwdArgs &A, int p, T *ACT, con
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m = mt * 32 + r;
-        const float d0 = DPH[m * 12 + hd * 3 + 0], d1 = DPH[m * 12 + hd * 3 + 1], d2 = DPH[m * 12 + hd * 3 + 2];
+        const float d0 = DPH[m * BN_DPH + hd * 3 + 0], d1 = DPH[m * BN_DPH + hd * 3 + 1], d2 = DPH[m * BN_DPH + hd * 3 + 2];
         float dg[8];
         ld8(DGs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), dg);
         float va[4], vb[4];
@@ -162,8 +197,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   const FieldGeom &g = A.g;
   const int F = g.F, LDA = F + Elem<T>::kPad, KSF = F / 16;
   T *ACT = (T *)smem;
-  float *DPH = (float *)(ACT + (size_t)BM * LDA);  // [BM][12] head pre-sigmoid gradients
-  float *DPT = DPH + BM * 12;                        // [BM][4]  (d sigma_raw, d normal_raw)
+  float *DPH = (float *)(ACT + (size_t)BM * LDA);  // [BM][BN_DPH] head pre-sigmoid gradients
+  float *DPT = DPH + BM * BN_DPH;                        // [BM][4]  (d sigma_raw, d normal_raw)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.M;
@@ -179,12 +214,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   if (tid < BM) {
     const int m = tid;
     const int64_t gm = m0 + m;
-    float dph[12], dpt[4];
+    float dph[BN_DPH], dpt[4];
     bwd_dpre(A, gm, dph, dpt);
-    float *sh = (float *)(A.stash + A.sl.dpre_head) + gm * 12;
+    float *sh = (float *)(A.stash + A.sl.dpre_head) + gm * BN_DPH;
     float *st = (float *)(A.stash + A.sl.dpre_trunk) + gm * 4;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { DPH[m * 12 + i] = dph[i] * gs; sh[i] = dph[i]; }
+    for (int i = 0; i < BN_DPH; ++i) { DPH[m * BN_DPH + i] = dph[i] * gs; sh[i] = dph[i]; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { DPT[m * 4 + i] = dpt[i] * gs; st[i] = dpt[i]; }
   }
@@ -357,7 +392,7 @@ __device__ __forceinline__ float wg_unscale(const float *amax, int sel) {
   if (amax == nullptr || sel == 0) return 1.f;
   return 1.f / (sel == 1 ? chain_scale(amax) : grad_scale_from(amax + 1, BN_GS_TARGET_ADJ));
 }
-#define BN_MAX_WGRAD_JOBS 40
+#define BN_MAX_WGRAD_JOBS 44
 struct WgradArgs {
   WgradJob job[BN_MAX_WGRAD_JOBS];
   int tile0[BN_MAX_WGRAD_JOBS + 1];  // prefix sum of 128x128 output tiles per job
@@ -749,7 +784,7 @@ struct SkinnyJob {
   int scale_sel;       // fp16 loss scaling carried by X (see WgradJob.scale_sel; the fp32 dpre columns are never scaled)
   int unit_dpre;       // 1: dpre == 1 for every point (column sums of X)
 };
-#define BN_MAX_SKINNY_JOBS 8
+#define BN_MAX_SKINNY_JOBS 10
 struct SkinnyArgs {
   SkinnyJob job[BN_MAX_SKINNY_JOBS];
   int n_jobs;
@@ -877,7 +912,7 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
 
 template <typename T, int MT, int NT, int WAVES> static int launch_bwd(const BwdArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
-  const size_t lds = (size_t)BM * (a.g.F + Elem<T>::kPad) * sizeof(T) + (size_t)BM * 16 * sizeof(float);
+  const size_t lds = (size_t)BM * (a.g.F + Elem<T>::kPad) * sizeof(T) + (size_t)BM * (BN_DPH + 4) * sizeof(float);
   if (int e = bn_configure_lds((const void *)field_bwd_kernel<T, MT, NT, WAVES>, lds, "field_bwd")) return e;
   BnProfScope prof_(BN_K_BWD_CHAIN, st);
   field_bwd_kernel<T, MT, NT, WAVES><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
@@ -981,6 +1016,10 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     b_native = 0; scale_sel = 1;
     add(S + sl.dG[0], g.pass_N[0], 0, S + sl.dirpe, g.KD, 0, G->head0_wdir, (int)G->head0_wdir_ld, nullptr, g.H2, g.DD);
   }
+  if (g.TD > 0 && G->head1_wt) {     // d/d beta_from_xyz.0.weight[:, F:] = dG_beta^T [image embedding]
+    b_native = 0; scale_sel = 1;
+    add(S + sl.dG[0], g.pass_N[0], g.H2, S + sl.dirpe, g.KD, g.KT0, G->head1_wt, (int)G->head1_wt_ld, nullptr, g.H2, g.TD);
+  }
   BN_REQUIRE(w.n_jobs <= BN_MAX_WGRAD_JOBS, "field_backward: too many wgrad jobs");
   if (bf && w.n_jobs > 0) {
     // 256 x 256 tiles, one 8-wave workgroup per CU: size the point splits for ~4 workgroups per CU in total
@@ -1050,7 +1089,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     SkinnyJob &j = s.job[s.n_jobs++];
     j.X = S + sl.G[p]; j.ldx = 0; j.x_col0 = hl * g.H2; j.K = g.H2;
     j.native = 1; j.bm = BM; j.ntw = g.pass_NTW[p]; j.tstride = BM * F;
-    j.dpre = (const float *)(S + sl.dpre_head); j.ldp = 12; j.p_col0 = hd * 3; j.nc = desc->head_out[hd];
+    j.dpre = (const float *)(S + sl.dpre_head); j.ldp = BN_DPH; j.p_col0 = hd * 3; j.nc = desc->head_out[hd];
     for (int c = 0; c < 4; ++c) { j.out[c] = nullptr; j.bias[c] = nullptr; }
     for (int c = 0; c < j.nc; ++c) { j.out[c] = G->head_w2[hd] + (size_t)c * g.H2; j.bias[c] = G->head_b2[hd] ? G->head_b2[hd] + c : nullptr; }
   }
@@ -1066,6 +1105,16 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     else if (bf) skinny_wgrad_kernel<bf16><<<grid, 256, 0, st>>>(s);
     else skinny_wgrad_kernel<float><<<grid, 256, 0, st>>>(s);
     BN_LAUNCH_CHECK("skinny_wgrad");
+  }
+  if (g.TD > 0 && G->d_t_embed) {   // gradient of the beta head's embedding input, per point
+    BN_REQUIRE(params->head1_wt && params->head1_wt_ld >= g.TD && g.H2 <= 256, "field_backward: head1_wt missing (beta)");
+    const int64_t M = pts->n_points;
+    const unsigned blocks = (unsigned)(ceil_div64(M, 4) < 4096 ? ceil_div64(M, 4) : 4096);
+    const int ldg = g.pass_N[0];
+    if (f16m) head_xin_grad_kernel<f16><<<dim3(blocks), 256, 0, st>>>((const f16 *)(S + sl.dG[0]), ldg, g.H2, g.H2, params->head1_wt, params->head1_wt_ld, g.TD, M, amax, G->d_t_embed);
+    else if (bf) head_xin_grad_kernel<bf16><<<dim3(blocks), 256, 0, st>>>((const bf16 *)(S + sl.dG[0]), ldg, g.H2, g.H2, params->head1_wt, params->head1_wt_ld, g.TD, M, amax, G->d_t_embed);
+    else head_xin_grad_kernel<float><<<dim3(blocks), 256, 0, st>>>((const float *)(S + sl.dG[0]), ldg, g.H2, g.H2, params->head1_wt, params->head1_wt_ld, g.TD, M, amax, G->d_t_embed);
+    BN_LAUNCH_CHECK("head_xin_grad");
   }
   return 0;
 }

@@ -48,8 +48,8 @@ template <bool FAST> __device__ __forceinline__ float act_prescale(int act, floa
   return (FAST && act == BN_ACT_SIN) ? w0 * BN_INV_2PI : 1.f;
 }
 
-// --input_viewdir: one row of the direction tile = mapping[1](view direction of the point) (spsbrdfnerf.py:689-692), zero
-// beyond its valid width.
+// One row of the extra-input tile (FieldGeom.KD columns): mapping[1](view direction of the point) for --input_viewdir
+// (spsbrdfnerf.py:689-692), then the image embedding for --beta, zero elsewhere.
 template <typename T>
 __device__ __forceinline__ void fill_dir_row(const FwdArgs &A, int64_t gm, T *row) {
   constexpr bool FAST = Elem<T>::kFastMath;
@@ -63,21 +63,28 @@ __device__ __forceinline__ void fill_dir_row(const FwdArgs &A, int64_t gm, T *ro
       dv[0] = rr[3]; dv[1] = rr[4]; dv[2] = rr[5];
     }
   }
-  if (g.dir_freqs > 0) {
-    for (int k = 0; k < g.dir_freqs; ++k) {
-      const float f = (float)(1 << k);
+  if (g.DD > 0) {
+    if (g.dir_freqs > 0) {
+      for (int k = 0; k < g.dir_freqs; ++k) {
+        const float f = (float)(1 << k);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float sn, co;
-        sincos_t<FAST>(f * dv[c], sn, co);
-        row[6 * k + c] = (T)sn;
-        row[6 * k + 3 + c] = (T)co;
+        for (int c = 0; c < 3; ++c) {
+          float sn, co;
+          sincos_t<FAST>(f * dv[c], sn, co);
+          row[6 * k + c] = (T)sn;
+          row[6 * k + 3 + c] = (T)co;
+        }
       }
+    } else {
+      for (int k = 0; k < 3; ++k) row[k] = (T)dv[k];
     }
-    for (int k = g.DD; k < g.KD; ++k) row[k] = (T)0.f;
-  } else {
-    for (int k = 0; k < g.KD; ++k) row[k] = (T)(k < 3 ? dv[k] : 0.f);
   }
+  for (int k = g.DD; k < g.KT0; ++k) row[k] = (T)0.f;
+  // --beta: the per-image embedding of the point's ray, raw (spsbrdfnerf.py:709)
+  const float *te = nullptr;
+  if (g.TD > 0 && gm < A.pts.n_points && A.pts.t_embed)
+    te = A.pts.t_embed + (A.pts.xyz ? gm : gm / A.pts.n_samples) * g.TD;
+  for (int k = g.KT0; k < g.KD; ++k) row[k] = (T)((te && k - g.KT0 < g.TD) ? te[k - g.KT0] : 0.f);
 }
 
 // One pass over up to two heads: hidden = act(W1 feats + b1) kept in registers, second layer (<= 3 outputs)
@@ -111,8 +118,8 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
   }
   // --input_viewdir: the encoded view direction of every point, an extra K segment of the rgb head's first layer (like the
   // positional-encoding segment of the skip layer).  The tile lives behind the staged parameters in the (free) encoding buffer.
-  // DIR is a template parameter: compiled into the one kernel, the segment costs the hot head pass registers (2 - 3 % of the
-  // forward with no direction input at all: profiles/r02_ablation.txt)
+  // DIR (= the model has extra inputs, KD > 0) is a template parameter: compiled into the one kernel, the segment costs the hot
+  // head pass registers (2 - 3 % of the forward with no extra input at all: profiles/r02_ablation.txt)
   const bool dir_on = DIR && p == 0;
   T *DIRT = (T *)((char *)PRM + 8192);
   const int LDD = g.KD + Elem<T>::kPad;
@@ -197,11 +204,11 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
     for (int c = 0; c < 3; ++c) {
       float s = 0.f;
       for (int w = hl2 * wph; w < (hl2 + 1) * wph; ++w) s += RED[(w * 3 + c) * BM + m];
-      v[c] = c < nout ? sigmoid_f(s + A.p.head_b2[hd2][c]) : 0.f;
+      v[c] = c < nout ? (kind == BN_HEAD_BETA ? softplus_f(s + A.p.head_b2[hd2][c]) : sigmoid_f(s + A.p.head_b2[hd2][c])) : 0.f;
     }
     if (gm < M) {
       float *o = A.out + gm * g.C + g.head_col[hd2];
-      if (kind == BN_HEAD_PLAIN) {
+      if (kind == BN_HEAD_PLAIN || kind == BN_HEAD_BETA) {
         for (int c = 0; c < nout; ++c) o[c] = v[c];
       } else if (kind == BN_HEAD_HAPKE_THETA) {
         o[0] = v[0] * 0.52359877559829887f;  // pi*30/180
@@ -599,7 +606,9 @@ struct PackJob {
   int row_off, col_off;  // offsets into src (in the packed matrix's own row/col sense)
   int transposed;    // 1: packed[row][k] = src[k - k_lo + col_off][row + row_off]
   int k_lo;          // first packed k this job owns
-  int masked;        // 1: touch only k in [k_lo, k_lo+K) (several jobs fill one packed matrix)
+  int masked;        // 1: touch only k in [k_lo, k_lo+K_touch) (several jobs fill one packed matrix)
+  int K_touch;       // masked jobs: width of the k range this job owns (>= K; the part beyond K is zero-filled)
+  int row_lo;        // first PACKED row that holds src data (rows below it are zero-filled like rows >= row_lo + rows)
   float scale;       // multiplies every element (w0/(2 pi) for the forward Siren matrices in bf16 mode)
 };
 #define BN_MAX_PACK_JOBS 48
@@ -620,11 +629,12 @@ template <typename T> __global__ void pack_kernel(const PackArgs A) {
     const int ks = blk % KS, rt = blk / KS;
     const int row = rt * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + e;
     const int kk = k - j.k_lo;
-    if (j.masked && (kk < 0 || kk >= j.K)) continue;
+    if (j.masked && (kk < 0 || kk >= j.K_touch)) continue;
     float v = 0.f;
-    if (row < j.rows && kk >= 0 && kk < j.K)
-      v = j.transposed ? j.src[(size_t)(kk + j.col_off) * j.ld + row + j.row_off]
-                       : j.src[(size_t)(row + j.row_off) * j.ld + kk + j.col_off];
+    const int rr = row - j.row_lo;
+    if (rr >= 0 && rr < j.rows && kk >= 0 && kk < j.K)
+      v = j.transposed ? j.src[(size_t)(kk + j.col_off) * j.ld + rr + j.row_off]
+                       : j.src[(size_t)(rr + j.row_off) * j.ld + kk + j.col_off];
     dst[i] = (T)(v * j.scale);
   }
 }
@@ -660,6 +670,7 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
     j.src = src; j.dst = dst; j.ld = ld; j.rows = rows; j.K = K;
     j.rows_pad = (int)bn_pad(rows, 32); j.K_pad = (int)bn_pad(K, 16);
     j.row_off = row_off; j.col_off = col_off; j.transposed = tr; j.k_lo = 0; j.masked = 0; j.scale = 1.f;
+    j.K_touch = K; j.row_lo = 0;
   };
   // bf16 Siren: forward matrices carry w0/(2 pi) so the epilogue feeds v_sin/v_cos directly (see act_eval)
   const bool prescale = bn_half(desc->dtype) && desc->act == BN_ACT_SIN;
@@ -715,12 +726,21 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
       add(P->head_w1[hd], pl.fwd_head[p] + (size_t)hl * g.H2 * F, F, g.H2, F, 0, 0, 0);
       fwd_scale(1, 1.f);
     }
-  if (g.DD > 0) {   // view-direction columns of the rgb head's first layer: rows of head 0 inside pass 0, the rest zero
-    BN_REQUIRE(P->head0_wdir && P->head0_wdir_ld >= g.DD, "pack: head0_wdir missing (input_viewdir)");
-    add(P->head0_wdir, pl.fwd_dir, (int)P->head0_wdir_ld, g.H2, g.DD, 0, 0, 0);
-    a.job[a.n_jobs - 1].rows_pad = g.pass_N[0];
-    a.job[a.n_jobs - 1].K_pad = g.KD;
+  // extra-input columns of pass 0's first layers, one [pass_N[0]][KD] block: k in [0, KT0) belongs to the view direction (rows
+  // of head 0 = the rgb head's direction columns, other rows zero), k in [KT0, KD) to the image embedding (rows of head 1 = the
+  // beta head's embedding columns, other rows zero)
+  auto xin = [&](const float *src, int64_t ld, int row_lo, int k_lo, int K, int K_touch) {
+    add(src, pl.fwd_dir, (int)ld, g.H2, K, 0, 0, 0);
+    PackJob &j = a.job[a.n_jobs - 1];
+    j.rows_pad = g.pass_N[0]; j.K_pad = g.KD; j.masked = 1; j.k_lo = k_lo; j.K_touch = K_touch; j.row_lo = row_lo;
+    if (!src) j.rows = 0;   // zero fill only
     fwd_scale(1, 1.f);
+  };
+  if (g.KD > 0) {
+    BN_REQUIRE(g.DD == 0 || (P->head0_wdir && P->head0_wdir_ld >= g.DD), "pack: head0_wdir missing (input_viewdir)");
+    BN_REQUIRE(g.TD == 0 || (P->head1_wt && P->head1_wt_ld >= g.TD), "pack: head1_wt missing (beta)");
+    if (g.KT0 > 0) xin(P->head0_wdir, P->head0_wdir_ld, 0, 0, g.DD, g.KT0);
+    xin(g.TD > 0 ? P->head1_wt : nullptr, P->head1_wt_ld, g.H2, g.KT0, g.TD, g.KD - g.KT0);
   }
   // transposed head-1 weights: packed[row j][k = column in pass] = W1_hd[k - hl*H2][j]; the heads of a pass
   // interleave along k, so each head fills its own k range of the shared packed matrix (masked job).
@@ -729,7 +749,7 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
       PackJob &j = a.job[a.n_jobs++];
       j.src = P->head_w1[2 * p + hl]; j.dst = pl.bwd_head[p]; j.ld = F; j.rows = F; j.K = g.H2;
       j.rows_pad = F; j.K_pad = g.pass_N[p]; j.row_off = 0; j.col_off = 0; j.transposed = 1;
-      j.k_lo = hl * g.H2; j.masked = 1; j.scale = 1.f;
+      j.k_lo = hl * g.H2; j.masked = 1; j.scale = 1.f; j.K_touch = j.K; j.row_lo = 0;
     }
   BN_REQUIRE(a.n_jobs <= BN_MAX_PACK_JOBS, "pack: too many jobs");
   dim3 grid(64, a.n_jobs);
@@ -743,7 +763,7 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
 
 template <typename T, int MT, int NT, int WAVES, bool KEEP, bool DIR> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st);
 template <typename T, int MT, int NT, int WAVES> static int launch_fwd(const FwdArgs &a, int64_t tiles, hipStream_t st) {
-  if (a.g.DD > 0 && !a.sigma_only)      // --input_viewdir: the variant with the direction segment in the rgb head
+  if (a.g.KD > 0 && !a.sigma_only)      // --input_viewdir / --beta: the variant with the extra-input segment in pass 0
     return a.stash ? launch_fwd_k<T, MT, NT, WAVES, true, true>(a, tiles, st) : launch_fwd_k<T, MT, NT, WAVES, false, true>(a, tiles, st);
   return a.stash ? launch_fwd_k<T, MT, NT, WAVES, true, false>(a, tiles, st) : launch_fwd_k<T, MT, NT, WAVES, false, false>(a, tiles, st);
 }
@@ -792,6 +812,7 @@ int bn_field_forward_impl(const bn_field_desc *desc, const bn_field_params *para
   BN_REQUIRE(pts && pts->n_points > 0 && (pts->xyz || (pts->rays && pts->z && pts->n_samples > 0)), "field: bad points");
   BN_REQUIRE(!desc->dir_dim || sigma_only || !pts->xyz || pts->dirs, "field: input_viewdir needs pts.dirs with the xyz point form");
   BN_REQUIRE(!desc->dir_dim || pts->xyz || pts->ray_stride >= 6, "field: input_viewdir needs rays with directions");
+  BN_REQUIRE(!desc->t_dim || sigma_only || pts->t_embed, "field: the beta head needs pts.t_embed");
   BN_REQUIRE(packed && out, "field: null buffer");
   a.d = *desc; a.p = *params; a.packed = packed; a.pts = *pts; a.out = out; a.stash = (char *)stash;
   a.sigma_only = sigma_only;

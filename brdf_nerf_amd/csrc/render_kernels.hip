@@ -53,7 +53,7 @@ extern "C" int bn_stratified_z(const float *near, const float *far, int64_t nf_s
 // Lane i of the ray's wave owns samples [i*c, (i+1)*c), c = ceil(S/64) <= BN_MAX_C: the exclusive prefix product
 // of (1 - alpha + 1e-10) is a per-lane serial product + a 6-step wavefront shuffle scan.
 #define BN_MAX_CPL 8   // samples per lane -> S <= 512
-#define BN_MAX_CH 16
+#define BN_MAX_CH 32   // rgb3 + sigma + beta + two normals + three 3-wide BRDF heads = 20 at most today
 
 struct CompArgs {
   const float *z, *sigma, *noise, *chan;
@@ -146,11 +146,13 @@ template <int LG, bool VEC> __device__ __forceinline__ void comp_flat_bwd_store(
     if (A.flat_vec) {                                                             \
       if (A.flat_lg == 0) FN<0, true>(__VA_ARGS__);                               \
       else if (A.flat_lg == 1) FN<1, true>(__VA_ARGS__);                          \
-      else FN<2, true>(__VA_ARGS__);                                              \
+      else if (A.flat_lg == 2) FN<2, true>(__VA_ARGS__);                          \
+      else FN<3, true>(__VA_ARGS__);                                              \
     } else {                                                                      \
       if (A.flat_lg == 0) FN<0, false>(__VA_ARGS__);                              \
       else if (A.flat_lg == 1) FN<1, false>(__VA_ARGS__);                         \
-      else FN<2, false>(__VA_ARGS__);                                             \
+      else if (A.flat_lg == 2) FN<2, false>(__VA_ARGS__);                         \
+      else FN<3, false>(__VA_ARGS__);                                             \
     }                                                                             \
   } while (0)
 __device__ __forceinline__ void lds_wave_sync() {   // LDS hand-over inside one wave: its DS operations execute in order
@@ -267,9 +269,6 @@ template <bool BWD> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void comp
       BN_COMP_FLAT(comp_flat_bwd_dot, A, ray, lane, gs);
       lds_wave_sync();
     }
-    float dacc[BN_MAX_CH];
-#pragma unroll
-    for (int c = 0; c < BN_MAX_CH; ++c) dacc[c] = (!flat && A.d_acc && c < A.C) ? A.d_acc[ray * A.C + c] : 0.f;
     float g[BN_MAX_CPL], gw = 0.f;
 #pragma unroll
     for (int j = 0; j < BN_MAX_CPL; ++j) {
@@ -282,12 +281,11 @@ template <bool BWD> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void comp
         else if (A.chan && A.d_acc) {
           const float *ch = A.chan + (ray * S + s) * A.chan_stride;
           float *dch = A.d_chan ? A.d_chan + (ray * S + s) * A.d_chan_stride : nullptr;
-#pragma unroll
-          for (int c = 0; c < BN_MAX_CH; ++c)
-            if (c < A.C) {
-              gg += dacc[c] * ch[c];
-              if (dch) dch[c] = w[j] * dacc[c];
-            }
+          for (int c = 0; c < A.C; ++c) {          // (generic strided rows only: the dense layout takes the flat path)
+            const float dc = A.d_acc[ray * A.C + c];
+            gg += dc * ch[c];
+            if (dch) dch[c] = w[j] * dc;
+          }
         }
         g[j] = gg;
         gw += gg * w[j];
@@ -311,11 +309,11 @@ template <bool BWD> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void comp
   }
 }
 
-// flat channel path: dense rows (any C <= 16); float4 groups when C % 4 == 0 and every block is 16-byte aligned
+// flat channel path: dense rows (any C <= 32); float4 groups when C % 4 == 0 and every block is 16-byte aligned
 static void comp_flat_config(CompArgs &a, const float *chan, int64_t chan_stride, int C, const void *p1, const void *p2) {
   a.flat_lg = -1; a.flat_vec = 0;
   if (!chan || chan_stride != C || C < 1) return;
-  a.flat_lg = C <= 4 ? 0 : (C <= 8 ? 1 : 2);
+  a.flat_lg = C <= 4 ? 0 : (C <= 8 ? 1 : (C <= 16 ? 2 : 3));
   a.flat_vec = (C % 4 == 0 && ((uintptr_t)chan | (uintptr_t)p1 | (uintptr_t)p2) % 16 == 0) ? 1 : 0;
 }
 

@@ -48,8 +48,6 @@ class SpSBRDFNeRF(nn.Module):
                  t_embedding_dims=16, beta=True, roughness=True, normal="none", sun_v="none", indirect_light=False,
                  glossy_scale=1.0, MultiBRDF=False, dim_RPV=3, compute_dtype="fp32"):
         super().__init__()
-        if beta:
-            raise NotImplementedError(_UNSUPPORTED + "--beta (transient embedding; reference README recommends it off)")
         if sun_v not in ("none", "analystic"):      # 'analystic' adds no parameters: the sun pass lives in render_rays
             raise NotImplementedError(_UNSUPPORTED + f"--sun_v {sun_v} (reference quirk 3: NameError upstream)")
         if indirect_light:
@@ -67,8 +65,8 @@ class SpSBRDFNeRF(nn.Module):
         self.pe_freqs = mapping_sizes[0] if mapping else 0
         self.compute_dtype = compute_dtype
 
-        self.number_of_outputs = 4
-        self.number_of_outputs_brdf = 4
+        self.number_of_outputs = 5 if beta else 4                      # + beta (spsbrdfnerf.py:476-477)
+        self.number_of_outputs_brdf = self.number_of_outputs
         if roughness:
             self.number_of_outputs_brdf += 1
         elif self.RPV:
@@ -97,6 +95,9 @@ class SpSBRDFNeRF(nn.Module):
         if siren:
             self.fc_net.apply(_sine_init)
             self.fc_net[0].apply(_first_layer_sine_init)
+        if beta:        # transient scalar on cat([xyz_features, t embedding]) (spsbrdfnerf.py:571-575); registered before grad_from_xyz
+            self.beta_from_xyz = nn.Sequential(nn.Linear(t_embedding_dims + feat, feat // 2), nl, nn.Linear(feat // 2, 1),
+                                               nn.Softplus())
         if normal in ("analystic_learned", "learned"):
             self.grad_from_xyz = nn.Linear(feat, 3)
         if roughness:
@@ -145,8 +146,11 @@ class SpSBRDFNeRF(nn.Module):
         return None
 
     # ------------------------------------------------------------------ HIP plumbing
-    def head_list(self, apply_brdf, apply_theta):
+    def head_list(self, apply_brdf, apply_theta, beta=None):
         heads = [("rgb_from_xyzdir", 3, L.BN_HEAD_PLAIN)]
+        if self.beta if beta is None else beta:
+            # always evaluated by the full forward, BRDF or not (spsbrdfnerf.py:708-711); head 1 by the ABI's rule
+            heads.append(("beta_from_xyz", 1, L.BN_HEAD_BETA))
         a = self.args
         if apply_brdf:
             if self.roughness:
@@ -167,17 +171,22 @@ class SpSBRDFNeRF(nn.Module):
                     heads.append(("theta_from_xyz", 1, L.BN_HEAD_HAPKE_THETA))
         return heads
 
-    def spec(self, apply_brdf=False, apply_theta=False, nr_lr_on=False, nr_an_on=False):
+    def spec(self, apply_brdf=False, apply_theta=False, nr_lr_on=False, nr_an_on=False, beta=None):
+        """beta=False leaves the --beta head (and its output channel) out: the fused training step does that, because the
+        reference's loss for this model never reads beta_coarse (load_loss -> SNerfLoss, metrics.py:172-173; main.py:237-245),
+        so the head's parameters receive no gradient upstream either."""
+        beta = bool(self.beta if beta is None else (beta and self.beta))
         if self.compute_dtype not in L.DTYPES:
             raise ValueError(f"compute_dtype {self.compute_dtype!r}: expected one of {sorted(L.DTYPES)}")
         dtype = L.DTYPES[self.compute_dtype]
-        key = (bool(apply_brdf), bool(apply_theta), bool(nr_lr_on), bool(nr_an_on), dtype)
+        key = (bool(apply_brdf), bool(apply_theta), bool(nr_lr_on), bool(nr_an_on), dtype, beta)
         if key not in self._specs:
             skip = self.skips[0] if self.skips and 0 < self.skips[0] < self.layers else -1   # --fc_layers <= 4: no skip layer
             self._specs[key] = Fn.FieldSpec(self.feat, self.layers, skip, self.pe_freqs,
                                             L.BN_ACT_SIN if self.siren_on else L.BN_ACT_RELU, dtype,
-                                            self.head_list(apply_brdf, apply_theta), nr_lr_on, nr_an_on,
-                                            dir_dim=self.dir_dim, dir_freqs=self.dir_freqs)
+                                            self.head_list(apply_brdf, apply_theta, beta), nr_lr_on, nr_an_on,
+                                            dir_dim=self.dir_dim, dir_freqs=self.dir_freqs,
+                                            t_dim=self.t_embedding_dims if beta else 0)
         return self._specs[key]
 
     def named(self):
@@ -195,7 +204,7 @@ class SpSBRDFNeRF(nn.Module):
 
     def forward(self, input_xyz_, input_dir=None, input_sun_dir=None, input_t=None, sigma_only=False, apply_brdf=False,
                 apply_theta=False, nr_an_on=False, nr_lr_on=False, sun_ray=False, mode="train"):
-        """(B,3) points -> (B,C) [rgb3, sigma, (normal_lr3), BRDF head outputs], or (B,1) sigma."""
+        """(B,3) points -> (B,C) [rgb3, sigma, (beta), (normal_an3), (normal_lr3), BRDF head outputs], or (B,1) sigma."""
         spec = self.spec(apply_brdf, apply_theta, nr_lr_on, nr_an_on and not sigma_only)
         packed = self.repack(spec)
         xyz = input_xyz_.detach().float().contiguous()
@@ -206,12 +215,16 @@ class SpSBRDFNeRF(nn.Module):
             if input_dir is None:
                 raise ValueError("--input_viewdir: forward() needs input_dir (B,3)")
             dirs = input_dir.detach().float().contiguous()
-        return self.evaluate(spec, packed, xyz=xyz, dirs=dirs)
+        if self.beta and input_t is None:
+            raise ValueError("--beta: forward() needs input_t (B, t_embedding_dims)")
+        return self.evaluate(spec, packed, xyz=xyz, dirs=dirs, t_embed=input_t if self.beta else None)
 
-    def evaluate(self, spec, packed, xyz=None, rays=None, z=None, dirs=None):
+    def evaluate(self, spec, packed, xyz=None, rays=None, z=None, dirs=None, t_embed=None):
+        """t_embed: the --beta image embedding, per point with `xyz`, per ray with `rays` (differentiable)."""
         names = spec.used_param_names()
         named = self.named()
-        return Fn.FieldFunction.apply(spec, packed, xyz, rays, z, (names, torch.is_grad_enabled(), dirs), *[named[n] for n in names])
+        return Fn.FieldFunction.apply(spec, packed, xyz, rays, z, t_embed, (names, torch.is_grad_enabled(), dirs),
+                                      *[named[n] for n in names])
 
 
 def load_model(args, compute_dtype=None):

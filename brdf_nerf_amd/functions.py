@@ -31,7 +31,7 @@ class FieldSpec:
     """Host-side description of one evaluation of the field: which heads, which dtype."""
 
     def __init__(self, feat, layers, skip, pe_freqs, act, dtype, heads, normal_lr, normal_an=False, fold_feats=None,
-                 dir_dim=0, dir_freqs=0):
+                 dir_dim=0, dir_freqs=0, t_dim=0):
         # heads: list of (name, n_out, kind); heads[0] must be ("rgb_from_xyzdir", 3, PLAIN)
         self.feat, self.layers, self.skip, self.pe_freqs, self.act, self.dtype = feat, layers, skip, pe_freqs, act, dtype
         self.heads, self.normal_lr, self.normal_an = list(heads), bool(normal_lr), bool(normal_an)
@@ -46,37 +46,47 @@ class FieldSpec:
         self.dir_dim, self.dir_freqs = int(dir_dim), int(dir_freqs)
         if self.dir_dim and not self.fold_feats:
             raise NotImplementedError("--input_viewdir needs the folded feats layer (BRDFNERF_FOLD_FEATS=1, the default)")
+        # --beta: head 1 (kind BN_HEAD_BETA) also reads the per-image embedding, t_dim extra input columns
+        self.t_dim = int(t_dim)
+        if (self.t_dim > 0) != (len(self.heads) > 1 and self.heads[1][2] == L.BN_HEAD_BETA):
+            raise ValueError("t_dim goes with a beta head at index 1")
+        if self.t_dim and not self.fold_feats:
+            raise NotImplementedError("--beta needs the folded feats layer (BRDFNERF_FOLD_FEATS=1, the default)")
         self.folded, self.fold_grads = {}, {}
         d = L.FieldDesc()
         d.feat, d.layers, d.skip, d.pe_freqs, d.act, d.dtype = feat, layers, skip, pe_freqs, act, dtype
         d.fold_feats = int(self.fold_feats)
-        d.dir_dim, d.dir_freqs = self.dir_dim, self.dir_freqs
+        d.dir_dim, d.dir_freqs, d.t_dim = self.dir_dim, self.dir_freqs, self.t_dim
         d.n_heads = len(self.heads)
-        c = 4 + (3 if normal_an else 0) + (3 if normal_lr else 0)
+        c0 = 5 if self.t_dim else 4                     # [rgb3, sigma, (beta)]
+        c = c0 + (3 if normal_an else 0) + (3 if normal_lr else 0)
         self.head_cols = []
         for i, (_, n_out, kind) in enumerate(self.heads):
             d.head_out[i], d.head_kind[i] = n_out, kind
             if i == 0:
                 self.head_cols.append((0, 3))
+            elif kind == L.BN_HEAD_BETA:
+                self.head_cols.append((4, 1))
             else:
                 w = n_out if kind in (L.BN_HEAD_PLAIN, L.BN_HEAD_HAPKE_THETA) else 3
                 self.head_cols.append((c, w))
                 c += w
         d.normal_lr, d.normal_an, d.out_channels = int(normal_lr), int(normal_an), c
         self.desc, self.out_channels = d, c
-        self.ch_normal_an = 4 if normal_an else -1
-        self.ch_normal_lr = (7 if normal_an else 4) if normal_lr else -1
+        self.ch_beta = 4 if self.t_dim else -1
+        self.ch_normal_an = c0 if normal_an else -1
+        self.ch_normal_lr = (c0 + 3 if normal_an else c0) if normal_lr else -1
         self.packed_bytes = L.lib().bn_field_packed_bytes(C.byref(d))
         if self.packed_bytes == 0:
             raise RuntimeError("bn_field_packed_bytes: " + L.lib().bn_last_error().decode())
 
     def key(self):
         return (self.feat, self.layers, self.skip, self.pe_freqs, self.act, self.dtype, tuple(self.heads), self.normal_lr,
-                self.normal_an, self.fold_feats, self.dir_dim, self.dir_freqs)
+                self.normal_an, self.fold_feats, self.dir_dim, self.dir_freqs, self.t_dim)
 
     def params_struct(self, named, grads=False):
         """named: dict state_dict-key -> tensor (parameters, or same-shaped gradient buffers)."""
-        s = L.FieldParams()
+        s = L.FieldGrads() if grads else L.FieldParams()
         for l in range(self.layers):
             s.trunk_w[l] = named[f"fc_net.{2*l}.weight"].data_ptr()
             s.trunk_b[l] = named[f"fc_net.{2*l}.bias"].data_ptr()
@@ -107,6 +117,10 @@ class FieldSpec:
             w = named[f"{self.heads[0][0]}.0.weight"]
             assert w.shape[1] == self.feat + self.dir_dim and w.is_contiguous()
             s.head0_wdir, s.head0_wdir_ld = w.data_ptr() + 4 * self.feat, w.shape[1]
+        if self.t_dim:          # embedding columns of the beta head's first layer
+            w = named[f"{self.heads[1][0]}.0.weight"]
+            assert w.shape[1] == self.feat + self.t_dim and w.is_contiguous()
+            s.head1_wt, s.head1_wt_ld = w.data_ptr() + 4 * self.feat, w.shape[1]
         return s
 
     @torch.no_grad()
@@ -155,9 +169,13 @@ class FieldSpec:
         return names
 
 
-def make_points(xyz=None, rays=None, z=None, dirs=None):
+def make_points(xyz=None, rays=None, z=None, dirs=None, t_embed=None):
     pts = L.Points()
-    pts.dirs = None
+    pts.dirs = pts.t_embed = None
+    if t_embed is not None:      # per point with xyz, per ray with rays
+        rows = xyz.shape[0] if xyz is not None else rays.shape[0]
+        assert t_embed.shape[0] == rows and t_embed.is_contiguous() and t_embed.dtype == torch.float32
+        pts.t_embed = t_embed.data_ptr()
     if xyz is not None:
         pts.xyz, pts.rays, pts.z = xyz.data_ptr(), None, None
         pts.ray_stride, pts.n_samples, pts.n_points = 0, 0, xyz.shape[0]
@@ -193,17 +211,21 @@ def field_sigma(spec, named_params, packed, xyz=None, rays=None, z=None):
 
 
 class FieldFunction(torch.autograd.Function):
-    """out[n_points][C] = field(points; params).  Differentiable w.r.t. the parameters only (the reference never
-    needs d/d xyz outside the analytic-normal path: z_vals are detached, rendering.py:262)."""
+    """out[n_points][C] = field(points; params).  Differentiable w.r.t. the parameters and the --beta embedding input
+    `t_embed` only (the reference never needs d/d xyz outside the analytic-normal path: z_vals are detached,
+    rendering.py:262)."""
 
     @staticmethod
-    def forward(ctx, spec, packed, xyz, rays, z, names_grad, *params):
+    def forward(ctx, spec, packed, xyz, rays, z, t_embed, names_grad, *params):
         names, grad_enabled, dirs = names_grad      # grad mode is always off inside Function.forward: passed in
         named = dict(zip(names, params))
-        pts = make_points(xyz, rays, z, dirs)
+        if t_embed is not None:
+            t_embed = t_embed.detach().float().contiguous()
+        pts = make_points(xyz, rays, z, dirs, t_embed)
         ref = xyz if xyz is not None else z
         out = torch.empty(pts.n_points, spec.out_channels, dtype=torch.float32, device=ref.device)
-        need_grad = grad_enabled and any(p.requires_grad for p in params)
+        ctx.t_grad = bool(grad_enabled and t_embed is not None and ctx.needs_input_grad[5])
+        need_grad = grad_enabled and (any(p.requires_grad for p in params) or ctx.t_grad)
         stash = None
         if need_grad or spec.normal_an:
             nbytes = L.lib().bn_field_stash_bytes(C.byref(spec.desc), pts.n_points)
@@ -217,7 +239,7 @@ class FieldFunction(torch.autograd.Function):
             if not need_grad:
                 stash = None
         ctx.spec, ctx.packed, ctx.names, ctx.stash = spec, packed, names, stash
-        ctx.pts_t = (xyz, rays, z, dirs)
+        ctx.pts_t = (xyz, rays, z, dirs, t_embed)
         ctx.save_for_backward(out, *params)
         return out
 
@@ -238,16 +260,24 @@ class FieldFunction(torch.autograd.Function):
         named_grads = dict(zip(names, grads))
         gs = spec.params_struct(named_grads, grads=True)
         ps = spec.params_struct(named)
-        xyz, rays, z, dirs = ctx.pts_t
-        pts = make_points(xyz, rays, z, dirs)
+        xyz, rays, z, dirs, t_embed = ctx.pts_t
+        pts = make_points(xyz, rays, z, dirs, t_embed)
+        d_t = None
+        if ctx.t_grad:          # per point; the rays form's per-ray gradient is the sum over the ray's samples
+            d_t = torch.empty(pts.n_points, spec.t_dim, dtype=torch.float32, device=out.device)
+            gs.d_t_embed = d_t.data_ptr()
+            if rays is not None:
+                d_t = d_t.view(rays.shape[0], -1, spec.t_dim)
         d_out = _f32(d_out)
         L.check(L.lib().bn_field_backward(C.byref(spec.desc), C.byref(ps), _p(ctx.packed), C.byref(pts), _p(out),
                                           _p(d_out), _p(ctx.stash), C.byref(gs), _stream()), "bn_field_backward")
         if spec.fold_feats:
             spec.unfold_grads(named, named_grads)
         ctx.stash = None
-        return (None, None, None, None, None, None) + tuple(g if p.requires_grad else None
-                                                            for g, p in zip(grads, params))
+        if d_t is not None and d_t.dim() == 3:
+            d_t = d_t.sum(1)
+        return (None, None, None, None, None, d_t, None) + tuple(g if p.requires_grad else None
+                                                                 for g, p in zip(grads, params))
 
 
 # ----------------------------------------------------------------------------------------- compositing

@@ -14,6 +14,14 @@ def snerf_loss(rgb, target, lambda_rgb=1.0):
     return lambda_rgb * torch.mean((rgb - target) ** 2)
 
 
+def uncertainty_aware_loss(rgb, weights, beta_samples, target, beta_min=0.05):
+    """uncertainty_aware_loss (metrics.py:24-28) on the --beta channel: beta = sum_s w beta_s + beta_min; returns
+    (mean((rgb - gt)^2 / (2 beta^2)), (3 + mean(log beta)) / 2).  The reference's own training of spsbrdf-nerf never calls it
+    (load_loss returns SNerfLoss for this model, metrics.py:172-173); offered for callers who want the SatNeRF-style term."""
+    beta = torch.sum(weights.unsqueeze(-1) * beta_samples, -2) + beta_min
+    return ((rgb - target) ** 2 / (2 * beta ** 2)).mean(), (3 + torch.log(beta).mean()) / 2
+
+
 def depth_loss(z_vals, depth, weights, target_depth, target_weight, valid_depth, target_std, lambda_ds,
                usealldepth=False):
     sel = valid_depth > 0

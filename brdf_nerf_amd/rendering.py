@@ -77,10 +77,15 @@ def inference(model, args, rays_xyz, z_vals, rays_d=None, sun_d=None, rays_t=Non
         return {"sigmas": sig.unsqueeze(-1), "depth": d, "alphas": a, "weights": w, "transparency": T,
                 "z_vals": z_vals}, "Lambertian"
 
-    dirs = None
+    dirs = t_embed = None
     if _rays is None and getattr(model, "dir_dim", 0):       # --input_viewdir with explicit points: rays_d per sample (:96,121)
         dirs = torch.repeat_interleave(rays_d.float(), S, dim=0).contiguous()
-    out = model.evaluate(spec, packed, xyz=xyz, rays=_rays, z=None if _rays is None else z_vals, dirs=dirs).view(R, S, spec.out_channels)
+    if model.beta:                                           # --beta: the image embedding of the ray, repeated per sample (:98)
+        if rays_t is None:
+            raise ValueError("--beta: inference() needs rays_t = models['t'](ts)")
+        t_embed = rays_t if _rays is not None else torch.repeat_interleave(rays_t, S, dim=0)
+    out = model.evaluate(spec, packed, xyz=xyz, rays=_rays, z=None if _rays is None else z_vals, dirs=dirs,
+                         t_embed=t_embed).view(R, S, spec.out_channels)
     if S == 1:
         raise NotImplementedError("single-sample pass 2 is undefined in the reference (SURVEY quirk 4)")
     alphas, transparency, weights, depth, acc = Fn.composite(z_vals, out, noise_arg, args.noise_std)
@@ -105,6 +110,8 @@ def shade(model, args, spec, out, z_vals, alphas, transparency, weights, depth, 
         result["sort_idx"] = sort_idx
     if z_vals_unsort is not None:
         result["z_vals_unsort"] = z_vals_unsort
+    if spec.ch_beta >= 0:                       # transient uncertainty per sample (:156-158, :225-226)
+        result["beta"] = out[..., spec.ch_beta:spec.ch_beta + 1]
     normal = normal_s = None
     if spec.normal_an:
         c0 = spec.ch_normal_an
@@ -229,6 +236,11 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
     nr_an = model.normal in ("analystic_learned", "analystic") or bTestNormal
     spec = model.spec(apply_brdf, apply_theta, nr_lr, nr_an)
     packed = model.repack(spec)
+    rays_t = None
+    if model.beta:                              # rendering.py:226-229
+        if ts is None or "t" not in models:
+            raise ValueError("--beta: render_rays needs ts and models['t'] (the image embedding, main.py:113-118)")
+        rays_t = models["t"](ts)
 
     z_vals = get_z_vals(S, rays.device, near, far)
     C = spec.out_channels
@@ -243,7 +255,7 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
         # merged pass-2 set (the reference evaluates them twice - sigma only, then again among the S+G samples - with
         # the same values).  Pass-1 compositing stays detached, as upstream (rendering.py:262).
         noise1 = torch.randn(R, S, device=rays.device)
-        out1 = model.evaluate(spec, packed, rays=rays, z=z_vals).view(R, S, C)
+        out1 = model.evaluate(spec, packed, rays=rays, z=z_vals, t_embed=rays_t).view(R, S, C)
         with torch.no_grad():
             _, _, w1, d1, _ = Fn.composite_forward_raw(z_vals, out1.detach(), noise1 if noise_on else None, args.noise_std)
     sun_res = {}
@@ -279,12 +291,12 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
         z2, z_all, idx = Fn.guided_samples(z_vals, w1, d1, u, rays[0, 6:8], None, args.std_range, use_t, tdep,
                                            tstd, u_t, trow, merge=not gsam_only)
     if gsam_only:
-        result, brdf_type = inference(model, args, None, z2, rays_d=rays_d, sun_d=sun_d, z_vals_unsort=z2, apply_brdf=apply_brdf,
+        result, brdf_type = inference(model, args, None, z2, rays_d=rays_d, sun_d=sun_d, rays_t=rays_t, z_vals_unsort=z2, apply_brdf=apply_brdf,
                                       bTestNormal=bTestNormal, sun_res=sun_res, sort_idx=None, mode=mode, apply_theta=apply_theta,
                                       cos_irra_on=cos_irra_on, _rays=rays, _packed=packed)
         return {f"{k}_coarse": v for k, v in result.items()}, brdf_type
     z_unsort = torch.cat([z_vals, z2], -1)
-    out2 = model.evaluate(spec, packed, rays=rays, z=z2).view(R, G, C)
+    out2 = model.evaluate(spec, packed, rays=rays, z=z2, t_embed=rays_t).view(R, G, C)
     out = torch.cat([out1, out2], 1).gather(1, idx.unsqueeze(-1).expand(-1, -1, C))      # depth-sorted order
     noise2 = torch.randn(R, S + G, device=rays.device)
     alphas, transparency, weights, depth, acc = Fn.composite(z_all, out, noise2 if noise_on else None, args.noise_std)

@@ -29,11 +29,19 @@ class TrainLoop:
         self.rank, self.world = world_info()
         dev = torch.device(device) if device is not None else table.device
         self.model = load_model(args, compute_dtype).to(dev)
+        # --beta: the per-image embedding of main.py:113-118, looked up by render_rays (rendering.py:226-229).  The loss of this
+        # model never reads beta_coarse, so like upstream the table (and the beta head) receives no gradient in training; it is
+        # created under the same RNG stream position, kept in the checkpoints under the reference's key and used by rendering.
+        self.embedding_t = None
+        if getattr(args, "beta", False):
+            self.embedding_t = torch.nn.Embedding(getattr(args, "t_embbeding_vocab", 30), args.t_embbeding_tau).to(dev)
         in_ckpts = getattr(args, "in_ckpts", "none")
         if in_ckpts != "none":                              # stage-2 warm start of the shared sub-modules (main.py:97-104)
             subs = ["fc_net", "sigma_from_xyz", "feats_from_xyz"] + ([] if args.b == True else ["rgb_from_xyzdir"])  # noqa: E712
             for sub in subs:
                 load_ckpt(self.model, in_ckpts, model_name=f"nerf_coarse.{sub}", drop_len=11, trusted=trusted_ckpts)
+            if self.embedding_t is not None:                # main.py:116-117
+                load_ckpt(self.embedding_t, in_ckpts, model_name="embedding_t", trusted=trusted_ckpts)
         g = lambda k, d=0.0: getattr(args, k, d)
         self.trainer = FusedTrainer(self.model, args, lr=args.lr, lambda_rgb=g("lambda_rgb", 1.0), ds_lambda=g("ds_lambda"),
                                     usealldepth=bool(g("usealldepth", False)), process_group=process_group, strict_rng=False,
@@ -44,6 +52,14 @@ class TrainLoop:
         self.last = {}
 
     # ------------------------------------------------------------------ one optimisation step
+    @property
+    def models(self):
+        """The dict render_rays / render_image take (main.py:92-118): {'coarse': field[, 't': image embedding]}."""
+        m = {"coarse": self.model}
+        if self.embedding_t is not None:
+            m["t"] = self.embedding_t
+        return m
+
     def step(self):
         a, tr, sch = self.args, self.trainer, self.schedule
         flags = sch.begin_step()
@@ -87,7 +103,10 @@ class TrainLoop:
         """`<ckpts_dir>/epoch=<e>.ckpt` in the reference's layout + resume state; `opts.json` in logs_dir (opt.py)."""
         os.makedirs(ckpts_dir, exist_ok=True)
         tr = self.trainer
-        ckpt = {"state_dict": {f"nerf_coarse.{k}": v.detach().clone() for k, v in self.model.state_dict().items()},
+        sd = {f"nerf_coarse.{k}": v.detach().clone() for k, v in self.model.state_dict().items()}
+        if self.embedding_t is not None:
+            sd.update({f"embedding_t.{k}": v.detach().clone() for k, v in self.embedding_t.state_dict().items()})
+        ckpt = {"state_dict": sd,
                 "epoch": self.schedule.epoch, "global_step": self.global_step,
                 "fused_trainer": {"exp_avg": tr.exp_avg.clone(), "exp_avg_sq": tr.exp_avg_sq.clone(),
                                   "adam_steps": dict(tr.adam_steps)},
@@ -104,6 +123,8 @@ class TrainLoop:
     def resume(self, path):
         ckpt = torch.load(path, map_location=self.trainer.flat_param.device, weights_only=False)
         load_ckpt(self.model, path, model_name="nerf_coarse")
+        if self.embedding_t is not None:
+            load_ckpt(self.embedding_t, path, model_name="embedding_t")
         tr = self.trainer
         ft = ckpt["fused_trainer"]
         tr.exp_avg.copy_(ft["exp_avg"]); tr.exp_avg_sq.copy_(ft["exp_avg_sq"])

@@ -53,7 +53,7 @@ class FusedTrainer:
         corrections at step 1 then: every group has its own counter and is stepped only while it is in the graph."""
         model = self.model
         named = dict(model.named_parameters())
-        base = set(model.spec(False, False, self.nr_lr).used_param_names())
+        base = set(model.spec(False, False, self.nr_lr, beta=False).used_param_names())
         theta = {n for n in named if n.startswith("theta_from_xyz.")}
         groups = [("base", [n for n in named if n in base]),
                   ("brdf", [n for n in named if n not in base and n not in theta]),
@@ -117,7 +117,7 @@ class FusedTrainer:
         S, G = args.n_samples, args.guided_samples
         R = rays.shape[0]
         dev = rays.device
-        spec = model.spec(apply_brdf, apply_theta, self.nr_lr, self.nr_an)
+        spec = model.spec(apply_brdf, apply_theta, self.nr_lr, self.nr_an, beta=False)   # (field.py spec(): the loss never reads beta)
         named = model.named()
         packed = model.repack(spec)
         near, far = rays[:, 6:7], rays[:, 7:8]

@@ -34,9 +34,9 @@
 extern "C" {
 #endif
 
-#define BN_ABI_VERSION 2
+#define BN_ABI_VERSION 3
 #define BN_MAX_LAYERS 12
-#define BN_MAX_HEADS 4 /* rgb + up to 3 BRDF heads evaluated together */
+#define BN_MAX_HEADS 6 /* rgb (+ beta) + up to 3 BRDF heads evaluated together, two per pass */
 
 typedef enum { BN_OK = 0, BN_EINVAL = -1, BN_EUNSUPPORTED = -2, BN_ELAUNCH = -3 } bn_status;
 typedef enum { BN_F32 = 0, BN_BF16 = 1, BN_F16 = 2 } bn_dtype;
@@ -47,7 +47,10 @@ typedef enum {
   BN_HEAD_RPV_K = 1,       /* (v-.5)*2+1, 1-wide tiled x3                                       */
   BN_HEAD_RPV_THETA = 2,   /* (v-.5)*2,   1-wide tiled x3                                       */
   BN_HEAD_HAPKE_THETA = 3, /* v*pi/6, width 1                                                   */
-  BN_HEAD_TILE3 = 4        /* sigmoid, 1-wide tiled x3 (rhoc, b, c)                             */
+  BN_HEAD_TILE3 = 4,       /* sigmoid, 1-wide tiled x3 (rhoc, b, c)                             */
+  BN_HEAD_BETA = 5         /* --beta (spsbrdfnerf.py:571-575,708-711): SOFTPLUS instead of sigmoid, width 1, written to
+                              channel 4 (right after sigma, before the normals); only as head 1; its first layer also
+                              reads the per-image embedding (desc.t_dim columns)                  */
 } bn_head_kind;
 
 int bn_abi_version(void);
@@ -86,6 +89,10 @@ typedef struct bn_field_desc {
                                           6 * dir_freqs.  Needs fold_feats = 1: params.head_w1[0] is the folded [F/2][F] matrix and
                                           params.head0_wdir the direction columns of <rgb head>.0.weight                        */
   int32_t dir_freqs;                   /* octaves of the direction encoding (mapping_sizes[1] = 4), 0 = raw direction              */
+  int32_t t_dim;                       /* --beta: width of the per-image embedding (--t_embbeding_tau, default 4) that head 1
+                                          (kind BN_HEAD_BETA) reads beside the features; 0 without that head.  Needs fold_feats;
+                                          params.head1_wt = beta_from_xyz.0.weight[:, F:].  Together with dir_dim:
+                                          round_up(dir_dim, 8) + t_dim <= 32                                                      */
 } bn_field_desc;
 
 /* fp32 parameter tensors in PyTorch nn.Linear layout (weight [out][in], row-major). */
@@ -99,6 +106,8 @@ typedef struct bn_field_params {
   const float *normal_w, *normal_b;    /* grad_from_xyz (may be NULL)                          */
   const float *head0_wdir;             /* rgb_from_xyzdir.0.weight[:, F:]  ([F/2][dir_dim], row stride head0_wdir_ld); NULL when dir_dim == 0 */
   int64_t head0_wdir_ld;
+  const float *head1_wt;               /* beta_from_xyz.0.weight[:, F:]  ([F/2][t_dim], row stride head1_wt_ld); NULL when t_dim == 0 */
+  int64_t head1_wt_ld;
 } bn_field_params;
 
 /* Same shape as bn_field_params but writable: gradient accumulators (fp32, += semantics). */
@@ -109,6 +118,10 @@ typedef struct bn_field_grads {
   float *normal_w, *normal_b;
   float *head0_wdir;                   /* += d/d rgb_from_xyzdir.0.weight[:, F:]  (row stride head0_wdir_ld) */
   int64_t head0_wdir_ld;
+  float *head1_wt;                     /* += d/d beta_from_xyz.0.weight[:, F:]  (row stride head1_wt_ld) */
+  int64_t head1_wt_ld;
+  float *d_t_embed;                    /* nullable; = (overwritten) d/d t_embed per POINT, [n_points][t_dim], in both point forms
+                                          (the rays form's per-ray gradient is its sum over the ray's samples)            */
 } bn_field_grads;
 
 /* Bytes of the packed weight buffer (forward + transposed copies) for `desc`. */
@@ -129,13 +142,16 @@ typedef struct bn_points {
   int64_t n_points;
   const float *dirs;                   /* xyz form with desc.dir_dim > 0: view direction per point [n_points][3] (the rays form reads
                                           rays[ray][3:6], as inference() repeats rays_d per sample, spsbrdfnerf.py:96,121)       */
+  const float *t_embed;                /* desc.t_dim > 0: the per-image embedding models['t'](ts) (rendering.py:226-229) - xyz form:
+                                          per point [n_points][t_dim]; rays form: per ray [n_rays][t_dim] (repeated per sample,
+                                          spsbrdfnerf.py:98)                                                                       */
 } bn_points;
 
 /* sigma-only forward (forward(sigma_only=True), spsbrdfnerf.py:684): sigma[n_points]. */
 int bn_field_sigma(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
                    const bn_points *pts, float *sigma, void *stream);
 /* full forward: out[n_points][desc->out_channels], channel order of spsbrdfnerf.py:694-755:
- * [rgb3, sigma, (normal_an3), (normal_lr3), head outputs (1-wide RPV/Hapke b,c heads tiled x3)].
+ * [rgb3, sigma, (beta1), (normal_an3), (normal_lr3), head outputs (1-wide RPV/Hapke b,c heads tiled x3)].
  * `stash` != NULL keeps what bn_field_backward needs. */
 int bn_field_forward(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
                      const bn_points *pts, float *out, void *stash, void *stream);

@@ -41,6 +41,8 @@ class FieldConfig:
     sun_v: str = "none"                # none | analystic (sun-visibility pass, rendering.py:244-259; no parameters)
     input_viewdir: int = 0             # 1: the encoded view direction joins the rgb head's input (spsbrdfnerf.py:458,689-692)
     dir_freqs: int = 4                 # mapping_sizes[1], spsbrdfnerf.py:445
+    beta: bool = False                 # --beta: transient-uncertainty head on cat([xyz_features, t embedding]) (spsbrdfnerf.py:571-575,708-711)
+    t_dim: int = 4                     # --t_embbeding_tau (opt.py:199), width of the per-image embedding
 
     @property
     def RPV(self):
@@ -75,6 +77,10 @@ class FieldConfig:
             rgb[0] = ("rgb_from_xyzdir.0.weight", (F // 2, F + self.dir_dim), "linear")
             rgb[1] = ("rgb_from_xyzdir.0.bias", (F // 2,), "bias%d" % (F + self.dir_dim))
         out += rgb
+        if self.beta:         # Linear(t_embedding_dims + feat, feat // 2), nl, Linear(feat // 2, 1), Softplus  (spsbrdfnerf.py:571-574)
+            H2, k = F // 2, self.t_dim + F
+            out += [("beta_from_xyz.0.weight", (H2, k), "linear"), ("beta_from_xyz.0.bias", (H2,), "bias%d" % k),
+                    ("beta_from_xyz.2.weight", (1, H2), "linear"), ("beta_from_xyz.2.bias", (1,), "bias%d" % H2)]
         if self.normal in ("learned", "analystic_learned"):
             out.append(("grad_from_xyz.weight", (3, F), "linear"))
             out.append(("grad_from_xyz.bias", (3,), "bias%d" % F))
@@ -125,7 +131,7 @@ class FieldConfig:
 
     def out_channels(self, apply_brdf=False, apply_theta=False, bTestNormal=False):
         """Channel count of forward() (inference(): spsbrdfnerf.py:104-115)."""
-        c = 4
+        c = 5 if self.beta else 4
         if self.normal in ("analystic", "analystic_learned") or bTestNormal:
             c += 3
         if self.normal in ("learned", "analystic_learned"):

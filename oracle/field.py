@@ -75,12 +75,14 @@ def _tile3(v):
 
 
 def field_forward(params, cfg, xyz, sigma_only=False, apply_brdf=False, apply_theta=False,
-                  nr_an_on=False, nr_lr_on=False, dirs=None):
-    """SpSBRDFNeRF.forward (spsbrdfnerf.py:662-757) for sun_v='none', beta=False, indirect_light=False.
+                  nr_an_on=False, nr_lr_on=False, dirs=None, t_embed=None):
+    """SpSBRDFNeRF.forward (spsbrdfnerf.py:662-757) for sun_v='none', indirect_light=False.
+    `t_embed` (B, cfg.t_dim): per-point image embedding, used only with cfg.beta (spsbrdfnerf.py:708-711: one more output
+    channel beta = beta_from_xyz(cat([xyz_features, input_t])) right after sigma).
     `dirs` (B,3): per-point view directions, used only with cfg.input_viewdir == 1 (spsbrdfnerf.py:689-692: the rgb head
     reads cat([xyz_features, mapping[1](input_dir)])).
 
-    Channel order: [rgb3, sigma1, (normal_an3), (normal_lr3), (rough1 | k3,theta3,rhoc3 | b3,c3,theta1)].
+    Channel order: [rgb3, sigma1, (beta1), (normal_an3), (normal_lr3), (rough1 | k3,theta3,rhoc3 | b3,c3,theta1)].
     """
     h = trunk(params, cfg, xyz)
     sigma = torch.nn.functional.softplus(
@@ -93,6 +95,11 @@ def field_forward(params, cfg, xyz, sigma_only=False, apply_brdf=False, apply_th
         rgb_in = torch.cat([feats, positional_encoding(dirs, cfg.dir_freqs) if cfg.mapping else dirs], -1)
     rgb = _head(params, cfg, "rgb_from_xyzdir", rgb_in)
     out = [rgb, sigma]
+    if cfg.beta:
+        g = _act(cfg, torch.nn.functional.linear(torch.cat([feats, t_embed], -1), params["beta_from_xyz.0.weight"],
+                                                 params["beta_from_xyz.0.bias"]), 1.0)
+        out.append(torch.nn.functional.softplus(
+            torch.nn.functional.linear(g, params["beta_from_xyz.2.weight"], params["beta_from_xyz.2.bias"])))
     if nr_an_on:
         out.append(-l2_normalize(sigma_grad(params, cfg, xyz, create_graph=True)))
     if nr_lr_on:

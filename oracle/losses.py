@@ -68,3 +68,11 @@ def psnr(image_pred, image_gt):
     normalised by max(image_gt)^2 before the mean; returns the first element of the reference's (psnr, psnr_scl) pair."""
     value = (image_pred - image_gt) ** 2 / (torch.max(image_gt) ** 2)
     return -10.0 * torch.log10(torch.mean(value))
+
+
+def uncertainty_aware_loss(rgb, weights, beta_samples, targets, beta_min=0.05):
+    """uncertainty_aware_loss (metrics.py:24-28): beta = sum_s w beta_s + beta_min; colour term mean((rgb - gt)^2 / (2 beta^2)),
+    log term (3 + mean(log beta)) / 2.  Returns (colour, logbeta).  For spsbrdf-nerf the reference's training never calls it
+    (load_loss gives SNerfLoss, metrics.py:172-173): kept for users who add it, and to pin the beta channel end to end."""
+    beta = torch.sum(weights.unsqueeze(-1) * beta_samples, -2) + beta_min
+    return ((rgb - targets) ** 2 / (2 * beta ** 2)).mean(), (3 + torch.log(beta).mean()) / 2

@@ -127,15 +127,18 @@ def guided_samples(depth, weights, z, n_guided, near0, far0, rnd, d_range=3.0, m
 
 
 def inference(params, cfg, xyz, z, rays_d, sun_d, rnd, sigma_only=False, apply_brdf=False,
-              apply_theta=False, cos_irra_on=False, sort_idx=None, z_unsort=None, bTestNormal=False, sun_res=None):
-    """inference (spsbrdfnerf.py:71-416) for sun_v in ('none', 'analystic'), beta=False.  Returns (dict, brdf_type)."""
+              apply_theta=False, cos_irra_on=False, sort_idx=None, z_unsort=None, bTestNormal=False, sun_res=None,
+              rays_t=None):
+    """inference (spsbrdfnerf.py:71-416) for sun_v in ('none', 'analystic').  Returns (dict, brdf_type).
+    rays_t (R, t_dim): per-ray image embedding for --beta (repeated per sample, :98)."""
     R, S = z.shape
     pts = xyz.reshape(-1, 3)
     nr_an = cfg.normal in ("analystic", "analystic_learned") or bTestNormal
     nr_lr = cfg.normal in ("learned", "analystic_learned")
     dirs = torch.repeat_interleave(rays_d, S, dim=0) if cfg.dir_dim else None      # spsbrdfnerf.py:96,121
     out = field_forward(params, cfg, pts, sigma_only=sigma_only, apply_brdf=apply_brdf,
-                        apply_theta=apply_theta, nr_an_on=nr_an, nr_lr_on=nr_lr, dirs=dirs)
+                        apply_theta=apply_theta, nr_an_on=nr_an, nr_lr_on=nr_lr, dirs=dirs,
+                        t_embed=torch.repeat_interleave(rays_t, S, dim=0) if (cfg.beta and not sigma_only) else None)
     noise = rnd.randn((R, S), z.dtype)
     if sigma_only:
         sig = out.view(R, S)
@@ -148,6 +151,9 @@ def inference(params, cfg, xyz, z, rays_d, sun_d, rnd, sigma_only=False, apply_b
     idx = 4
     normal = None
     res = {}
+    if cfg.beta:                                 # :156-158, stored as result['beta'] (:225-226)
+        res["beta"] = out[..., idx:idx + 1]
+        idx += 1
     if nr_an:
         res["normal_an"] = normal = out[..., idx:idx + 3]
         idx += 3
@@ -270,8 +276,9 @@ def inference(params, cfg, xyz, z, rays_d, sun_d, rnd, sigma_only=False, apply_b
 
 def render_rays(params, cfg, rays, rnd, mode="test", valid_depth=None, target_depths=None, target_std=None,
                 apply_brdf=False, apply_theta=False, cos_irra_on=False, gsam_only=False, bTestNormal=False,
-                bTestSun_v=False):
-    """render_rays, spsbrdf-nerf branch (rendering.py:168-291), guided_samples>0, sun_v in ('none', 'analystic')."""
+                bTestSun_v=False, rays_t=None):
+    """render_rays, spsbrdf-nerf branch (rendering.py:168-291), guided_samples>0, sun_v in ('none', 'analystic').
+    rays_t = models['t'](ts) (rendering.py:226-229), needed with cfg.beta."""
     o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
     S, G = cfg.n_samples, cfg.guided_samples
     assert G > 0, "guided_samples<=0 returns an un-suffixed dict in the reference (SURVEY quirk 1)"
@@ -311,7 +318,7 @@ def render_rays(params, cfg, rays, rnd, mode="test", valid_depth=None, target_de
     xyz = o.unsqueeze(1) + d.unsqueeze(1) * z_all.unsqueeze(2)
     res, brdf_type = inference(params, cfg, xyz, z_all, d, sun_d, rnd, apply_brdf=apply_brdf,
                                apply_theta=apply_theta, cos_irra_on=cos_irra_on, sort_idx=idx,
-                               z_unsort=z_unsort, bTestNormal=bTestNormal, sun_res=sun_res)
+                               z_unsort=z_unsort, bTestNormal=bTestNormal, sun_res=sun_res, rays_t=rays_t)
     out = {f"{k}_coarse": v for k, v in res.items()}
     out["_pass1"] = res1
     out["_guided_inds"] = inds

@@ -47,7 +47,7 @@ def import_reference():
 def ref_args(cfg: FieldConfig):
     return argparse.Namespace(
         model="spsbrdf-nerf", fc_layers=cfg.layers, fc_feat=cfg.feat, mapping=cfg.mapping, siren=int(cfg.siren),
-        t_embbeding_tau=4, beta=False, roughness=cfg.roughness, normal=cfg.normal, indirect_light=False,
+        t_embbeding_tau=getattr(cfg, "t_dim", 4), beta=bool(getattr(cfg, "beta", False)), roughness=cfg.roughness, normal=cfg.normal, indirect_light=False,
         glossy_scale=1.0, sun_v=cfg.sun_v, MultiBRDF=int(cfg.MultiBRDF), dim_RPV=cfg.dim_RPV,
         input_viewdir=int(getattr(cfg, "input_viewdir", 0)),
         funcM=cfg.funcM, funcF=cfg.funcF, funcH=cfg.funcH, b=cfg.b, c=cfg.c, theta=cfg.theta, B0=0, h=0,
@@ -485,6 +485,50 @@ def gen_viewdir(ref):
          **arrays)
 
 
+def gen_beta(ref):
+    """--beta (spsbrdfnerf.py:571-575,708-711; rendering.py:226-229): one more output channel after sigma,
+    beta = Softplus(Linear(Siren(Linear(cat([xyz_features, t embedding]))))).  Field forward with per-point embeddings and the
+    gradients of a random linear functional w.r.t. every parameter AND the embedding input; the full render_rays dict in train
+    mode with models['t'] = an Embedding looked up by ts (RPV + learned normals), a loss that reads beta through
+    uncertainty_aware_loss (metrics.py:24-28), gradients of the parameters and of the embedding table."""
+    for tag, kw in (("beta", dict(beta=True, funcM=1, funcF=1, funcH=1, normal="learned")),
+                    ("beta_viewdir_relu", dict(beta=True, input_viewdir=1, siren=False, t_dim=6))):
+        cfg = mini(**kw)
+        model, csum = build_ref_model(ref, cfg, seed=15)
+        g = torch.Generator().manual_seed(12)
+        xyz = torch.rand(150, 3, generator=g) * 2 - 1
+        dirs = torch.nn.functional.normalize(torch.randn(150, 3, generator=g), dim=-1)
+        t_in = torch.randn(150, cfg.t_dim, generator=g).requires_grad_(True)
+        nlr = cfg.normal in ("learned", "analystic_learned")
+        out = quiet(model, xyz.clone(), input_dir=dirs, input_t=t_in, apply_brdf=True, apply_theta=True, nr_an_on=False,
+                    nr_lr_on=nlr)
+        coef = torch.randn(out.shape, generator=g)
+        (out * coef).sum().backward()
+        grads = {f"grad/{k}": (p_.grad if p_.grad is not None else torch.zeros_like(p_)) for k, p_ in model.named_parameters()}
+        save(f"field_{tag}_F64", xyz=xyz, dirs=dirs, t_in=t_in.detach(), out_brdf=out, coef=coef, d_t_in=t_in.grad,
+             param_checksum=csum, param_seed=15, **grads)
+    cfg = mini(beta=True, funcM=1, funcF=1, funcH=1, normal="learned")
+    model, csum = build_ref_model(ref, cfg, seed=11)
+    rays = sat_rays(64, 22)
+    emb = torch.nn.Embedding(5, cfg.t_dim)
+    with torch.no_grad():
+        emb.weight.copy_(torch.randn(5, cfg.t_dim, generator=torch.Generator().manual_seed(8)))
+    ts = torch.randint(0, 5, (64,), generator=torch.Generator().manual_seed(9))
+    with RecordRandoms(torch.Generator().manual_seed(2)) as rec:
+        res, bt = quiet(ref["rendering"].render_rays, {"coarse": model, "t": emb}, ref_args(cfg), rays, ts, mode="train",
+                        apply_brdf=True, apply_theta=True, cos_irra_on=True)
+    tgt = torch.rand(64, 3, generator=torch.Generator().manual_seed(5))
+    ld = ref["metrics"].uncertainty_aware_loss({}, res, tgt, "coarse")
+    loss = ld["coarse_color"] + ld["coarse_logbeta"] + 0.01 * res["depth_coarse"].mean()
+    loss.backward()
+    arrays = {f"out/{k}": v for k, v in res.items()}
+    arrays.update({f"rand{i}": t for i, t in enumerate(rec.log)})
+    arrays.update({f"grad/{k}": (p_.grad if p_.grad is not None else torch.zeros_like(p_)) for k, p_ in model.named_parameters()})
+    save("render_beta_train", rays=rays, ts=ts, emb=emb.weight.detach(), d_emb=emb.weight.grad, targets=tgt, loss=loss,
+         loss_color=ld["coarse_color"], loss_logbeta=ld["coarse_logbeta"], brdf_type=np.array(bt), param_checksum=csum,
+         param_seed=11, **arrays)
+
+
 INIT_CONFIGS = {
     "lambert": dict(),
     "rpv111_anlr": dict(funcM=1, funcF=1, funcH=1, normal="analystic_learned"),
@@ -493,6 +537,7 @@ INIT_CONFIGS = {
     "relu_rpvM": dict(siren=False, funcM=1),
     "nomap": dict(mapping=False),
     "viewdir": dict(input_viewdir=1),
+    "beta_nlr": dict(beta=True, normal="learned", funcM=1),
 }
 
 
@@ -530,6 +575,9 @@ if __name__ == "__main__":
     if "--only-field-variants" in sys.argv:
         gen_field_variants(ref)
         sys.exit(0)
+    if "--only-beta" in sys.argv:
+        gen_beta(ref)
+        sys.exit(0)
     if "--only-sunv" in sys.argv:
         gen_render_sunv(ref)
         sys.exit(0)
@@ -549,3 +597,4 @@ if __name__ == "__main__":
     gen_regularisers(ref)
     gen_init(ref)
     gen_viewdir(ref)
+    gen_beta(ref)

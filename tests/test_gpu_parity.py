@@ -32,7 +32,7 @@ def mini(**kw):
 def make_args(cfg, compute_dtype="fp32"):
     return argparse.Namespace(
         model="spsbrdf-nerf", fc_layers=cfg.layers, fc_feat=cfg.feat, mapping=cfg.mapping, siren=int(cfg.siren),
-        t_embbeding_tau=4, beta=False, roughness=cfg.roughness, normal=cfg.normal, indirect_light=False, glossy_scale=1.0,
+        t_embbeding_tau=cfg.t_dim, beta=bool(cfg.beta), roughness=cfg.roughness, normal=cfg.normal, indirect_light=False, glossy_scale=1.0,
         sun_v=getattr(cfg, "sun_v", "none"), MultiBRDF=int(cfg.MultiBRDF), dim_RPV=cfg.dim_RPV, input_viewdir=int(cfg.input_viewdir), funcM=cfg.funcM,
         funcF=cfg.funcF, funcH=cfg.funcH, b=cfg.b, c=cfg.c, theta=cfg.theta, shell_hapke=cfg.shell_hapke, hpk_scl=cfg.hpk_scl,
         guided_samples=cfg.guided_samples, n_samples=cfg.n_samples, n_importance=0, std_range=cfg.std_range, data=cfg.data,
@@ -88,7 +88,7 @@ def diag(line):
 # the top octave multiplies a 1-ulp difference in a sample depth (torch.linspace / torch.sum low bits, see
 # test_stratified_z) by 2^9, so they are held to 1e-3; with identical inputs the field itself is held to 1e-4
 # (test_field_forward_*).  Ray-level results (rgb, depth, weights, ...) are held to the north_star's 1e-4.
-PER_SAMPLE = ("sigmas", "albedo", "normal_lr", "rpv_k", "rpv_theta", "rpv_rhoc", "hpk_b", "hpk_c", "hpk_theta", "roughness")
+PER_SAMPLE = ("sigmas", "albedo", "normal_lr", "beta", "rpv_k", "rpv_theta", "rpv_rhoc", "hpk_b", "hpk_c", "hpk_theta", "roughness")
 # the north_star's 1e-4 quantities: rendered pixel values, depths and the compositing weights they are built from
 RAY_HEADLINE = ("rgb", "depth", "albedo_accu", "weights", "alphas", "transparency", "z_vals", "z_vals_unsort", "irradiance",
                 "rays_d", "sun_d")
@@ -106,6 +106,10 @@ def compare_render(res, g, tag, ray_tol=(1e-4, 2e-5), other_tol=(1e-3, 2e-4)):
             continue
         got = res[k].detach().cpu().double().numpy()
         refd = ref.astype(np.float64)
+        if k == "hpk_scl_coarse":
+            # 1 / (hpk_scl (n.v + n.l)) (spsbrdfnerf.py:248): a diagnostic that is unbounded where the two cosines cancel, so it
+            # is compared through its reciprocal - the sum of two ray-level dot products, each held to ~1e-4 elsewhere
+            got, refd = 1.0 / got, 1.0 / refd
         both = np.isnan(got) & np.isnan(refd)
         err = np.where(both, 0.0, np.abs(got - refd))
         base = k[:-7]
@@ -127,7 +131,7 @@ def compare_render(res, g, tag, ray_tol=(1e-4, 2e-5), other_tol=(1e-3, 2e-4)):
 # ------------------------------------------------------------------------------------------------ C ABI smoke
 def test_library_loads_on_gpu():
     from brdf_nerf_amd import _lib
-    assert _lib.lib().bn_abi_version() == 2
+    assert _lib.lib().bn_abi_version() == 3
 
 
 def test_device_fault_word_stays_clear():
@@ -178,9 +182,10 @@ def test_composite_golden(S):
 def test_composite_channels_and_sizes():
     """Weighted channel sums + backward against the oracle, S from 1..192 incl. ragged (S not a multiple of 64)."""
     from brdf_nerf_amd import functions as Fn
-    # C in {4, 8, 16} with dense rows takes the flat float4 channel path (render_kernels.hip), everything else the generic one
+    # dense rows take the flat 4-channel-group path (render_kernels.hip): float4 groups when C % 4 == 0; C in (16, 32] (beta /
+    # both normals + three RPV heads) walks 8 groups per sample
     for S, C, R in ((1, 4, 7), (63, 7, 33), (64, 4, 128), (130, 13, 65), (192, 16, 9), (128, 16, 65), (128, 8, 9), (17, 8, 5),
-                    (512, 16, 3), (3, 16, 2), (128, 12, 4)):
+                    (512, 16, 3), (3, 16, 2), (128, 12, 4), (128, 17, 9), (80, 20, 33), (128, 32, 5), (65, 19, 3)):
         g = torch.Generator().manual_seed(S)
         z = torch.sort(torch.rand(R, S, generator=g) * 2, -1)[0]
         out = torch.randn(R, S, C, generator=g)
@@ -923,10 +928,104 @@ def test_field_input_viewdir_half_tracks_fp32(dtype):
 
 
 
+# ------------------------------------------------------------------------------------------------ --beta
+BETA = {"beta": dict(beta=True, funcM=1, funcF=1, funcH=1, normal="learned"),          # rgb + beta + 3 RPV heads: three head passes
+        "beta_viewdir_relu": dict(beta=True, input_viewdir=1, siren=False, t_dim=6)}  # both extra-input segments in one tile
+
+
+@pytest.mark.parametrize("tag", list(BETA))
+def test_field_beta_golden_fp32(tag):
+    """--beta (spsbrdfnerf.py:571-575,708-711): channel 4 = Softplus(Linear(nl(Linear(cat([xyz_features, t embedding]))))).
+    The embedding is one more K segment of head 1's first layer; outputs, parameter gradients (the embedding columns of
+    beta_from_xyz.0.weight in place at column offset F) and the gradient w.r.t. the embedding input against the reference."""
+    g = load_golden(f"field_{tag}_F64")
+    cfg = mini(**BETA[tag])
+    model = build_model(cfg, 15)
+    xyz, dirs = torch.from_numpy(g["xyz"]).to(DEV), torch.from_numpy(g["dirs"]).to(DEV)
+    t_in = torch.from_numpy(g["t_in"]).to(DEV).requires_grad_(True)
+    out = model(xyz, input_dir=dirs, input_t=t_in, apply_brdf=True, apply_theta=True, nr_lr_on=cfg.normal == "learned")
+    assert_close(out, g["out_brdf"], 1e-4, 1e-5, "out")
+    (out * torch.from_numpy(g["coef"]).to(DEV)).sum().backward()
+    ref = g["d_t_in"]
+    assert float((t_in.grad.cpu() - torch.from_numpy(ref)).abs().max()) <= 2e-4 * float(np.abs(ref).max()), "d_t_in"
+    for k, v in model.named_parameters():
+        ref = g[f"grad/{k}"]
+        got = v.grad.cpu().numpy() if v.grad is not None else np.zeros_like(ref)
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        err = float(np.abs(got - ref).max())
+        diag(f"field_{tag} grad {k}: err {err:.3e} scale {scale:.3e}")
+        assert err <= 2e-4 * scale + 1e-9, f"{k}: err {err:.3e} scale {scale:.3e}"
+    with pytest.raises(ValueError):
+        model(xyz, input_dir=dirs, apply_brdf=True)       # no embedding given
+
+
+def test_render_rays_beta_golden_fp32():
+    """render_rays with --beta, models['t'](ts) (rendering.py:226-229), train mode: every key of the reference's dict
+    (beta_coarse among them), the uncertainty-aware loss (metrics.py:24-28), gradients of the parameters and of the
+    embedding table (the per-ray embedding gradient is the kernel's per-sample one summed over both sample sets)."""
+    from brdf_nerf_amd import render_rays, losses
+    g = load_golden("render_beta_train")
+    cfg = mini(**BETA["beta"])
+    model = build_model(cfg, 11)
+    emb = torch.nn.Embedding(*g["emb"].shape).to(DEV)
+    with torch.no_grad():
+        emb.weight.copy_(torch.from_numpy(g["emb"]))
+    ts = torch.from_numpy(g["ts"]).to(DEV)
+    with Replay(replay_list(g)) as rp:
+        res, brdf_type = render_rays({"coarse": model, "t": emb}, make_args(cfg), torch.from_numpy(g["rays"]).to(DEV), ts,
+                                     mode="train", apply_brdf=True, apply_theta=True, cos_irra_on=True)
+        assert rp.draws == []
+    assert brdf_type == str(g["brdf_type"])
+    assert {k[4:] for k in g if k.startswith("out/")} == set(res)
+    compare_render(res, g, "render_beta_train", ray_tol=(1e-4, 2e-5))
+    tgt = torch.from_numpy(g["targets"]).to(DEV)
+    l_color, l_logbeta = losses.uncertainty_aware_loss(res["rgb_coarse"], res["weights_coarse"], res["beta_coarse"], tgt)
+    assert_close(l_color, g["loss_color"], 1e-4, 1e-7, "loss_color")
+    assert_close(l_logbeta, g["loss_logbeta"], 1e-4, 1e-7, "loss_logbeta")
+    loss = l_color + l_logbeta + 0.01 * torch.mean(res["depth_coarse"])
+    loss.backward()
+    ref = g["d_emb"]
+    err = float((emb.weight.grad.cpu() - torch.from_numpy(ref)).abs().max())
+    diag(f"render_beta_train d_emb: err {err:.3e} scale {float(np.abs(ref).max()):.3e}")
+    assert err <= 5e-3 * float(np.abs(ref).max()) + 1e-9
+    for k, v in model.named_parameters():
+        ref = g[f"grad/{k}"]
+        got = v.grad.cpu().numpy() if v.grad is not None else np.zeros_like(ref)
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        err = float(np.abs(got - ref).max())
+        diag(f"render_beta_train grad {k}: err {err:.3e} scale {scale:.3e}")
+        assert err <= 5e-3 * scale + 1e-9, f"{k}: err {err:.3e} scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_field_beta_half_tracks_fp32(dtype):
+    """The 16-bit modes with the embedding segment and five heads at F=512: beta within the rgb bound (relative), the
+    embedding-input gradient and the embedding columns' gradient point the same way as in the fp32 mode."""
+    cfg = FieldConfig(feat=512, beta=True, funcM=1, funcF=1, funcH=1, normal="learned")
+    g = torch.Generator().manual_seed(4)
+    xyz = (torch.rand(1500, 3, generator=g) * 2 - 1).to(DEV)
+    t0 = torch.randn(1500, cfg.t_dim, generator=g).to(DEV)
+    outs, gw, gt = {}, {}, {}
+    for dt in ("fp32", dtype):
+        model = build_model(cfg, 5, dt)
+        t_in = t0.clone().requires_grad_(True)
+        out = model(xyz, input_t=t_in, apply_brdf=True, nr_lr_on=True)
+        coef = torch.randn(out.shape, generator=torch.Generator().manual_seed(6)).to(DEV)
+        (out * coef).sum().backward()
+        outs[dt], gw[dt], gt[dt] = out.detach(), model.beta_from_xyz[0].weight.grad[:, cfg.feat:].clone(), t_in.grad.clone()
+    b = HALF_BOUNDS[dtype]
+    rel = float(((outs[dtype][:, 4] - outs["fp32"][:, 4]).abs() / (outs["fp32"][:, 4].abs() + 0.1)).max())
+    cw = float(torch.nn.functional.cosine_similarity(gw[dtype].flatten(), gw["fp32"].flatten(), dim=0))
+    ct = float(torch.nn.functional.cosine_similarity(gt[dtype].flatten(), gt["fp32"].flatten(), dim=0))
+    diag(f"beta {dtype}: max rel err of beta {rel:.3e}, cos(d W_t) {cw:.5f}, cos(d t_embed) {ct:.5f}")
+    assert rel <= 3 * b["rgb"] and cw >= b["cos"] and ct >= b["cos"]
+
+
+
 # ------------------------------------------------------------------------------------------------ fused trainer
 @pytest.mark.parametrize("name,with_depth", [("lambert", False), ("lambert", True), ("rpv111_nlr", True), ("rpv111_nan", False),
                                              ("rpv111_nlr_multibrdf", False), ("hapke_bct_multibrdf", True),
-                                             ("rpv111_nlr_viewdir", False)])
+                                             ("rpv111_nlr_viewdir", False), ("hapke_bct_beta", True)])
 def test_fused_trainer_matches_autograd_path(name, with_depth):
     """FusedTrainer.step (the path bench.py times) == render_rays + losses + loss.backward() + torch.optim.Adam, same draws.
     With depth priors the reference's quirk 7 (target_std == 0) is used, so the ground-truth-guided rows do not depend on
@@ -936,7 +1035,8 @@ def test_fused_trainer_matches_autograd_path(name, with_depth):
     # --MultiBRDF: one BRDF per SAMPLE (spsbrdfnerf.py:289-307,350-352): the loss reads per-sample field outputs directly
     allc = dict(CONFIGS, **CONFIGS_AN, rpv111_nlr_multibrdf=dict(CONFIGS["rpv111_nlr"], MultiBRDF=True),
                 hapke_bct_multibrdf=dict(CONFIGS["hapke_bct"], MultiBRDF=True),
-                rpv111_nlr_viewdir=dict(CONFIGS["rpv111_nlr"], input_viewdir=1))
+                rpv111_nlr_viewdir=dict(CONFIGS["rpv111_nlr"], input_viewdir=1),
+                hapke_bct_beta=dict(CONFIGS["hapke_bct"], beta=True))
     cfg = mini(**allc[name])
     args = make_args(cfg)
     g = torch.Generator().manual_seed(3)
@@ -957,8 +1057,13 @@ def test_fused_trainer_matches_autograd_path(name, with_depth):
 
     ma = build_model(cfg, 11)
     opt = torch.optim.Adam(ma.parameters(), lr=5e-4)
+    models_a, ts = {"coarse": ma}, None
+    if cfg.beta:      # --beta: the autograd path evaluates the beta head (models['t'](ts)); SNerfLoss never reads it, so it gets
+        models_a["t"] = torch.nn.Embedding(5, cfg.t_dim).to(DEV)      # no gradient - the fused step leaves the head out
+        ts = torch.randint(0, 5, (R,), generator=g).to(DEV)
     with Replay(draws_ref):
-        res, _ = render_rays({"coarse": ma}, args, rays, None, mode="train", **flags, **dk)
+        res, _ = render_rays(models_a, args, rays, ts, mode="train", **flags, **dk)
+    assert ("beta_coarse" in res) == bool(cfg.beta)
     loss_a = losses.snerf_loss(res["rgb_coarse"], rgbs)
     if with_depth:
         loss_a = loss_a + losses.depth_loss(res["z_vals_coarse"], res["depth_coarse"], res["weights_coarse"], depths[:, 0],
@@ -973,6 +1078,12 @@ def test_fused_trainer_matches_autograd_path(name, with_depth):
         loss_b, _ = tr.step(rays, rgbs, valid_depth=valid if with_depth else None, depths=depths if with_depth else None,
                             depth_std=dstd if with_depth else None, **flags)
     assert_close(loss_b, loss_a.detach(), 1e-5, 1e-7, "loss")
+    if cfg.beta:
+        assert models_a["t"].weight.grad is None or float(models_a["t"].weight.grad.abs().max()) == 0.0
+        for k in tr.grad_views:
+            if k.startswith("beta_from_xyz."):
+                assert k not in grads_a or float(grads_a[k].abs().max()) == 0.0
+                assert float(tr.grad_views[k].abs().max()) == 0.0, k
     for k, ga in grads_a.items():
         gb = tr.grad_views[k]
         scale = float(ga.abs().max())
@@ -1708,7 +1819,7 @@ def test_bad_arguments_come_back_as_errors_not_faults():
     with pytest.raises(RuntimeError, match="composite"):
         Fn.composite_forward_raw(z, torch.rand(3, 513, 4, device=DEV))                # S beyond 512
     with pytest.raises(RuntimeError, match="composite"):
-        Fn.composite_forward_raw(z[:, :8].contiguous(), torch.rand(3, 8, 17, device=DEV))   # more channels than supported
+        Fn.composite_forward_raw(z[:, :8].contiguous(), torch.rand(3, 8, 33, device=DEV))   # more channels than supported
     z16 = torch.sort(torch.rand(5, 16, device=DEV), -1)[0]
     w = torch.rand(5, 16, device=DEV)
     with pytest.raises(RuntimeError, match="guided_samples"):

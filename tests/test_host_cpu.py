@@ -28,7 +28,7 @@ def make_args(cfg, **over):
     import argparse
     a = argparse.Namespace(
         model="spsbrdf-nerf", fc_layers=cfg.layers, fc_feat=cfg.feat, mapping=cfg.mapping, siren=int(cfg.siren),
-        t_embbeding_tau=4, beta=False, roughness=cfg.roughness, normal=cfg.normal, indirect_light=False, glossy_scale=1.0,
+        t_embbeding_tau=cfg.t_dim, beta=bool(cfg.beta), roughness=cfg.roughness, normal=cfg.normal, indirect_light=False, glossy_scale=1.0,
         sun_v="none", MultiBRDF=0, dim_RPV=cfg.dim_RPV, input_viewdir=int(cfg.input_viewdir), funcM=cfg.funcM, funcF=cfg.funcF, funcH=cfg.funcH,
         b=cfg.b, c=cfg.c, theta=cfg.theta, shell_hapke=0, hpk_scl=4.0, guided_samples=64, n_samples=64, n_importance=0,
         std_range=3.0, data="sat", sc_lambda=0.0, chunk=5120, noise_std=0.0, margin=1e-4, stdscale=1, fresnel_f0=0.04)
@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(bn_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
     L = _lib.lib()                       # dlopen; resolves every symbol or raises
-    assert L.bn_abi_version() == 2
+    assert L.bn_abi_version() == 3
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
@@ -105,7 +105,7 @@ def test_init_is_rng_order_identical_to_reference():
     kinds = {"lambert": dict(), "rpv111_anlr": dict(funcM=1, funcF=1, funcH=1, normal="analystic_learned"),
              "hapke_bct_nlr": dict(b=1, c=1, theta=1, normal="learned"), "microfacet_nlr": dict(roughness=True, normal="learned"),
              "relu_rpvM": dict(siren=False, funcM=1), "nomap": dict(mapping=False),
-             "viewdir": dict(input_viewdir=1)}
+             "viewdir": dict(input_viewdir=1), "beta_nlr": dict(beta=True, normal="learned", funcM=1)}
     for name, kw in kinds.items():
         cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16, **kw)
         torch.manual_seed(seed)
@@ -121,7 +121,7 @@ def test_init_is_rng_order_identical_to_reference():
 
 def test_unsupported_flags_raise():
     from brdf_nerf_amd import load_model
-    for over in (dict(beta=True), dict(sun_v="learned"), dict(indirect_light=True)):
+    for over in (dict(sun_v="learned"), dict(indirect_light=True)):
         with pytest.raises(NotImplementedError):
             load_model(make_args(FieldConfig(feat=64), **over))
     with pytest.raises(ValueError):

@@ -335,6 +335,63 @@ def test_render_rays_input_viewdir():
         assert float((got - torch.from_numpy(ref)).abs().max()) <= 2e-4 * scale + 1e-9, k
 
 
+@pytest.mark.parametrize("tag,kw", [("beta", dict(beta=True, funcM=1, funcF=1, funcH=1, normal="learned")),
+                                    ("beta_viewdir_relu", dict(beta=True, input_viewdir=1, siren=False, t_dim=6))])
+def test_field_beta(tag, kw):
+    """--beta (spsbrdfnerf.py:571-575,708-711): the transient-uncertainty channel after sigma; forward, parameter gradients
+    and the gradient w.r.t. the per-point embedding input against the reference."""
+    g = load_golden(f"field_{tag}_F64")
+    cfg = mini(**kw)
+    p = tparams(cfg, 15)
+    for v in p.values():
+        v.requires_grad_(True)
+    t_in = torch.from_numpy(g["t_in"]).requires_grad_(True)
+    out = F.field_forward(p, cfg, torch.from_numpy(g["xyz"]), apply_brdf=True, apply_theta=True, nr_lr_on=cfg.normal == "learned",
+                          dirs=torch.from_numpy(g["dirs"]), t_embed=t_in)
+    assert_close(out, g["out_brdf"], 1e-5, 1e-6, "out")
+    (out * torch.from_numpy(g["coef"])).sum().backward()
+    assert_close(t_in.grad, g["d_t_in"], 1e-4, 1e-7, "d_t_in")
+    for k, v in p.items():
+        ref = g[f"grad/{k}"]
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        got = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert float((got - torch.from_numpy(ref)).abs().max()) <= 1e-4 * scale + 1e-9, k
+
+
+def test_render_rays_beta():
+    """render_rays with --beta and models['t'](ts) (rendering.py:226-229), train mode; uncertainty_aware_loss
+    (metrics.py:24-28) reads beta_coarse; gradients of the parameters and of the embedding table."""
+    g = load_golden("render_beta_train")
+    cfg = mini(beta=True, funcM=1, funcF=1, funcH=1, normal="learned")
+    p = tparams(cfg, 11)
+    for v in p.values():
+        v.requires_grad_(True)
+    emb = torch.from_numpy(g["emb"]).requires_grad_(True)
+    rays_t = emb[torch.from_numpy(g["ts"])]
+    res, bt = RD.render_rays(p, cfg, torch.from_numpy(g["rays"]), RD.Randoms(replay=replay_list(g)), mode="train",
+                             apply_brdf=True, apply_theta=True, cos_irra_on=True, rays_t=rays_t)
+    assert bt == str(g["brdf_type"])
+    assert {k[4:] for k in g if k.startswith("out/")} == {k for k in res if not k.startswith("_")}
+    for k in sorted(k[4:] for k in g if k.startswith("out/")):
+        if k == "sort_idx_coarse":
+            assert (res[k].numpy() == g["out/" + k]).all()
+        else:
+            assert_close(res[k], g["out/" + k], 2e-5, 2e-6, k)
+    l_color, l_logbeta = L.uncertainty_aware_loss(res["rgb_coarse"], res["weights_coarse"], res["beta_coarse"],
+                                                  torch.from_numpy(g["targets"]))
+    assert_close(l_color, g["loss_color"], 1e-5, 1e-7, "loss_color")
+    assert_close(l_logbeta, g["loss_logbeta"], 1e-5, 1e-7, "loss_logbeta")
+    loss = l_color + l_logbeta + 0.01 * res["depth_coarse"].mean()
+    assert_close(loss, g["loss"], 1e-5, 1e-7, "loss")
+    loss.backward()
+    assert_close(emb.grad, g["d_emb"], 2e-4, 1e-7, "d_emb")
+    for k, v in p.items():
+        ref = g[f"grad/{k}"]
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        got = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert float((got - torch.from_numpy(ref)).abs().max()) <= 2e-4 * scale + 1e-9, k
+
+
 def test_regulariser_losses():
     g = load_golden("loss_regularisers")
     t = {k: torch.from_numpy(v) for k, v in g.items()}
