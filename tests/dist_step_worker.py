@@ -20,7 +20,8 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("BN_DIST_BACKEND", "gloo")      # "nccl" = RCCL: world 1 on the one-GPU box (one rank per device)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     import bench
     from oracle.config import FieldConfig
     from test_gpu_parity import make_args
@@ -62,7 +63,12 @@ def main():
 
     lo, hi = shard_bounds(R, rank, world)
     tr2 = run(lo, hi, True)
-    assert tr2.world == 2
+    assert tr2.world == world
+    if backend == "nccl":       # the product's collective on the product's buffer, through RCCL (sum over one rank: unchanged)
+        before = tr2.flat_grad.clone()      # (allreduce_sum_ skips the call at world 1: issue the same collective directly)
+        dist.all_reduce(tr2.flat_grad, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        assert dist.get_backend() == "nccl" and torch.equal(before, tr2.flat_grad)
     got = tr2.flat_grad / world                      # what Adam's grad_scale = 1 / world applied
     tr1 = run(0, R, False)
     assert tr1.world == 1

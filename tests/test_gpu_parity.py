@@ -1762,6 +1762,22 @@ def test_two_rank_step_matches_one_rank(name):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
 
 
+def test_rccl_initialises_and_reduces_the_flat_gradient():
+    """RCCL through this code on the one-GPU box: a world of ONE rank on backend nccl (RCCL refuses two ranks on one device)
+    runs the data-parallel FusedTrainer.step and `allreduce_sum_` on the flat gradient buffer; same worker, same checks as
+    the two-rank gloo case (the N > 1 RCCL runs are the driver's, bench.py --gpus N)."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_step_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", WORLD_SIZE="1", RANK="0", BN_DIST_CONFIG="lambert",
+               BN_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    for line in p.stdout.splitlines():
+        if line.startswith("RESULT"):
+            diag("rccl world 1: " + line)
+    assert p.returncode == 0, p.stdout
+
+
 def test_ray_table_on_device_feeds_the_fused_step():
     """the ray table lives in HBM, batches are gathers by a device permutation (no host round trip):
     every row exactly once per epoch, rank shards partition each global batch, the generator state resumes the stream, and
