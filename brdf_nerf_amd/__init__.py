@@ -10,5 +10,6 @@ The HIP library is mandatory: importing the compute entry points without it rais
 from .field import SpSBRDFNeRF, load_model  # noqa: F401
 from .rendering import render_rays, inference, get_z_vals, cal_weight  # noqa: F401
 from . import functions  # noqa: F401
+from ._lib import set_deterministic  # noqa: F401
 
-__all__ = ["SpSBRDFNeRF", "load_model", "render_rays", "inference", "get_z_vals", "cal_weight", "functions"]
+__all__ = ["SpSBRDFNeRF", "load_model", "render_rays", "inference", "get_z_vals", "cal_weight", "functions", "set_deterministic"]

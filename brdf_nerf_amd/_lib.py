@@ -59,6 +59,7 @@ _lib = None
 _SIGS = {
     "bn_abi_version": (C.c_int, []),
     "bn_last_error": (C.c_char_p, []),
+    "bn_set_deterministic": (C.c_int, [C.c_int]),
     "bn_field_packed_bytes": (C.c_size_t, [C.POINTER(FieldDesc)]),
     "bn_pack_field": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), fptr, fptr]),
     "bn_field_stash_bytes": (C.c_size_t, [C.POINTER(FieldDesc), C.c_int64]),
@@ -133,7 +134,16 @@ def lib():
     global _lib
     if _lib is None:
         _lib = load(LIB_PATH)
+        if os.environ.get("BRDFNERF_DETERMINISTIC", "0") not in ("", "0"):
+            _lib.bn_set_deterministic(1)
     return _lib
+
+
+def set_deterministic(on=True):
+    """Run-to-run reproducible parameter gradients (bn_set_deterministic; the reference's Trainer(deterministic=True),
+    main.py:726): the split weight-gradient sums are added in a fixed order.  Also switched on by BRDFNERF_DETERMINISTIC=1.
+    Returns the previous setting."""
+    return bool(lib().bn_set_deterministic(1 if on else 0))
 
 
 def use(handle):

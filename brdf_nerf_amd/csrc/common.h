@@ -39,6 +39,19 @@ int bn_configure_lds(const void *kernel, size_t lds, const char *what);
     }                                                                     \
   } while (0)
 
+#define BN_HIP_CHECK(call, what)                                          \
+  do {                                                                    \
+    hipError_t e_ = (call);                                               \
+    if (e_ != hipSuccess) {                                               \
+      bn_set_error("%s: %s", what, hipGetErrorString(e_));                \
+      return BN_ELAUNCH;                                                  \
+    }                                                                     \
+  } while (0)
+
+// bn_set_deterministic(): process-wide switch read by bn_field_backward (field_bwd.hip, det_enter)
+int bn_deterministic();
+#define BN_DET_TICKETS 4096      // turn counters per backward call: first half weight-gradient tiles, second half skinny jobs
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t bn_esize(int dtype) { return dtype == BN_F32 ? 4 : 2; }
 static inline bool bn_half(int dtype) { return dtype != BN_F32; }   // 16-bit throughput modes (bf16, fp16)

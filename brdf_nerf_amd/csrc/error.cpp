@@ -1,4 +1,5 @@
 // Thread-local error string of the C ABI (bn_last_error).
+#include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
 #include <hip/hip_runtime.h>
@@ -18,6 +19,10 @@ void bn_set_error(const char *fmt, ...) {
 
 extern "C" const char *bn_last_error(void) { return g_err; }
 extern "C" int bn_abi_version(void) { return BN_ABI_VERSION; }
+
+static std::atomic<int> g_deterministic{0};
+int bn_deterministic() { return g_deterministic.load(std::memory_order_relaxed); }
+extern "C" int bn_set_deterministic(int on) { return g_deterministic.exchange(on ? 1 : 0); }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of a kernel: remember what has been set for
 // (device, kernel) so that a second device in the same process gets its own call and concurrent callers do not race.

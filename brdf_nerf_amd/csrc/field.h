@@ -149,6 +149,7 @@ struct StashLayout {
   size_t gscale;                  // fp32 [2] as bits: max |d pre-activation| (primal chain), max |gbar_PE| (adjoint chain): fp16 loss scaling
   size_t sraw;                    // fp32 [Mpad]  pre-softplus sigma
   size_t nraw;                    // fp32 [Mpad][4] learned-normal pre-normalisation vector
+  size_t tickets;                 // u32 [BN_DET_TICKETS] turn counters of the deterministic mode (field_bwd.hip det_enter)
   size_t dpre_trunk;              // fp32 [Mpad][4]  (d sigma_raw, d normal_raw xyz)      (bwd-produced)
   size_t dpre_head;               // fp32 [Mpad][BN_DPH] (per head, 3 each)                   (bwd-produced)
   size_t pe;                      // T [Mpad][KP]
@@ -182,6 +183,7 @@ static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, in
   s->gscale = take(256);
   s->sraw = take((size_t)Mpad * 4);
   s->nraw = take((size_t)Mpad * 16);
+  s->tickets = take((size_t)BN_DET_TICKETS * 4);
   s->dpre_trunk = take((size_t)Mpad * 16);
   s->dpre_head = take((size_t)Mpad * BN_DPH * 4);
   s->pe = take((size_t)Mpad * g.KP * esz);

@@ -374,6 +374,40 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
 }
 
 // ------------------------------------------------------------------------------------------ weight gradients
+// ---- deterministic accumulation (bn_set_deterministic(1)) ---------------------------------------------------------------------
+// The weight-gradient kernels split the points over many workgroups that add their partial sums into the same fp32 output with
+// atomics: the order of those additions - and with it the last bits of the gradient - changes from run to run.  In deterministic
+// mode the workgroups that add into one output tile take TURNS in split order: a ticket per output tile (zeroed per call, in the
+// stash) counts the splits that have added; split s waits for ticket == s, adds (the same atomics), fences, and passes the turn.
+// Blocks are numbered split-major, and the hardware starts blocks in id order on every XCD, so the block a waiter depends on was
+// always started before it: the smallest unfinished id never waits.  Jobs that add into the same matrix (the primal and the
+// analytic-normal term of a trunk layer) go to separate, stream-ordered launches.  The spin is bounded; a timeout is reported
+// through bn_device_faults() (bit 1) and the block proceeds.
+__device__ unsigned int g_det_fault = 0u;
+__device__ __forceinline__ void det_enter(unsigned int *ticket, unsigned int seq) {
+  if (ticket == nullptr) return;
+  if (threadIdx.x == 0) {
+    unsigned int spins = 0;
+    while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+      __builtin_amdgcn_s_sleep(32);
+      if (++spins > (1u << 25)) { g_det_fault = 1u; break; }   // ~ 30 s: never in a correct run
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void det_leave(unsigned int *ticket) {
+  if (ticket == nullptr) return;
+  __threadfence();       // this workgroup's additions are performed before the next one's turn
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+unsigned int bn_bwd_fault_read(hipStream_t st) {   // (bn_device_faults, field_fwd.hip)
+  unsigned int v = 0u;
+  if (hipStreamSynchronize(st) != hipSuccess) return 0x80000000u;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_det_fault), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) return 0x80000000u;
+  return v;
+}
+
 struct WgradJob {
   const void *A;   // [Mpad][lda] T : gradient rows (dZ / dFeats / dG)
   const void *B;   // [Mpad][ldb] T : layer input rows (PE / Y / feats)
@@ -400,6 +434,7 @@ struct WgradArgs {
   int64_t Mpad;
   int m_per_block;                   // points per split (multiple of 32)
   const float *amax;                 // fp16 mode only (else nullptr): see wg_unscale
+  unsigned int *tickets;             // deterministic mode: one turn counter per output tile of this launch (else nullptr)
 };
 
 #define WG_BK 32
@@ -490,6 +525,8 @@ template <typename T> __global__ __launch_bounds__(256) void wgrad_kernel(const 
   }
   // C[n][k]: accumulator row index = n (A operand rows), column (lane&31) = k
   const int r = lane & 31, h = lane >> 5;
+  unsigned int *ticket = A.tickets ? A.tickets + blockIdx.x : nullptr;
+  det_enter(ticket, blockIdx.y);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -502,6 +539,7 @@ template <typename T> __global__ __launch_bounds__(256) void wgrad_kernel(const 
       }
     }
   if (do_bias && n0 + tid < J.N) atomicAdd(J.bias + n0 + tid, bsum);
+  det_leave(ticket);
 }
 
 // ---- bf16 throughput variant: 256(n) x 256(k) output tile per 8-wave workgroup, 32-point stages double-buffered in
@@ -555,8 +593,9 @@ template <typename T> __device__ __forceinline__ typename Elem<T>::frag w2_frag(
 // One 256 x 256 output tile over the points [mb, me).  NBV = 32-column accumulator tiles this WAVE multiplies (4 for a
 // full tile; the 60-column positional-encoding operand only has columns for two tiles of the wc = 0 waves - the other
 // waves of such a block just take part in staging and barriers).
-template <typename T, int NBV, bool BNAT>
-__device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64_t mb, int64_t me, T *sA, T *sB, float osc) {
+template <typename T, int NBV, bool BNAT, bool DET>
+__device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64_t mb, int64_t me, T *sA, T *sB, float osc,
+                                        unsigned int *ticket, unsigned int seq) {
   typedef typename Elem<T>::frag frag_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
   const T *gA = (const T *)J.A + J.a_col0 + n0;
@@ -711,6 +750,7 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
     buf ^= 1;
   }
   const int r = lane & 31, h = lane >> 5;
+  if constexpr (DET) det_enter(ticket, seq);
 #pragma unroll
   for (int a = 0; a < W2_RA; ++a)
 #pragma unroll
@@ -730,18 +770,21 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
       if (h == 0 && n < J.N) atomicAdd(J.bias + n, v);
     }
   }
+  if constexpr (DET) det_leave(ticket);
   WG_PH(4)
   WG_PH_FLUSH
 }
 
-template <typename T>
+// DET (deterministic mode) is a template parameter: as a run-time branch it cost the default kernel 3 % (profiles/r02_ablation.txt)
+template <typename T, bool DET>
 __global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256_kernel(const WgradArgs A, int n_split, int n_blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem_w[];
   T *sA = (T *)smem_w;                 // [2][W2_BK][W2_LD]
   T *sB = sA + 2 * W2_STAGE;
   // XCD-aware id: hardware deals consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous range
+  // (deterministic mode: ids in dispatch order, see det_enter - the tiles of a split then sit on different XCDs)
   const int per = n_blocks / 8;              // n_blocks is a multiple of 8
-  const int lid = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  const int lid = DET ? (int)blockIdx.x : (int)((blockIdx.x % 8) * per + blockIdx.x / 8);
   const int total_tiles = A.tile0[A.n_jobs];
   if (lid >= total_tiles * n_split) return;
   const int split = lid / total_tiles, tt = lid % total_tiles;
@@ -757,17 +800,18 @@ __global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256
   const int wc = (threadIdx.x >> 6) & 1;
   const int cols = J.K - k0 - wc * 128;          // output columns this wave's tiles can reach
   const float osc = wg_unscale(A.amax, J.scale_sel);
+  unsigned int *ticket = DET ? A.tickets + tt : nullptr;
 #ifdef BN_CLOCK_STAMP_WGRAD
   BN_CLK_BEGIN
 #endif
   if (J.b_native) {     // layer-output operand in native order: full-width column blocks only (F is a multiple of 64)
-    if (cols >= 65) w2_body<T, 4, true>(J, n0, k0, mb, me, sA, sB, osc);
-    else if (cols >= 33) w2_body<T, 2, true>(J, n0, k0, mb, me, sA, sB, osc);
-    else w2_body<T, 0, true>(J, n0, k0, mb, me, sA, sB, osc);
-  } else if (cols >= 65) w2_body<T, 4, false>(J, n0, k0, mb, me, sA, sB, osc);
-  else if (cols >= 33) w2_body<T, 2, false>(J, n0, k0, mb, me, sA, sB, osc);
-  else if (cols >= 1) w2_body<T, 1, false>(J, n0, k0, mb, me, sA, sB, osc);
-  else w2_body<T, 0, false>(J, n0, k0, mb, me, sA, sB, osc);
+    if (cols >= 65) w2_body<T, 4, true, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
+    else if (cols >= 33) w2_body<T, 2, true, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
+    else w2_body<T, 0, true, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
+  } else if (cols >= 65) w2_body<T, 4, false, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
+  else if (cols >= 33) w2_body<T, 2, false, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
+  else if (cols >= 1) w2_body<T, 1, false, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
+  else w2_body<T, 0, false, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
 #ifdef BN_CLOCK_STAMP_WGRAD
   BN_CLK_END
 #endif
@@ -791,6 +835,7 @@ struct SkinnyArgs {
   int64_t Mpad;
   int m_per_block;
   const float *amax;
+  unsigned int *tickets;   // deterministic mode: one turn counter per job of this launch (else nullptr), see det_enter
 };
 
 template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const SkinnyArgs A) {
@@ -848,8 +893,15 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
 #pragma unroll
           for (int gp = 0; gp < 2; ++gp)
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              atomicAdd(&red[c * 512 + cb * 32 + 16 * gp + 4 * h + (e & 3) + 8 * (e >> 2)], s[gp][c][e]);   // LDS, 32-way
+            for (int e = 0; e < 8; ++e) {
+              float *dst = &red[c * 512 + cb * 32 + 16 * gp + 4 * h + (e & 3) + 8 * (e >> 2)];
+              if (A.tickets) {          // deterministic mode: a fixed butterfly over the 32 points instead of 32-way LDS atomics
+                float v = s[gp][c][e];
+#pragma unroll
+                for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                if (r == 0) *dst = v;   // (column blocks of different waves are disjoint)
+              } else atomicAdd(dst, s[gp][c][e]);   // LDS, 32-way
+            }
         }
       if (cb == 0) {   // the bias gradient is the dpre column sum: taken from the pass over the head's first column block
 #pragma unroll
@@ -861,7 +913,14 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
     if (wv == 0 && h == 0) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if (c < J.nc) atomicAdd(&red[4 * 512 + c], bs0[c]);
+        if (c < J.nc) {
+          if (A.tickets) {
+            float v = bs0[c];
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+            if (r == 0) red[4 * 512 + c] = v;
+          } else atomicAdd(&red[4 * 512 + c], bs0[c]);
+        }
     }
   } else {
   const T *X = (const T *)J.X + J.x_col0;
@@ -889,8 +948,21 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
       }
     }
   }
-  // row groups meet in LDS (nrg-way LDS atomics)
-  if (rg < nrg) {
+  // row groups meet in LDS (nrg-way LDS atomics; deterministic mode: the row groups add one after the other)
+  if (A.tickets) {
+    for (int turn = 0; turn < nrg; ++turn) {
+      if (rg == turn) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < J.nc) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[c * 512 + cg * 8 + e] += s[c][e];
+            if (cg == 0) red[4 * 512 + c] += bs[c];
+          }
+      }
+      __syncthreads();
+    }
+  } else if (rg < nrg) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       if (c < J.nc) {
@@ -903,11 +975,14 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
   // ONE global atomic per output element per block (same-address atomics from thousands of adders serialise at the
   // memory side)
   __syncthreads();
+  unsigned int *ticket = A.tickets ? A.tickets + blockIdx.y : nullptr;
+  det_enter(ticket, blockIdx.x);
   for (int i = tid; i < J.nc * J.K; i += 256) {
     const int c = i / J.K, k = i % J.K;
     atomicAdd(J.out[c] + k, red[c * 512 + k] * osc);
   }
   if (tid < J.nc && J.bias[tid]) atomicAdd(J.bias[tid], red[4 * 512 + tid]);   // bias sums come from the unscaled fp32 dpre
+  det_leave(ticket);
 }
 
 template <typename T, int MT, int NT, int WAVES> static int launch_bwd(const BwdArgs &a, int64_t tiles, hipStream_t st) {
@@ -1021,43 +1096,81 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     add(S + sl.dG[0], g.pass_N[0], g.H2, S + sl.dirpe, g.KD, g.KT0, G->head1_wt, (int)G->head1_wt_ld, nullptr, g.H2, g.TD);
   }
   BN_REQUIRE(w.n_jobs <= BN_MAX_WGRAD_JOBS, "field_backward: too many wgrad jobs");
-  if (bf && w.n_jobs > 0) {
-    // 256 x 256 tiles, one 8-wave workgroup per CU: size the point splits for ~4 workgroups per CU in total
-    for (int j = 0; j < w.n_jobs; ++j)
-      w.tile0[j + 1] = w.tile0[j] + ((w.job[j].N + 255) / 256) * ((w.job[j].K + 255) / 256);
-    const int tiles = w.tile0[w.n_jobs];
+  // deterministic mode (det_enter): turn counters in the stash, zeroed per call
+  const bool det = bn_deterministic() != 0;
+  unsigned int *tickets = det ? (unsigned int *)(S + sl.tickets) : nullptr;
+  unsigned int tk_used = 0;
+  if (det) BN_HIP_CHECK(hipMemsetAsync(tickets, 0, BN_DET_TICKETS * sizeof(unsigned int), st), "field_backward: ticket memset");
+  auto launch_wgrad = [&](WgradArgs &wv, unsigned int *tk) -> int {
+    if (wv.n_jobs == 0) return 0;
+    wv.tickets = tk;
+    if (bf) {
+      // 256 x 256 tiles, one 8-wave workgroup per CU: size the point splits for ~4 workgroups per CU in total
+      for (int j = 0; j < wv.n_jobs; ++j)
+        wv.tile0[j + 1] = wv.tile0[j] + ((wv.job[j].N + 255) / 256) * ((wv.job[j].K + 255) / 256);
+      const int tiles = wv.tile0[wv.n_jobs];
 #ifndef W2_BLOCKS
 #define W2_BLOCKS 512   // tiles x point splits <= two rounds of the 256 CUs (one 144 KB workgroup per CU): 1024 -> 1.295 ms, 512 -> 1.253, 256 -> 1.290
 #endif
-    int64_t n_split = W2_BLOCKS / tiles;
-    if (n_split < 1) n_split = 1;
-    int64_t mpb2 = ceil_div64(ceil_div64(sl.Mpad, n_split), W2_BK) * W2_BK;
-    if (mpb2 < 512) mpb2 = 512;
-    n_split = ceil_div64(sl.Mpad, mpb2);
-    w.m_per_block = (int)mpb2;
-    const int n_blocks = (int)ceil_div64((int64_t)tiles * n_split, 8) * 8;
-    const size_t lds = (size_t)4 * W2_STAGE * 2;
-    const void *kfn = f16m ? (const void *)wgrad256_kernel<f16> : (const void *)wgrad256_kernel<bf16>;
-    if (int e = bn_configure_lds(kfn, lds, "wgrad256")) return e;
-    {
+      int64_t n_split = W2_BLOCKS / tiles;
+      if (n_split < 1) n_split = 1;
+      int64_t mpb2 = ceil_div64(ceil_div64(sl.Mpad, n_split), W2_BK) * W2_BK;
+      if (mpb2 < 512) mpb2 = 512;
+      n_split = ceil_div64(sl.Mpad, mpb2);
+      wv.m_per_block = (int)mpb2;
+      const int n_blocks = (int)ceil_div64((int64_t)tiles * n_split, 8) * 8;
+      const size_t lds = (size_t)4 * W2_STAGE * 2;
+      const void *kfn = tk ? (f16m ? (const void *)wgrad256_kernel<f16, true> : (const void *)wgrad256_kernel<bf16, true>)
+                           : (f16m ? (const void *)wgrad256_kernel<f16, false> : (const void *)wgrad256_kernel<bf16, false>);
+      if (int e = bn_configure_lds(kfn, lds, "wgrad256")) return e;
       BnProfScope prof_(BN_K_WGRAD, st);
-      if (f16m) wgrad256_kernel<f16><<<dim3((unsigned)n_blocks), W2_WAVES * 64, lds, st>>>(w, (int)n_split, n_blocks);
-      else wgrad256_kernel<bf16><<<dim3((unsigned)n_blocks), W2_WAVES * 64, lds, st>>>(w, (int)n_split, n_blocks);
+      const dim3 grd((unsigned)n_blocks), blk(W2_WAVES * 64);
+      if (tk) {
+        if (f16m) wgrad256_kernel<f16, true><<<grd, blk, lds, st>>>(wv, (int)n_split, n_blocks);
+        else wgrad256_kernel<bf16, true><<<grd, blk, lds, st>>>(wv, (int)n_split, n_blocks);
+      } else {
+        if (f16m) wgrad256_kernel<f16, false><<<grd, blk, lds, st>>>(wv, (int)n_split, n_blocks);
+        else wgrad256_kernel<bf16, false><<<grd, blk, lds, st>>>(wv, (int)n_split, n_blocks);
+      }
       BN_LAUNCH_CHECK("wgrad256");
+      return 0;
     }
-    w.n_jobs = 0;  // done
-  }
-  // fp32 parity path: 128 x 128 tiles; split the points so that the grid has a few thousand workgroups
-  int64_t splits = 2048 / (w.tile0[w.n_jobs] > 0 ? w.tile0[w.n_jobs] : 1);
-  if (splits < 1) splits = 1;
-  int64_t mpb = ceil_div64(ceil_div64(sl.Mpad, splits), WG_BK) * WG_BK;
-  if (mpb < 256) mpb = 256;
-  w.m_per_block = (int)mpb;
-  if (w.n_jobs > 0) {
-    dim3 grid((unsigned)w.tile0[w.n_jobs], (unsigned)ceil_div64(sl.Mpad, mpb));
+    // fp32 parity path: 128 x 128 tiles; split the points so that the grid has a few thousand workgroups
+    for (int j = 0; j < wv.n_jobs; ++j)
+      wv.tile0[j + 1] = wv.tile0[j] + ((wv.job[j].N + 127) / 128) * ((wv.job[j].K + 127) / 128);
+    int64_t splits = 2048 / (wv.tile0[wv.n_jobs] > 0 ? wv.tile0[wv.n_jobs] : 1);
+    if (splits < 1) splits = 1;
+    int64_t mpb = ceil_div64(ceil_div64(sl.Mpad, splits), WG_BK) * WG_BK;
+    if (mpb < 256) mpb = 256;
+    wv.m_per_block = (int)mpb;
+    dim3 grid((unsigned)wv.tile0[wv.n_jobs], (unsigned)ceil_div64(sl.Mpad, mpb));
     BnProfScope prof_(BN_K_WGRAD, st);
-    wgrad_kernel<float><<<grid, 256, 0, st>>>(w);     // bf16 jobs were consumed by wgrad256_kernel above
+    wgrad_kernel<float><<<grid, 256, 0, st>>>(wv);
     BN_LAUNCH_CHECK("wgrad");
+    return 0;
+  };
+  if (!det) {
+    if (int e = launch_wgrad(w, nullptr)) return e;
+  } else {
+    // jobs that add into the same matrix (same C: the primal and the analytic-normal term of a trunk layer) take separate,
+    // stream-ordered launches, each job list in its original order
+    bool left[BN_MAX_WGRAD_JOBS];
+    for (int j = 0; j < w.n_jobs; ++j) left[j] = true;
+    for (int n_left = w.n_jobs; n_left > 0;) {
+      WgradArgs gen = w;
+      gen.n_jobs = 0; gen.tile0[0] = 0;
+      for (int j = 0; j < w.n_jobs; ++j) {
+        if (!left[j]) continue;
+        bool clash = false;
+        for (int q = 0; q < gen.n_jobs; ++q) clash = clash || gen.job[q].C == w.job[j].C;
+        if (clash) continue;
+        gen.job[gen.n_jobs++] = w.job[j];
+        left[j] = false; --n_left;
+      }
+      if (int e = launch_wgrad(gen, tickets + tk_used)) return e;
+      tk_used += (unsigned int)gen.tile0[gen.n_jobs];
+      BN_REQUIRE(tk_used <= BN_DET_TICKETS / 2, "field_backward: too many output tiles for the deterministic mode");
+    }
   }
   SkinnyArgs s;
   s.n_jobs = 0; s.Mpad = sl.Mpad; s.amax = amax;
@@ -1097,14 +1210,45 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
 #ifndef SKINNY_SPLITS
 #define SKINNY_SPLITS 256   // 512: 0.129 ms, 256: 0.102 ms, 128: 0.169 ms per launch (the per-block LDS + global atomics tail vs parallelism)
 #endif
-    int64_t smpb = ceil_div64(ceil_div64(sl.Mpad, SKINNY_SPLITS), BM) * BM;   // whole tiles per block (native jobs walk tile images)
+    // deterministic mode: the splits of a job add one after the other (~3.5 us a turn): 64 instead of 256 (0.94 -> see
+    // profiles/r02_ablation.txt)
+    const int skinny_splits = det ? 64 : SKINNY_SPLITS;
+    int64_t smpb = ceil_div64(ceil_div64(sl.Mpad, skinny_splits), BM) * BM;   // whole tiles per block (native jobs walk tile images)
     s.m_per_block = (int)smpb;
-    dim3 grid((unsigned)ceil_div64(sl.Mpad, smpb), (unsigned)s.n_jobs);
-    BnProfScope prof_(BN_K_SKINNY, st);
-    if (f16m) skinny_wgrad_kernel<f16><<<grid, 256, 0, st>>>(s);
-    else if (bf) skinny_wgrad_kernel<bf16><<<grid, 256, 0, st>>>(s);
-    else skinny_wgrad_kernel<float><<<grid, 256, 0, st>>>(s);
-    BN_LAUNCH_CHECK("skinny_wgrad");
+    auto launch_skinny = [&](SkinnyArgs &sv, unsigned int *tk) -> int {
+      if (sv.n_jobs == 0) return 0;
+      sv.tickets = tk;
+      dim3 grid((unsigned)ceil_div64(sl.Mpad, smpb), (unsigned)sv.n_jobs);
+      BnProfScope prof_(BN_K_SKINNY, st);
+      if (f16m) skinny_wgrad_kernel<f16><<<grid, 256, 0, st>>>(sv);
+      else if (bf) skinny_wgrad_kernel<bf16><<<grid, 256, 0, st>>>(sv);
+      else skinny_wgrad_kernel<float><<<grid, 256, 0, st>>>(sv);
+      BN_LAUNCH_CHECK("skinny_wgrad");
+      return 0;
+    };
+    if (!det) {
+      if (int e = launch_skinny(s, nullptr)) return e;
+    } else {     // same rule as above: two jobs that add into the same row (sigma_w: primal and analytic-normal term) never share a launch
+      bool left[BN_MAX_SKINNY_JOBS];
+      for (int j = 0; j < s.n_jobs; ++j) left[j] = true;
+      unsigned int tk2 = BN_DET_TICKETS / 2;
+      for (int n_left = s.n_jobs; n_left > 0;) {
+        SkinnyArgs gen = s;
+        gen.n_jobs = 0;
+        for (int j = 0; j < s.n_jobs; ++j) {
+          if (!left[j]) continue;
+          bool clash = false;
+          for (int q = 0; q < gen.n_jobs; ++q)
+            for (int c = 0; c < 4; ++c)
+              for (int c2 = 0; c2 < 4; ++c2) clash = clash || (s.job[j].out[c] && gen.job[q].out[c2] == s.job[j].out[c]);
+          if (clash) continue;
+          gen.job[gen.n_jobs++] = s.job[j];
+          left[j] = false; --n_left;
+        }
+        if (int e = launch_skinny(gen, tickets + tk2)) return e;
+        tk2 += (unsigned int)gen.n_jobs;
+      }
+    }
   }
   if (g.TD > 0 && G->d_t_embed) {   // gradient of the beta head's embedding input, per point
     BN_REQUIRE(params->head1_wt && params->head1_wt_ld >= g.TD && g.H2 <= 256, "field_backward: head1_wt missing (beta)");

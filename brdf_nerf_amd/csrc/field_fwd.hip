@@ -789,6 +789,8 @@ template <typename T, int MT, int NT, int WAVES, bool KEEP, bool DIR> static int
 // 0: no fault seen so far (asynchronous view: what the last mirrored copy showed)
 int bn_fwd_fault_seen() { return g_fwd_fault_host && *g_fwd_fault_host != 0u; }
 
+unsigned int bn_bwd_fault_read(hipStream_t st);   // field_bwd.hip: 1 = a deterministic-mode turn wait timed out
+
 extern "C" int bn_device_faults(unsigned int *faults, void *stream) {
   BN_REQUIRE(faults, "device_faults: null argument");
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
@@ -796,6 +798,9 @@ extern "C" int bn_device_faults(unsigned int *faults, void *stream) {
     bn_set_error("device_faults: cannot read the fault word");
     return BN_ELAUNCH;
   }
+  const unsigned int b = bn_bwd_fault_read((hipStream_t)stream);
+  if (b & 0x80000000u) { bn_set_error("device_faults: cannot read the backward fault word"); return BN_ELAUNCH; }
+  *faults = (*faults != 0u ? 1u : 0u) | (b ? 2u : 0u);      // bit 0: forward hand-over lost; bit 1: deterministic turn timed out
   return 0;
 }
 

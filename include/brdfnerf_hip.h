@@ -55,6 +55,12 @@ typedef enum {
 
 int bn_abi_version(void);
 const char *bn_last_error(void);
+/* Run-to-run reproducible parameter gradients (the reference trains with Lightning's deterministic=True, main.py:726).
+ * The weight-gradient kernels of bn_field_backward split the points over workgroups that add fp32 partial sums with
+ * atomics; on = 1 makes the workgroups of one output tile add in a fixed order (a turn counter per tile): bitwise
+ * identical gradients for identical inputs, for 13-16 % of a training step (profiles/r02_ablation.txt).  Process-wide; returns
+ * the old value. */
+int bn_set_deterministic(int on);
 
 /* ---------------------------------------------------------------------------------------------
  * Field MLP (SpSBRDFNeRF.forward, models/spsbrdfnerf.py:662-757; calc_features :636-646;
@@ -268,7 +274,8 @@ int bn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
 int bn_count_nonfinite(const float *x, int64_t n, unsigned long long *counts, void *stream);
 
 /* Device-side fault word of the fused kernels (bit 0: a wave of the barrier-free forward trunk gave up waiting for an LDS
- * hand-over - never in a correct run; the affected launch's results are invalid).  The library mirrors the word to the
+ * hand-over - never in a correct run; the affected launch's results are invalid; bit 1: a workgroup of the deterministic
+ * mode gave up waiting for its turn - its sums were still added, only the order is not the fixed one).  The library mirrors the word to the
  * host asynchronously and fails the NEXT bn_field_* call with BN_ELAUNCH once it is set; this call synchronises `stream`
  * and reads it directly. */
 int bn_device_faults(unsigned int *faults, void *stream);

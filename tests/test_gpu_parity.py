@@ -1022,6 +1022,40 @@ def test_field_beta_half_tracks_fp32(dtype):
 
 
 
+def test_field_everything_on_against_oracle():
+    """The widest head set: --beta + --input_viewdir + RPV funcM/F/H + analytic AND learned normals (20 output channels,
+    five heads in three passes, both extra-input segments, the double backward through the analytic normals), F=128, ragged
+    point count, against the oracle (autograd with create_graph=True): outputs, every parameter gradient, d/d t_embed."""
+    cfg = mini(feat=128, beta=True, input_viewdir=1, funcM=1, funcF=1, funcH=1, normal="analystic_learned")
+    flags = dict(apply_brdf=True, apply_theta=True, nr_an_on=True, nr_lr_on=True)
+    model = build_model(cfg, 21)
+    p = tparams(cfg, 21)
+    for v in p.values():
+        v.requires_grad_(True)
+    g = torch.Generator().manual_seed(77)
+    B = 333
+    xyz = torch.rand(B, 3, generator=g) * 2 - 1
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    t_ref = torch.randn(B, cfg.t_dim, generator=g).requires_grad_(True)
+    ref = OF.field_forward(p, cfg, xyz, dirs=dirs, t_embed=t_ref, **flags)
+    assert ref.shape[1] == 20
+    coef = torch.randn(ref.shape, generator=g)
+    (ref * coef).sum().backward()
+    t_gpu = t_ref.detach().to(DEV).requires_grad_(True)
+    out = model(xyz.to(DEV), input_dir=dirs.to(DEV), input_t=t_gpu, **flags)
+    assert_close(out, ref, 2e-4, 2e-5, "out")
+    (out * coef.to(DEV)).sum().backward()
+    scale = float(t_ref.grad.abs().max())
+    assert float((t_gpu.grad.cpu() - t_ref.grad).abs().max()) <= 2e-4 * scale, "d_t_embed"
+    for k, v in model.named_parameters():
+        want = p[k].grad
+        scale = float(want.abs().max())
+        err = float((v.grad.cpu() - want).abs().max())
+        diag(f"field_everything_on {k}: err {err:.3e} scale {scale:.3e}")
+        assert err <= 1e-3 * scale + 1e-7, f"{k}: err {err:.3e} scale {scale:.3e}"
+
+
+
 # ------------------------------------------------------------------------------------------------ fused trainer
 @pytest.mark.parametrize("name,with_depth", [("lambert", False), ("lambert", True), ("rpv111_nlr", True), ("rpv111_nan", False),
                                              ("rpv111_nlr_multibrdf", False), ("hapke_bct_multibrdf", True),
@@ -1808,6 +1842,52 @@ def test_ray_table_on_device_feeds_the_fused_step():
     b = t.next_batch(64)
     loss, rgb = tr.step(b["rays"], b["rgbs"], valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"])
     assert rgb.shape == (64, 3) and bool(torch.isfinite(loss)) and bool(torch.isfinite(tr.flat_grad).all())
+
+
+@pytest.mark.parametrize("name,dtype,feat,R", [("lambert", "bf16", 512, 1024), ("rpv_nan", "bf16", 512, 512), ("rpv_nan", "fp16", 256, 512),
+                                               ("hapke_nlr", "fp32", 64, 256)])
+def test_deterministic_mode_gives_bitwise_identical_gradients(name, dtype, feat, R):
+    """set_deterministic(True) (the reference trains with deterministic=True, main.py:726): two fused training steps from
+    the same state, batch and draws produce BITWISE identical flat gradients and parameters - the split weight-gradient
+    sums take turns per output tile (field_bwd.hip det_enter) - and they agree with the default atomic-order mode to
+    rounding.  Covers many point splits per tile (F=512), the second launch generation of the analytic-normal terms, the
+    native and row-major skinny jobs and the fp32 kernels; the device fault word (turn time-outs) stays clear."""
+    import brdf_nerf_amd
+    from brdf_nerf_amd import _lib
+    from brdf_nerf_amd.trainer import FusedTrainer
+    import ctypes as C
+    kw = {"lambert": dict(), "rpv_nan": dict(funcM=1, funcF=1, funcH=1, normal="analystic"),
+          "hapke_nlr": dict(b=1, c=1, theta=1, normal="learned")}[name]
+    cfg = FieldConfig(feat=feat, n_samples=32, guided_samples=32, **kw)
+    args = make_args(cfg, dtype)
+    flags = dict() if name == "lambert" else dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)
+    import bench
+    b = bench.synthetic_batch(R, 5, torch.device(DEV))
+    rays, rgbs = b["rays"], b["rgbs"]
+
+    def run(det):
+        prev = brdf_nerf_amd.set_deterministic(det)
+        try:
+            torch.manual_seed(3)
+            model = build_model(cfg, 11, dtype)
+            tr = FusedTrainer(model, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+            tr.step(rays, rgbs, valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"], near_far=(0.0, 2.0),
+                    **flags)
+            torch.cuda.synchronize()
+            return tr.flat_grad.clone(), tr.flat_param.clone()
+        finally:
+            brdf_nerf_amd.set_deterministic(prev)
+
+    g1, p1 = run(True)
+    g2, p2 = run(True)
+    assert torch.equal(g1, g2) and torch.equal(p1, p2), f"max diff {float((g1 - g2).abs().max()):.3e}"
+    g0, _ = run(False)
+    scale = float(g0.abs().max())
+    diag(f"deterministic {name} {dtype} F={feat}: |det - atomic| max {float((g1 - g0).abs().max()):.3e} of {scale:.3e}")
+    assert float((g1 - g0).abs().max()) <= 2e-4 * scale
+    faults = C.c_uint(0)
+    _lib.check(_lib.lib().bn_device_faults(C.byref(faults), None), "bn_device_faults")
+    assert faults.value == 0
 
 
 def test_count_nonfinite_hook():
