@@ -144,7 +144,7 @@ def source_hash():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "brdf_nerf_amd", "csrc")
     files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".cpp")))
-    for f in files + [os.path.join(ROOT, "include", "brdfnerf_hip.h")]:
+    for f in files + [os.path.join(ROOT, "include", "brdfnerf_hip.h"), os.path.join(ROOT, "brdf_nerf_amd", "build.py")]:   # (per-file compiler flags)
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

@@ -30,13 +30,23 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(verbose=False, force=False, defines=(), out=None):
-    """defines/out: build a VARIANT library (A/B experiments, profiles/): objects go to build/<tag>/, the result to `out`;
-    load it with BRDFNERF_HIP_LIB=<out>."""
-    variant = bool(defines) or out is not None
+# extra hipcc flags per source file (basename), on top of FLAGS.  The weight-gradient kernels gain from the max-ILP machine
+# scheduler (fp16 256-tile kernel -13 %, skinny kernel -16 % with analytic normals); the chain kernels lose 1-6 % with it
+# (profiles/r02_ablation.txt, session 24) - hence their own translation unit.
+# The backward chain and the analytic-normal chains gain 1-3 % from the AMDGPU register-pressure trackers in the scheduler (the
+# forward loses 2-7 % with them, the weight-gradient kernels 2-20 %: session 25).
+_TRACKERS = ("-mllvm", "-amdgpu-use-amdgpu-trackers=1")
+FILE_FLAGS = {"field_wgrad.hip": ("-mllvm", "-amdgpu-sched-strategy=max-ilp"),
+              "field_bwd.hip": _TRACKERS, "field_adjoint.hip": _TRACKERS, "field_adjbwd.hip": _TRACKERS}
+
+
+def build(verbose=False, force=False, defines=(), out=None, extra_flags=(), tag=None):
+    """defines/out/extra_flags/tag: build a VARIANT library (A/B experiments, profiles/): objects go to build/<tag>/, the result
+    to `out`; load it with BRDFNERF_HIP_LIB=<out>.  extra_flags: hipcc flags for every file (e.g. -mllvm options)."""
+    variant = bool(defines) or out is not None or bool(extra_flags)
     if not variant and not force and not needs_build():
         return LIB
-    tag = "_".join(d.replace("=", "-") for d in defines) or "default"
+    tag = tag or "_".join(d.replace("=", "-") for d in defines) or "default"
     objdir = os.path.join(HERE, "build", tag) if variant else os.path.join(HERE, "build")
     out = out or (os.path.join(objdir, "libbrdfnerf_hip.so") if variant else LIB)
     os.makedirs(objdir, exist_ok=True)
@@ -47,10 +57,12 @@ def build(verbose=False, force=False, defines=(), out=None):
         objs.append(obj)
         if os.path.exists(obj) and not force:
             hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
-            hdr_t = max(hdr_t, os.path.getmtime(os.path.join(ROOT, "include", "brdfnerf_hip.h")))
+            hdr_t = max(hdr_t, os.path.getmtime(os.path.join(ROOT, "include", "brdfnerf_hip.h")),
+                        os.path.getmtime(os.path.abspath(__file__)))          # (this file holds the per-file compiler flags)
             if os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
                 continue
-        cmd = [HIPCC] + FLAGS + ["-D" + d for d in defines] + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + list(FILE_FLAGS.get(os.path.basename(src), ())) + list(extra_flags) + ["-D" + d for d in defines] + \
+            ["-x", "hip", "-c", src, "-o", obj]
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd))
@@ -74,4 +86,7 @@ def build(verbose=False, force=False, defines=(), out=None):
 if __name__ == "__main__":
     defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
     outs = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")]
-    print(build(verbose="--verbose" in sys.argv, force="--force" in sys.argv, defines=defs, out=outs[0] if outs else None))
+    xf = [w for a in sys.argv[1:] if a.startswith("--flags=") for w in a.split("=", 1)[1].split()]
+    tags = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--tag=")]
+    print(build(verbose="--verbose" in sys.argv, force="--force" in sys.argv, defines=defs, out=outs[0] if outs else None,
+                extra_flags=xf, tag=tags[0] if tags else None))

@@ -30,7 +30,7 @@ def main():
         for src in B.sources():
             if not src.endswith(".hip"):
                 continue
-            cmd = [B.HIPCC] + B.FLAGS + ["-D" + d for d in defs] + ["-x", "hip", "-c", src, "-o", os.path.join(td, os.path.basename(src) + ".o"),
+            cmd = [B.HIPCC] + B.FLAGS + list(B.FILE_FLAGS.get(os.path.basename(src), ())) + ["-D" + d for d in defs] + ["-x", "hip", "-c", src, "-o", os.path.join(td, os.path.basename(src) + ".o"),
                                                                    "-Rpass-analysis=kernel-resource-usage"]
             procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         for p in procs:

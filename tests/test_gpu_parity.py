@@ -1656,7 +1656,7 @@ def _learnable_table(n_rays, seed):
 RPV_NAN = dict(funcM=1, funcF=1, funcH=1, normal="analystic")
 
 
-def _psnr_run(cfg, dtype, n_pre, n_brdf, train, held, draw_seed, init_state=None, lr0=5e-4):
+def _psnr_run(cfg, dtype, n_pre, n_brdf, train, held, draw_seed, init_state=None, lr0=5e-4, adam=None, keep_adam=None):
     """One training run of the PSNR gates: each stage (Lambertian pretraining, then the BRDF stage: the reference trains them
     as two runs, README.md:100-132) decays its learning rate from 5e-4 to 0 on a cosine, so the end state does not ride on
     the slope of a still-climbing curve; depth supervision during the pretraining only (--ds_drop, main.py:264).
@@ -1671,6 +1671,8 @@ def _psnr_run(cfg, dtype, n_pre, n_brdf, train, held, draw_seed, init_state=None
     if init_state is not None:
         model.load_state_dict(init_state)
     tr = FusedTrainer(model, args, lr=lr0, ds_lambda=10.0, strict_rng=False)
+    if adam is not None:          # continue a run: the optimiser's moments and step counts come along (same flat layout in every mode)
+        tr.exp_avg.copy_(adam["exp_avg"]); tr.exp_avg_sq.copy_(adam["exp_avg_sq"]); tr.adam_steps.update(adam["adam_steps"])
     train.load_state_dict({"gen": torch.Generator(device=DEV).manual_seed(5).get_state(), "perm": None, "cursor": 0, "epoch": 0})
     torch.manual_seed(draw_seed)
     first = None
@@ -1688,6 +1690,8 @@ def _psnr_run(cfg, dtype, n_pre, n_brdf, train, held, draw_seed, init_state=None
     res = render_image({"coarse": model}, args, held.data["rays"], held.data["rgbs"], keys=("rgb",), chunk=2048,
                        apply_brdf=on, apply_theta=on, cos_irra_on=on)
     assert all(bool(torch.isfinite(p).all()) for p in model.parameters()), dtype
+    if keep_adam is not None:
+        keep_adam.update(exp_avg=tr.exp_avg.clone(), exp_avg_sq=tr.exp_avg_sq.clone(), adam_steps=dict(tr.adam_steps))
     return float(res["psnr"]), first, {k: v.detach().clone() for k, v in model.state_dict().items()}
 
 
@@ -1722,11 +1726,13 @@ def test_reduced_precision_heldout_psnr_tracks_fp32_rpv_analytic_normals():
     """The same gate for BASELINE config 3's model (RPV funcM/F/H = 1 + analytic normals, double backward active).  All modes
     start from ONE Lambertian pretraining (fp32, 400 steps), then the BRDF stage runs in fp32 / bf16 / fp16 with identical
     batches and draws.  Two measurements:
-      (a) the BRDF stage is first trained in fp32 (600 steps), then continued for 150 steps (lr 1e-4 -> 0) in every mode from
-          that shared model, BN_PSNR_REPEATS draw seeds per mode, differences PAIRED by seed: past the switch-on transient
-          trajectories that start together mostly stay together (differences of 0.01 - 0.1 dB, fp32 against itself
-          included), so the mean paired difference isolates what the arithmetic does to training - gated at the
-          north_star's 0.05 dB + 2 standard errors of that mean;
+      (a) the BRDF stage is first trained in fp32 (600 steps), then CONTINUED for 150 steps (lr 1e-4 -> 0) in every mode from
+          that shared model AND its optimiser state (Adam moments and step counts carried over), BN_PSNR_REPEATS draw seeds
+          per mode, differences paired by seed.  This isolates what the arithmetic does to training: trajectories that start
+          together stay together (measured over four starting states: |difference| <= 0.018 dB, profiles/
+          r02_psnr_state_study.txt) - gated at the north_star's 0.05 dB on the mean paired difference.  (With a FRESH Adam
+          state the first updates are +-lr per parameter whatever the gradient: fp32 itself then loses 0.2-0.3 dB and the modes
+          scatter by +-0.1 dB with either sign - a property of the restart, not of the arithmetic; same study.)
       (b) 600 BRDF steps, BN_PSNR_REPEATS runs per mode: the BRDF stage restarts three heads from their initialisation and
           its end state is chaotic - fp32 differs from ITSELF by several tenths of a dB between sampling draws - so the
           means are compared with that spread in view: |difference of means| <= 0.05 dB + 2 standard errors (pooled
@@ -1735,23 +1741,22 @@ def test_reduced_precision_heldout_psnr_tracks_fp32_rpv_analytic_normals():
     cfg = FieldConfig(n_samples=64, guided_samples=64, **RPV_NAN)
     train, held = _learnable_table(1024 * 64, 3), _learnable_table(8192, 11)
     _, first, warm = _psnr_run(cfg, "fp32", 400, 0, train, held, draw_seed=1)
-    p_trained, _, trained = _psnr_run(cfg, "fp32", 0, 600, train, held, draw_seed=3, init_state=warm)
+    adam = {}
+    p_trained, _, trained = _psnr_run(cfg, "fp32", 0, 600, train, held, draw_seed=3, init_state=warm, keep_adam=adam)
     reps = int(os.environ.get("BN_PSNR_REPEATS", "3"))
-    short = {dtype: [_psnr_run(cfg, dtype, 0, 150, train, held, draw_seed=7 + r, init_state=trained, lr0=1e-4)[0] for r in range(reps)]
-             for dtype in ("fp32", "bf16", "fp16")}
+    short = {dtype: [_psnr_run(cfg, dtype, 0, 150, train, held, draw_seed=7 + r, init_state=trained, lr0=1e-4, adam=adam)[0]
+                     for r in range(reps)] for dtype in ("fp32", "bf16", "fp16")}
     smean = {k: sum(v) / len(v) for k, v in short.items()}
-    # paired by draw seed: the spread of the per-seed differences is the noise of this measurement (the fp32 mode run twice
-    # on the same draws - atomics order only - is reported beside it); a systematic effect of the arithmetic shows in the mean
-    again = _psnr_run(cfg, "fp32", 0, 150, train, held, draw_seed=7, init_state=trained, lr0=1e-4)[0]
     pair = {k: [a - b for a, b in zip(short[k], short["fp32"])] for k in ("bf16", "fp16")}
-    pse = {k: (statistics.pstdev(v) * (reps / max(1, reps - 1)) ** 0.5) / reps ** 0.5 if reps > 1 else 0.0 for k, v in pair.items()}
-    diag(f"held-out PSNR rpv_nan, 150 more BRDF steps (lr 1e-4 -> 0) from a shared fp32 model ({p_trained:.4f} dB after 400 + 600 steps), "
-         f"{reps} draw seeds: " + ", ".join(f"{k} {smean[k]:.4f} dB (runs {' '.join(f'{x:.4f}' for x in v)})" for k, v in short.items())
+    again = _psnr_run(cfg, "fp32", 0, 150, train, held, draw_seed=7, init_state=trained, lr0=1e-4, adam=adam)[0]
+    diag(f"held-out PSNR rpv_nan, 150 more BRDF steps (lr 1e-4 -> 0, Adam state carried) from a shared fp32 model ({p_trained:.4f} dB "
+         f"after 400 + 600 steps), {reps} draw seeds: "
+         + ", ".join(f"{k} {smean[k]:.4f} dB (runs {' '.join(f'{x:.4f}' for x in v)})" for k, v in short.items())
          + "; paired differences to fp32: "
-         + ", ".join(f"{k} {sum(v) / reps:+.4f} dB (se {pse[k]:.4f})" for k, v in pair.items())
+         + ", ".join(f"{k} {sum(v) / reps:+.4f} dB (per seed {' '.join(f'{x:+.4f}' for x in v)})" for k, v in pair.items())
          + f"; fp32 repeated on the first seed's draws: {again - short['fp32'][0]:+.4f} dB")
     for k, v in pair.items():
-        assert abs(sum(v) / reps) <= 0.05 + 2 * pse[k], (k, short)
+        assert abs(sum(v) / reps) <= 0.05, (k, short)
     reps = int(os.environ.get("BN_PSNR_REPEATS", "3"))
     n_long = int(os.environ.get("BN_PSNR_BRDF_STEPS", "600"))
     long_ = {dtype: [_psnr_run(cfg, dtype, 0, n_long, train, held, draw_seed=11 + r, init_state=warm)[0] for r in range(reps)]
