@@ -1518,6 +1518,46 @@ def test_train_loop_runs_saves_and_resumes(tmp_path):
     assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(cont, cont2))   # later steps: fp32-atomic summation order only
 
 
+def test_train_loop_with_beta_keeps_the_embedding(tmp_path):
+    """--beta through the harness (main.py:113-118): TrainLoop owns the image embedding, checkpoints carry it under the
+    reference's key, a resumed loop gets it back, the fused step leaves the beta head and the table untouched (the loss of
+    this model never reads beta_coarse, metrics.py:172-173), and render_rays on `loop.models` returns beta_coarse."""
+    from brdf_nerf_amd import render_rays
+    from brdf_nerf_amd.raytable import synthetic_table
+    from brdf_nerf_amd.train import TrainLoop
+    cfg = mini(beta=True, b=1, c=1, normal="learned")
+
+    def fresh(seed):
+        a = make_args(cfg)
+        for k, v in dict(batch_size=64, lr=5e-4, max_train_steps=40, brdf_on=0.0, cos_irra_on=0.0, nrrg_on=0.0, ds_drop=0.5,
+                         ds_lambda=10.0, gsam_only_on=1.0, nr_reg_lr_lambda=0.0, hs_lambda=0.0, in_ckpts="none",
+                         t_embbeding_vocab=7).items():
+            setattr(a, k, v)
+        torch.manual_seed(seed)
+        return TrainLoop(a, synthetic_table(640, device=DEV, seed=4), compute_dtype="fp32", near_far=(0.0, 2.0))
+
+    loop = fresh(0)
+    assert loop.embedding_t.weight.shape == (7, cfg.t_dim)
+    emb0 = loop.embedding_t.weight.detach().clone()
+    beta0 = {k: v.detach().clone() for k, v in loop.model.state_dict().items() if k.startswith("beta_from_xyz.")}
+    losses_ = [float(loop.step()["loss"]) for _ in range(6)]
+    assert losses_[-1] < losses_[0]
+    assert torch.equal(loop.embedding_t.weight, emb0)
+    assert all(torch.equal(loop.model.state_dict()[k], v) for k, v in beta0.items())
+    path = loop.save(str(tmp_path / "ckpts"))
+    ck = torch.load(path, weights_only=False)
+    assert "embedding_t.weight" in ck["state_dict"] and "nerf_coarse.beta_from_xyz.0.weight" in ck["state_dict"]
+    loop2 = fresh(5)                                     # other initial embedding
+    assert not torch.equal(loop2.embedding_t.weight, emb0)
+    loop2.resume(path)
+    assert torch.equal(loop2.embedding_t.weight, emb0)
+    rays = loop.table.data["rays"][:32].contiguous()
+    ts = torch.arange(32, device=DEV) % 7
+    with torch.no_grad():
+        res, _ = render_rays(loop2.models, loop2.args, rays, ts, mode="test", apply_brdf=True, apply_theta=True, cos_irra_on=True)
+    assert res["beta_coarse"].shape == (32, cfg.n_samples + cfg.guided_samples, 1) and bool((res["beta_coarse"] > 0).all())
+
+
 @pytest.mark.parametrize("name", ["lambert", "rpv111_nlr"])
 def test_train_loop_trajectory_against_oracle(name):
     """TrainLoop (stage schedule + ray table + fused step + Adam + StepLR) for 8 optimisation steps against the CPU oracle
@@ -1561,7 +1601,7 @@ def test_train_loop_trajectory_against_oracle(name):
             loss = loss + OL.depth_loss(res, b["depths"][:, 0], b["depths"][:, 1], b["valid_depth"], b["depth_std"], a.ds_lambda)
         loss.backward()
         opt.step()
-        want.append(float(loss))
+        want.append(float(loss.detach()))
     diag(f"train loop trajectory {name}: fused {' '.join(f'{x:.6f}' for x in got)} | oracle {' '.join(f'{x:.6f}' for x in want)}")
     assert any(h for h in [out["apply_brdf"]]) == (name != "lambert") or name == "lambert"
     for i, (x, y) in enumerate(zip(got, want)):
