@@ -130,7 +130,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       const int cpr = F / EPC, rpp = (WAVES * 64) / cpr, row0 = tid / cpr, cc = (tid % cpr) * EPC;
       const int passes = BM / rpp;
       const T *Yg = (const T *)(A.stash + A.sl.Y[l]) + (size_t)m0 * F;
-      if ((passes & 7) == 0) {           // F >= 256: eight loads in flight per thread, no branch around them
+      if ((WAVES * 64) % cpr != 0) {     // F = 192: a row of chunks does not divide the workgroup - walk chunk ids instead
+        for (int id = tid; id < BM * cpr; id += WAVES * 64) {
+          const int row = id / cpr, c = (id % cpr) * EPC;
+          *(u32x4 *)(ACT + (size_t)row * LDA + c) = stash_load((const u32x4 *)(Yg + (size_t)row * F + c));
+        }
+      } else if ((passes & 7) == 0) {    // F >= 256: eight loads in flight per thread, no branch around them
         for (int i0 = 0; i0 < passes; i0 += 8) {
           u32x4 v[8];
 #pragma unroll

