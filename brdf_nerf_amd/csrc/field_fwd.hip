@@ -449,8 +449,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
   if constexpr (FAST) {
     const bool nlr = g.ch_normal_lr >= 0 && !A.sigma_only;
     float *SRED = (float *)PE;                         // [WAVES][BM][4]: sigma_raw, normal_raw xyz partial sums
-    const int nks = KSF >= WAVES ? KSF / WAVES : 1, ks0 = wave * nks;
+    // k-steps split over the waves: ceil(KSF / WAVES) each (F = 192: 12 steps, two per wave on six waves), the last active wave
+    // takes what is left
+    const int nks_w = (KSF + WAVES - 1) / WAVES, ks0 = wave * nks_w;
     const bool kon = ks0 < KSF;
+    const int nks = kon ? (KSF - ks0 < nks_w ? KSF - ks0 : nks_w) : 0;
     f32x16 sacc[1][MT], nacc[1][MT];
     zero_acc<MT, 1>(sacc);
     zero_acc<MT, 1>(nacc);
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
       const int m = tid;
       f32x4 sum = {0.f, 0.f, 0.f, 0.f};
       for (int w = 0; w < WAVES; ++w)
-        if (w * nks < KSF) sum += *(const f32x4 *)(SRED + ((size_t)w * BM + m) * 4);
+        if (w * nks_w < KSF) sum += *(const f32x4 *)(SRED + ((size_t)w * BM + m) * 4);
       const int64_t gm = m0 + m;
       const float sraw = sum[0] + A.p.sigma_b[0];
       const float sig = softplus_f(sraw);

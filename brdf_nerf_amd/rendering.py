@@ -280,8 +280,8 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
         # needs n_valid on the host (one sync; the reference does three via np.where(...cpu())).  The fused training step
         # draws (R, G) and indexes it by the valid-row rank instead: same distribution, no sync (trainer.py).
         n_valid = int(valid.sum())
+        u_t = torch.rand(n_valid, G, device=rays.device)        # drawn (an empty tensor) even without a valid row, as upstream (:76-91)
         if n_valid > 0:
-            u_t = torch.rand(n_valid, G, device=rays.device)
             use_t = valid.float().contiguous()
             tdep = target_depths[:, 0].float().contiguous()
             tstd = target_std.float().reshape(-1).contiguous()
