@@ -223,3 +223,128 @@ def test_random_render_rays_against_oracle(seed):
         if v.dtype.is_floating_point and k != "hpk_scl_coarse":
             assert bool(torch.isfinite(v).all()) == bool(torch.isfinite(ref[k]).all()), f"{tag}: {k} finiteness differs"
     assert {k for k in ref if not k.startswith("_")} == set(res), tag
+
+
+class _Record:
+    """Pass-through recorder of torch.rand / rand_like / randn (device draws of the HIP path), in call order."""
+
+    def __init__(self):
+        self.log = []
+
+    def __enter__(self):
+        self._o = (torch.rand, torch.rand_like, torch.randn)
+        o_rand, o_like, o_randn = self._o
+
+        def rand(*a, **k):
+            t = o_rand(*a, **k); self.log.append(t.clone()); return t
+
+        def rand_like(x, **k):
+            t = o_like(x, **k); self.log.append(t.clone()); return t
+
+        def randn(*a, **k):
+            t = o_randn(*a, **k); self.log.append(t.clone()); return t
+
+        torch.rand, torch.rand_like, torch.randn = rand, rand_like, randn
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.rand_like, torch.randn = self._o
+
+
+@pytest.mark.parametrize("seed", list(range(32)))
+def test_random_fused_step_against_autograd_path(seed):
+    """FusedTrainer.step (the path bench.py times: stash forward, composite, loss glue, explicit backward kernels, flat
+    gradient, fused Adam) on random configurations against render_rays + losses + loss.backward() + torch.optim.Adam of the
+    HIP autograd path (itself held to the oracle above) on the SAME draws: loss, every gradient, parameters after the step.
+    Random width / depth / heads / normals, regulariser lambdas, depth priors (target_std = 0: reference quirk 7), gsam_only,
+    sun visibility, MultiBRDF, --beta (left out by the fused step), --input_viewdir; fp32 mode."""
+    from test_gpu_parity import build_model, make_args, Replay, diag
+    from brdf_nerf_amd import render_rays, losses
+    from brdf_nerf_amd.trainer import FusedTrainer
+    rng = np.random.default_rng(13000 + seed)
+    cfg = draw_config(rng)
+    S, G = int(rng.choice([8, 16, 24])), int(rng.choice([8, 16]))
+    kw = dict(vars(cfg))
+    kw.update(feat=int(rng.choice([64, 128, 192])), n_samples=S, guided_samples=G)
+    brdf = bool(cfg.roughness or cfg.RPV or cfg.b)
+    gsam_only = bool(rng.random() < 0.3)
+    if brdf and gsam_only and rng.random() < 0.5:
+        kw["sun_v"] = "analystic"
+    if cfg.RPV and rng.random() < 0.3:
+        kw["MultiBRDF"] = True
+    cfg = FieldConfig(**kw)
+    args = make_args(cfg)
+    R = int(rng.integers(4, 80))
+    flags = dict(apply_brdf=brdf and bool(rng.random() < 0.85), apply_theta=bool(rng.random() < 0.7), cos_irra_on=bool(rng.random() < 0.6))
+    if cfg.sun_v == "analystic":
+        flags["apply_brdf"] = True
+    lam = dict(nr_reg_an_lambda=float(rng.choice([0.0, 0.2])), nr_reg_lr_lambda=float(rng.choice([0.0, 0.1])),
+               hs_lambda=float(rng.choice([0.0, 0.3])), nr_spv_lambda=float(rng.choice([0.0, 0.05])))
+    with_depth = bool(rng.random() < 0.5)
+    g = torch.Generator().manual_seed(seed)
+    rays = _sat_rays(R, g).to(DEV)
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    valid = (torch.rand(R, generator=g) < 0.6).float().to(DEV)
+    depths = torch.stack([0.8 + 0.4 * torch.rand(R, generator=g), torch.rand(R, generator=g)], -1).to(DEV)
+    dstd = torch.zeros(R, device=DEV)
+    dk = dict(valid_depth=valid, target_depths=depths, target_std=dstd) if with_depth else {}
+    tag = (f"fuzz-step {seed}: F={cfg.feat} L={cfg.layers} siren={int(cfg.siren)} normal={cfg.normal} sun_v={cfg.sun_v} multi={int(cfg.MultiBRDF)} "
+           f"beta={int(cfg.beta)} viewdir={cfg.input_viewdir} R={R} S={S} G={G} gsam_only={gsam_only} depth={with_depth} {flags} {lam}")
+
+    ma = build_model(cfg, 60 + seed)
+    opt = torch.optim.Adam(ma.parameters(), lr=5e-4)
+    models_a, ts = {"coarse": ma}, None
+    if cfg.beta:
+        models_a["t"] = torch.nn.Embedding(5, cfg.t_dim).to(DEV)
+        ts = torch.randint(0, 5, (R,), generator=g).to(DEV)
+    torch.manual_seed(7)
+    with _Record() as rec:
+        res, _ = render_rays(models_a, args, rays, ts, mode="train", gsam_only=gsam_only, **flags, **dk)
+    loss_a = losses.snerf_loss(res["rgb_coarse"], rgbs)
+    w, z, d = res["weights_coarse"], res["z_vals_coarse"], res["depth_coarse"]
+    if with_depth:
+        loss_a = loss_a + losses.depth_loss(z, d, w, depths[:, 0], depths[:, 1], valid, dstd, 10.0)
+    view = -rays[:, 3:6]
+    if lam["nr_reg_an_lambda"] > 0 and "normal_an_coarse" in res:
+        loss_a = loss_a + losses.normal_reg_loss(res["normal_an_coarse"], w, view, lam["nr_reg_an_lambda"])[0]
+    if lam["nr_reg_lr_lambda"] > 0 and "normal_lr_coarse" in res:
+        loss_a = loss_a + losses.normal_reg_loss(res["normal_lr_coarse"], w, view, lam["nr_reg_lr_lambda"])[0]
+    if lam["hs_lambda"] > 0:
+        loss_a = loss_a + losses.hard_surface_loss(z, d, w, lam["hs_lambda"])
+    if lam["nr_spv_lambda"] > 0 and "normal_an_coarse" in res and "normal_lr_coarse" in res:
+        loss_a = loss_a + losses.normal_loss(w, res["normal_an_coarse"], res["normal_lr_coarse"], lam["nr_spv_lambda"])
+    loss_a.backward()
+    grads_a = {k: v.grad.clone() for k, v in ma.named_parameters() if v.grad is not None}
+    opt.step()
+
+    # the fused step draws (R, G) uniforms for the depth-prior rows where render_rays draws (n_valid, G); with target_std = 0 the
+    # guided samples of those rows do not depend on them
+    n_valid = int(valid.sum())
+    draws = [torch.rand(R, G, device=DEV) if (with_depth and tuple(t.shape) == (n_valid, G) and i >= 3) else t for i, t in enumerate(rec.log)]
+    mb = build_model(cfg, 60 + seed)
+    tr = FusedTrainer(mb, args, lr=5e-4, ds_lambda=10.0 if with_depth else 0.0, **lam)
+    tr.sanitize_grads = False
+    with Replay(draws) as rp:
+        loss_b, _ = tr.step(rays, rgbs, valid_depth=valid if with_depth else None, depths=depths if with_depth else None,
+                            depth_std=dstd if with_depth else None, gsam_only=gsam_only, **flags)
+        assert rp.draws == [], f"{tag}: the fused step consumed a different number of draws"
+    la, lb = float(loss_a.detach()), float(loss_b)
+    if not np.isfinite(la):
+        pytest.skip(f"{tag}: the autograd path's loss is not finite for this random model")
+    assert abs(la - lb) <= 2e-5 * abs(la) + 1e-7, f"{tag}: loss {lb} vs {la}"
+    worst = 0.0
+    for k, ga in grads_a.items():
+        if not bool(torch.isfinite(ga).all()):
+            continue                                   # (singular BRDF point of a random model: autograd itself gives NaN / inf)
+        gb = tr.grad_views[k]
+        scale = float(ga.abs().max())
+        e = float((gb - ga).abs().max())
+        worst = max(worst, e / max(scale, 1e-30))
+        assert e <= 5e-4 * scale + 1e-9, f"{tag}: grad {k}: err {e:.3e} scale {scale:.3e}"
+    diag(f"{tag}: loss {la:.6f}, worst relative gradient error {worst:.2e}")
+    for k in tr.grad_views:
+        if k not in grads_a:
+            assert float(tr.grad_views[k].abs().max()) == 0.0, f"{tag}: {k} has no gradient in the autograd path"
+    if all(bool(torch.isfinite(ga).all()) for ga in grads_a.values()):
+        for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert float((pa - pb).detach().abs().max()) <= 2.1 * 5e-4, f"{tag}: param {k} after Adam"
