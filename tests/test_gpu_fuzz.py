@@ -348,3 +348,66 @@ def test_random_fused_step_against_autograd_path(seed):
     if all(bool(torch.isfinite(ga).all()) for ga in grads_a.values()):
         for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
             assert float((pa - pb).detach().abs().max()) <= 2.1 * 5e-4, f"{tag}: param {k} after Adam"
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_fused_step_half_and_deterministic(seed):
+    """The fused step on random configurations in a 16-bit mode: (1) deterministic mode twice - bitwise identical flat
+    gradients (random widths give tile / split / launch-generation counts the fixed tests do not); (2) against the fp32
+    fused step on the same draws - loss within 2 %, flat gradient pointing the same way."""
+    import brdf_nerf_amd
+    from test_gpu_parity import build_model, make_args, Replay, diag
+    from brdf_nerf_amd.trainer import FusedTrainer
+    rng = np.random.default_rng(17000 + seed)
+    cfg = draw_config(rng)
+    S, G = int(rng.choice([8, 16, 32])), int(rng.choice([8, 16, 32]))
+    kw = dict(vars(cfg))
+    kw.update(n_samples=S, guided_samples=G)
+    brdf = bool(cfg.roughness or cfg.RPV or cfg.b)
+    cfg = FieldConfig(**kw)
+    dtype = "bf16" if seed % 2 == 0 else "fp16"
+    R = int(rng.integers(16, 200))
+    flags = dict(apply_brdf=brdf and bool(rng.random() < 0.85), apply_theta=bool(rng.random() < 0.7), cos_irra_on=bool(rng.random() < 0.6))
+    g = torch.Generator().manual_seed(seed)
+    rays = _sat_rays(R, g).to(DEV)
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    tag = f"fuzz-step16 {seed} {dtype}: F={cfg.feat} L={cfg.layers} siren={int(cfg.siren)} normal={cfg.normal} R={R} S={S} G={G} {flags}"
+
+    def run(dt, det, draws=None):
+        prev = brdf_nerf_amd.set_deterministic(det)
+        try:
+            model = build_model(cfg, 80 + seed, dt)
+            tr = FusedTrainer(model, make_args(cfg, dt), lr=5e-4, hs_lambda=0.2)
+            if draws is None:
+                torch.manual_seed(5)
+                with _Record() as rec:
+                    loss, _ = tr.step(rays, rgbs, **flags)
+                draws = rec.log
+            else:
+                with Replay(list(draws)) as rp:
+                    loss, _ = tr.step(rays, rgbs, **flags)
+                    assert rp.draws == []
+            torch.cuda.synchronize()
+            return float(loss), tr.flat_grad.clone(), draws
+        finally:
+            brdf_nerf_amd.set_deterministic(prev)
+
+    l32, g32, draws = run("fp32", False)
+    l16a, g16a, _ = run(dtype, True, draws)
+    l16b, g16b, _ = run(dtype, True, draws)
+    assert torch.equal(g16a, g16b) and l16a == l16b, f"{tag}: deterministic mode is not reproducible (max diff {float((g16a - g16b).abs().max()):.3e})"
+    if not (np.isfinite(l32) and bool(torch.isfinite(g32).all())):
+        pytest.skip(f"{tag}: the fp32 step is not finite for this random model")
+    assert bool(torch.isfinite(g16a).all()), tag
+    cos = float(torch.nn.functional.cosine_similarity(g16a.double(), g32.double(), dim=0))
+    diag(f"{tag}: loss fp32 {l32:.5f} {dtype} {l16a:.5f}, flat-gradient cosine {cos:.5f}")
+    nr_an = cfg.normal in ("analystic", "analystic_learned")
+    # fp16 (11 significant bits) is held tightly - it runs the same templates as bf16, so a kernel fault shows here; bf16 (8 bits)
+    # on a RANDOM deep Siren model with a BRDF on top is only held coarsely (measured down to 0.88 where fp16 gives 0.997: the
+    # untrained normals put rays at grazing angles where the BRDFs amplify rounding); its acceptance criterion is the PSNR gate
+    if dtype == "fp16":
+        assert abs(l16a - l32) <= 0.02 * abs(l32) + 1e-4, f"{tag}: loss {l16a} vs {l32}"
+        assert cos >= (0.90 if nr_an else 0.97), f"{tag}: cosine {cos:.4f}"
+    else:
+        assert abs(l16a - l32) <= 0.05 * abs(l32) + 1e-4, f"{tag}: loss {l16a} vs {l32}"
+        assert cos >= 0.8, f"{tag}: cosine {cos:.4f}"
