@@ -411,3 +411,74 @@ def test_random_fused_step_half_and_deterministic(seed):
     else:
         assert abs(l16a - l32) <= 0.05 * abs(l32) + 1e-4, f"{tag}: loss {l16a} vs {l32}"
         assert cos >= 0.8, f"{tag}: cosine {cos:.4f}"
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_composite_and_guided_shapes_against_oracle(seed):
+    """The per-ray kernels at random (ragged) sizes: S in [1, 512], C in [1, 32], G in [1, 256], rays not a multiple of the
+    workgroup's, density noise on / off, depth priors on / off.  Compositing forward + backward against the oracle's autograd;
+    guided sampling + merge against the oracle with the same uniforms: depths to 1e-5, sort indices exact away from near-ties, the merged depths sorted and a permutation of the inputs."""
+    from brdf_nerf_amd import functions as Fn
+    from oracle import render as ORD
+    rng = np.random.default_rng(21000 + seed)
+    S, C, R = int(rng.integers(1, 513)), int(rng.integers(4, 33)), int(rng.integers(1, 150))
+    if seed % 3 == 0:
+        S = int(rng.integers(1, 70))
+    noise_std = float(rng.choice([0.0, 0.4]))
+    g = torch.Generator().manual_seed(seed)
+    z = torch.sort(torch.rand(R, S, generator=g) * 2, -1)[0]
+    out = torch.randn(R, S, C, generator=g)
+    out[..., 3] = torch.relu(out[..., 3]) * 8 * (torch.rand(R, S, generator=g) < 0.3)
+    noise = torch.randn(R, S, generator=g)
+    cw, cd, ca = torch.rand(R, S, generator=g), torch.rand(R, generator=g), torch.rand(R, C, generator=g)
+    ca[:, 3] = 0
+    o_ref = out.clone().requires_grad_(True)
+    a, T, w, d = ORD.composite(z, o_ref[..., 3], noise, noise_std)
+    acc = (w.unsqueeze(-1) * o_ref).sum(-2)
+    ((w * cw).sum() + (d * cd).sum() + (acc * ca).sum()).backward()
+    o_gpu = out.clone().to(DEV).requires_grad_(True)
+    a2, T2, w2, d2, acc2 = Fn.composite(z.to(DEV), o_gpu, noise.to(DEV) if noise_std else None, noise_std)
+    ((w2 * cw.to(DEV)).sum() + (d2 * cd.to(DEV)).sum() + (acc2 * ca.to(DEV)).sum()).backward()
+    tag = f"fuzz-ray {seed}: R={R} S={S} C={C} noise={noise_std}"
+    for name, got, want, tol in (("alphas", a2, a, 1e-6), ("trans", T2, T, 1e-6), ("weights", w2, w, 1e-6), ("depth", d2, d, 2e-6), ("acc", acc2, acc, 2e-5)):
+        e = float((got.detach().cpu() - want.detach()).abs().max())
+        assert e <= 1e-5 * float(want.detach().abs().max()) + tol, f"{tag}: {name} err {e:.2e}"
+    scale = float(o_ref.grad.abs().max())
+    assert float((o_gpu.grad.cpu() - o_ref.grad).abs().max()) <= 1e-4 * scale + 1e-7, f"{tag}: d_out"
+
+    # guided sampling around the composited depth (S >= 2 samples to resample from)
+    S2 = max(S, 2) if S <= 256 else 256
+    G = int(rng.integers(1, 257))
+    z = torch.sort(torch.rand(R, S2, generator=g) * 2, -1)[0]
+    sig = torch.relu(torch.randn(R, S2, generator=g)) * 20 * (torch.rand(R, S2, generator=g) < 0.25)
+    _, _, w, d = ORD.composite(z, sig)
+    train = bool(rng.random() < 0.5)
+    valid = (torch.rand(R, generator=g) < 0.5).float()
+    tdep = torch.stack([0.5 + torch.rand(R, generator=g), torch.rand(R, generator=g)], -1)
+    tstd = 0.02 + 0.05 * torch.rand(R, generator=g)
+    rnd = ORD.Randoms(generator=torch.Generator().manual_seed(seed))
+    z2_ref, _, _ = ORD.guided_samples(d, w, z, G, torch.tensor(0.0), torch.tensor(2.0), rnd, 3.0, "train" if train else "test",
+                                      valid if train else None, tdep if train else None, tstd if train else None)
+    z2_ref = torch.sort(z2_ref, -1)[0]
+    z_all_ref, idx_ref = torch.sort(torch.cat([z, z2_ref], -1), -1)
+    kw = {}
+    if train:
+        v = valid > 0
+        u_t = rnd.log[1] if len(rnd.log) > 1 else torch.zeros(0, G)
+        if int(v.sum()) > 0:
+            kw = dict(use_target=valid.to(DEV), target_depth=tdep[:, 0].contiguous().to(DEV), target_std=tstd.to(DEV), u_target=u_t.to(DEV),
+                      target_row=(torch.cumsum(v.int(), 0) - 1).clamp_min(0).int().to(DEV))
+    z2, z_all, idx = Fn.guided_samples(z.to(DEV), w.to(DEV), d.to(DEV), rnd.log[0].to(DEV), 0.0, 2.0, 3.0, **kw)
+    tag = f"fuzz-ray {seed}: guided R={R} S={S2} G={G} train={train}"
+    # (2e-6 at the reference's G = 64; the inverse-CDF interpolation over up to 256 bins sums in another order than torch.cumsum)
+    assert float((z2.cpu() - z2_ref).abs().max()) <= 1e-5, f"{tag}: z2 {float((z2.cpu() - z2_ref).abs().max()):.2e}"
+    assert float((z_all.cpu() - z_all_ref).abs().max()) <= 1e-5, tag
+    assert bool((z_all[:, 1:] >= z_all[:, :-1]).all()), tag
+    assert torch.equal(torch.sort(idx, -1)[0].cpu(), torch.arange(S2 + G).expand(R, -1)), tag
+    assert torch.equal(torch.gather(torch.cat([z.to(DEV), z2], -1), 1, idx), z_all), tag
+    near = (z_all_ref[:, 1:] - z_all_ref[:, :-1]).abs() <= 2e-5                 # depths closer than the tolerance may swap places
+    loose = torch.zeros_like(z_all_ref, dtype=torch.bool)
+    loose[:, 1:] |= near
+    loose[:, :-1] |= near
+    mism = (idx.cpu() != idx_ref) & ~loose
+    assert int(mism.sum()) == 0, f"{tag}: {int(mism.sum())} sort indices differ away from near-ties"
