@@ -19,7 +19,7 @@ DEV = "cuda"
 
 
 def draw_config(rng):
-    feat = int(rng.choice([64, 128, 192, 256]))
+    feat = int(rng.choice([64, 128, 192, 256, 512]))
     layers = int(rng.integers(2, 9))
     family = rng.choice(["lambert", "rpv", "hapke", "microfacet"])
     kw = dict(feat=feat, layers=layers, siren=bool(rng.random() < 0.7), mapping=bool(rng.random() < 0.8),
