@@ -1936,6 +1936,26 @@ def test_deterministic_mode_gives_bitwise_identical_gradients(name, dtype, feat,
     assert faults.value == 0
 
 
+def test_c_abi_from_a_plain_host_program(tmp_path):
+    """The drop-in boundary is a C ABI: examples/abi_smoke.cpp - no Python, no torch - links the library, allocates with the
+    HIP runtime, calls bn_stratified_z / bn_composite_forward on its own stream and checks them against a scalar restatement
+    of get_z_vals / cal_weight; a bad argument must come back as a status with a message."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(root, "brdf_nerf_amd")
+    subprocess.run([hipcc, "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "abi_smoke.cpp"), "-o", exe,
+                    "-L" + libdir, "-lbrdfnerf_hip", "-Wl,-rpath," + libdir], check=True, timeout=600)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    for line in p.stdout.splitlines():
+        diag("abi_smoke: " + line)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stdout
+
+
 def test_count_nonfinite_hook():
     """Sync-free replacement of check_nan (train_utils.py:14-25): NaN and Inf counters accumulate on the device."""
     from brdf_nerf_amd import functions as Fn
