@@ -555,7 +555,14 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
 #endif
     // deterministic mode: the splits of a job add one after the other (~3.5 us a turn): 64 instead of 256 (0.94 -> see
     // profiles/r02_ablation.txt)
-    const int skinny_splits = det ? 64 : SKINNY_SPLITS;
+    // small batches (strong scaling: 512 rays per GPU = 32,768 points per launch): at least 8 point tiles per split (measured
+    // neutral - 0.089 vs 0.084 ms per launch: the kernel's ~0.08 ms floor at that size is not the atomics tail - kept for the
+    // 8 x fewer global atomics)
+    int skinny_splits = det ? 64 : SKINNY_SPLITS;
+    {
+      const int64_t most = sl.Mpad / (8 * (int64_t)BM) > 1 ? sl.Mpad / (8 * (int64_t)BM) : 1;
+      if (skinny_splits > most) skinny_splits = (int)most;
+    }
     int64_t smpb = ceil_div64(ceil_div64(sl.Mpad, skinny_splits), BM) * BM;   // whole tiles per block (native jobs walk tile images)
     s.m_per_block = (int)smpb;
     auto launch_skinny = [&](SkinnyArgs &sv, unsigned int *tk) -> int { return bn_launch_skinny(sv, tk, bf, f16m, sl.Mpad, smpb, st); };
