@@ -116,6 +116,16 @@ def test_random_field_configuration_half_modes_track_fp32(seed):
         outs[dt] = out.detach()
         grads[dt] = {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}
         tg[dt] = t_in.grad.clone() if cfg.beta else None
+        # the inference variants of the forward kernel (no stash; sigma only) must give what the training forward gave
+        with torch.no_grad():
+            inf = model(xyz, input_dir=dirs, input_t=t0, **dict(flags, nr_an_on=False))
+            sg = model(xyz, sigma_only=True)
+        keep = [c for c in range(out.shape[1]) if not (nr_an and (5 if cfg.beta else 4) <= c < (8 if cfg.beta else 7))]
+        ref_cols = out.detach()[:, keep]
+        assert inf.shape[1] == len(keep), f"{dt}: inference forward has {inf.shape[1]} channels, expected {len(keep)}"
+        tol_inf = 1e-5 if dt == "fp32" else 2e-2
+        assert float((inf - ref_cols).abs().max()) <= tol_inf * max(1.0, float(ref_cols.abs().max())), f"{dt}: inference forward differs from the training forward"
+        assert float((sg[:, 0] - out.detach()[:, 3]).abs().max()) <= tol_inf * max(1.0, float(out.detach()[:, 3].abs().max())), f"{dt}: sigma-only forward differs"
     tag = (f"fuzz-half {seed} {dtype}: F={cfg.feat} L={cfg.layers} siren={int(cfg.siren)} pe={int(cfg.mapping)} normal={cfg.normal} "
            f"viewdir={cfg.input_viewdir} beta={int(cfg.beta)} heads={cfg.brdf_head_names(flags['apply_brdf'], flags['apply_theta'])} B={B}")
     b = HALF_BOUNDS[dtype]
