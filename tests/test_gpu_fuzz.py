@@ -69,11 +69,20 @@ def test_random_field_configuration_against_oracle(seed):
     tag = (f"fuzz {seed}: F={cfg.feat} L={cfg.layers} siren={int(cfg.siren)} pe={int(cfg.mapping)} normal={cfg.normal} "
            f"viewdir={cfg.input_viewdir} beta={int(cfg.beta)} heads={cfg.brdf_head_names(flags['apply_brdf'], flags['apply_theta'])} B={B}")
     assert out.shape == ref.shape, tag
-    err = float((out.detach().cpu() - ref.detach()).abs().max())
+    dif = (out.detach().cpu() - ref.detach()).abs()
+    err = float(dif.max())
     diag(f"{tag}: out max|err| {err:.2e}")
-    assert err <= 2e-4 * float(ref.detach().abs().max()) + 2e-5, tag
+    kink = nr_an and not cfg.siren      # ReLU + analytic normal: d sigma/dx is piecewise constant - a pre-activation within rounding of
+    if kink:                            # 0 takes the other branch in one of the two evaluations and moves that point's normal
+        c0 = 5 if cfg.beta else 4
+        other = torch.ones(out.shape[1], dtype=torch.bool)
+        other[c0:c0 + 3] = False
+        assert float(dif[:, other].max()) <= 2e-4 * float(ref.detach().abs().max()) + 2e-5, tag
+        assert int((dif[:, c0:c0 + 3].amax(-1) > 2e-4).sum()) <= max(1, B // 50), f"{tag}: analytic normals off at too many points"
+    else:
+        assert err <= 2e-4 * float(ref.detach().abs().max()) + 2e-5, tag
     (out * coef.to(DEV)).sum().backward()
-    tol = 1e-3 if nr_an else 2e-4
+    tol = (2e-2 if kink else 1e-3) if nr_an else 2e-4
     if cfg.beta:
         scale = float(t_ref.grad.abs().max())
         assert float((t_gpu.grad.cpu() - t_ref.grad).abs().max()) <= tol * scale + 1e-7, tag + " d_t_embed"
@@ -542,8 +551,9 @@ def test_random_brdf_inputs_against_oracle(seed):
 
     def check(pairs, brdf_got, brdf_ref, rtol):
         ok = torch.isfinite(brdf_ref).all(-1)
-        e = float((brdf_got.detach().cpu()[ok] - brdf_ref.detach()[ok]).abs().max()) if bool(ok.any()) else 0.0
-        assert e <= rtol * float(brdf_ref.detach()[ok].abs().max()) + 2e-6, f"{tag}: brdf err {e:.2e}"
+        if bool(ok.any()):     # elementwise: the GGX lobe spans five decades over these inputs (alpha down to 0.0025)
+            dv = (brdf_got.detach().cpu()[ok] - brdf_ref.detach()[ok]).abs() - 5 * rtol * brdf_ref.detach()[ok].abs()
+            assert float(dv.max()) <= 1e-4, f"{tag}: brdf err excess {float(dv.max()):.2e}"
         for name, got, want in pairs:
             if want is None:                       # the oracle's output does not depend on it (RPV with the HG factor alone: no normal)
                 assert got is None or float(got.abs().max()) == 0.0, f"{tag}: d{name} should be empty"
