@@ -555,12 +555,13 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
 #endif
     // deterministic mode: the splits of a job add one after the other (~3.5 us a turn): 64 instead of 256 (0.94 -> see
     // profiles/r02_ablation.txt)
-    // small batches (strong scaling: 512 rays per GPU = 32,768 points per launch): at least 8 point tiles per split (measured
-    // neutral - 0.089 vs 0.084 ms per launch: the kernel's ~0.08 ms floor at that size is not the atomics tail - kept for the
-    // 8 x fewer global atomics)
+    // small batches (strong scaling: 512 rays per GPU = 32,768 points per launch): a block walks its points in a latency-bound
+    // loop, so fewer points per block is faster until the atomics tail takes over - at least 2 point tiles per split
+    // (session 50, 512 rays: 32 splits 0.085 ms, 64 0.066, 128 0.060, 256 0.089 per launch)
     int skinny_splits = det ? 64 : SKINNY_SPLITS;
     {
-      const int64_t most = sl.Mpad / (8 * (int64_t)BM) > 1 ? sl.Mpad / (8 * (int64_t)BM) : 1;
+      int64_t most = sl.Mpad / (2 * (int64_t)BM) > 1 ? sl.Mpad / (2 * (int64_t)BM) : 1;
+      if (sl.Mpad <= 131072 && most > 128) most = 128;      // up to 2048 rays x 64 samples: 128 blocks per job keep the atomics tail short
       if (skinny_splits > most) skinny_splits = (int)most;
     }
     int64_t smpb = ceil_div64(ceil_div64(sl.Mpad, skinny_splits), BM) * BM;   // whole tiles per block (native jobs walk tile images)

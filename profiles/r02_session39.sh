@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-2 GPU session 39: where a small (strong-scaling) step goes - 512 and 1024 rays per GPU
-for r in 512 1024; do
+for r in 512 1024 2048; do
   timeout -k 10 200 python bench.py --rays $r --steps 50 --warmup 10 --no-cpu-baseline > gpurun_out/small_$r.json 2> gpurun_out/small_$r.err || exit 1
   python - $r <<'PY'
 import json, sys
