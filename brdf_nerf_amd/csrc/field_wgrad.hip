@@ -590,7 +590,9 @@ int bn_launch_wgrad(WgradArgs &wv, unsigned int *tk, bool bf, bool f16m, int64_t
 #ifndef W2_BLOCKS
 #define W2_BLOCKS 512   // tiles x point splits <= two rounds of the 256 CUs (one 144 KB workgroup per CU): 1024 -> 1.295 ms, 512 -> 1.253, 256 -> 1.290
 #endif
-    int64_t n_split = W2_BLOCKS / tiles;
+    // (small batches - up to 1024 rays x 64 samples per launch - run faster with one round of workgroups: 512 rays 0.232 ->
+    // 0.197 ms, 1024 rays 0.367 -> 0.345, session 51)
+    int64_t n_split = (Mpad <= 65536 ? W2_BLOCKS / 2 : W2_BLOCKS) / tiles;
     if (n_split < 1) n_split = 1;
     int64_t mpb2 = ceil_div64(ceil_div64(Mpad, n_split), W2_BK) * W2_BK;
     if (mpb2 < 512) mpb2 = 512;
