@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void guided_kernel(const Guid
   if (A.use_target && A.use_target[ray] > 0.f) {
     centre = A.target_depth[ray];
     std = A.target_std[ray];
-    u = A.u_target + (int64_t)A.target_row[ray] * G;
+    u = A.u_target + (A.target_row ? (int64_t)A.target_row[ray] : ray) * G;   // no row table: u_target has one row per ray
   } else {
     centre = A.depth[ray];
     float acc = 0.f;
@@ -600,7 +600,7 @@ static int guided_samples_impl(const float *z, const float *weights, const float
                                int64_t *sort_idx, void *stream) {
   BN_REQUIRE(z && weights && depth && u && z2_sorted && R > 0, "guided_samples: null argument");
   BN_REQUIRE(G >= 3 && G <= BN_MAX_G && S >= 1 && S + G <= BN_MAX_SG, "guided_samples: S=%d G=%d unsupported", S, G);
-  BN_REQUIRE(!use_target || (target_depth && target_std && u_target && target_row), "guided_samples: target arrays");
+  BN_REQUIRE(!use_target || (target_depth && target_std && u_target), "guided_samples: target arrays");
   GuidedArgs a = {z, weights, depth, u, use_target, target_depth, target_std, u_target, target_row, R, S, G,
                   near0, far0, d_range, z2_sorted, z_all, sort_idx, near_far};
   BnProfScope prof_(BN_K_GUIDED, (hipStream_t)stream);

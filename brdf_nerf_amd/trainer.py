@@ -158,14 +158,18 @@ class FusedTrainer:
             u = torch.rand(R, G, device=dev)
             use_t = tdep = tstd = u_t = trow = None
             if valid_depth is not None:
-                valid = valid_depth > 0
+                valid = (valid_depth > 0) if self.strict_rng else None
                 # the reference draws rand(n_valid, G); a (R, G) draw indexed by the valid-row rank is the same
                 # distribution and needs no host sync
                 u_t = torch.rand(R, G, device=dev)
-                use_t = valid.float().contiguous()
                 tdep = depths[:, 0].float().contiguous()
                 tstd = depth_std.float().reshape(-1).contiguous()
-                trow = (torch.cumsum(valid.int(), 0) - 1).clamp_min(0).int().contiguous()
+                if self.strict_rng:     # replaying the reference's stream: row k of its (n_valid, G) draw belongs to the k-th valid ray
+                    use_t = valid.float().contiguous()
+                    trow = (torch.cumsum(valid.int(), 0) - 1).clamp_min(0).int().contiguous()
+                else:                   # own draws: row r for ray r (no row table, no conversions: the kernel tests use_target > 0)
+                    use_t = valid_depth if (valid_depth.dtype == torch.float32 and valid_depth.is_contiguous()) \
+                        else (valid_depth > 0).float().contiguous()
             # the clamp window is the FIRST ray's (near, far) (rendering.py:133): read on the device from rays[0, 6:8]
             # unless the caller passes the pair
             near0, far0 = near_far if near_far is not None else (rays[0, 6:8], None)

@@ -217,7 +217,8 @@ int bn_stratified_z(const float *near, const float *far, int64_t nf_stride, cons
  * [near0, far0] and symmetrised; G Gaussian-weighted bins; inverse-CDF with u[R][G]; sort;
  * then z_all[R][S+G] = sort(cat[z, z2]) with sort_idx int64 (bit-exact index semantics).
  * Rows with use_target[r] != 0 (train mode & valid depth) sample around target_depth/target_std
- * with u_target[row_of_valid][G] instead (rendering.py:135-145).
+ * with u_target[target_row[r]][G] instead (rendering.py:135-145: the reference draws one row per VALID ray,
+ * target_row[r] = rank of ray r among them; target_row == NULL: u_target has one row per ray, [R][G]).
  * ------------------------------------------------------------------------------------------- */
 int bn_guided_samples(const float *z, const float *weights, const float *depth, const float *u, int64_t R,
                       int32_t S, int32_t G, float near0, float far0, float d_range, const float *use_target,
