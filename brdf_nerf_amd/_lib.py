@@ -59,6 +59,7 @@ _lib = None
 _SIGS = {
     "bn_abi_version": (C.c_int, []),
     "bn_last_error": (C.c_char_p, []),
+    "bn_build_flags": (C.c_char_p, []),
     "bn_set_deterministic": (C.c_int, [C.c_int]),
     "bn_field_packed_bytes": (C.c_size_t, [C.POINTER(FieldDesc)]),
     "bn_pack_field": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), fptr, fptr]),

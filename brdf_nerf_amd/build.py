@@ -35,11 +35,15 @@ def needs_build():
 # (profiles/r02_ablation.txt, session 24) - hence their own translation unit.
 # The backward chain and the analytic-normal chains gain 1-3 % from the AMDGPU register-pressure trackers in the scheduler (the
 # forward loses 2-7 % with them, the weight-gradient kernels 2-20 %: session 25).
-# Weight-fragment prefetch depth of the chain GEMM (field_kernels.h PipeDepth, k-steps in flight; 4 by default): the training
-# forward gains 1-1.7 % with 6, the backward / adjoint chains 1-3 % with 2 (session 42).
-_TRACKERS = ("-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-DBN_DEPTH_BF16=2")
+# (The weight-fragment prefetch depth of the chain GEMM is a template parameter per kernel instantiation: field_kernels.h
+# FwdDepth / BwdDepth.)
+# -fno-slp-vectorize (round 3): hipcc's SLP pass packs the epilogues' independent fp32 adds / multiplies into v_pk_*_f32 with
+# v_mov shuffles around them - more instructions AND more live registers: the fp16 training forward went from 944 to 132
+# bytes of scratch per lane, the inference forward from 700 to 0 (profiles/r03_kernel_resources.txt).
+_NOSLP = ("-fno-slp-vectorize",)
+_TRACKERS = ("-mllvm", "-amdgpu-use-amdgpu-trackers=1") + _NOSLP
 FILE_FLAGS = {"field_wgrad.hip": ("-mllvm", "-amdgpu-sched-strategy=max-ilp"),
-              "field_fwd.hip": ("-DBN_DEPTH_BF16=6",),
+              "field_fwd.hip": _NOSLP,
               "field_bwd.hip": _TRACKERS, "field_adjoint.hip": _TRACKERS, "field_adjbwd.hip": _TRACKERS}
 
 

@@ -20,6 +20,45 @@ void bn_set_error(const char *fmt, ...) {
 extern "C" const char *bn_last_error(void) { return g_err; }
 extern "C" int bn_abi_version(void) { return BN_ABI_VERSION; }
 
+// Every -D switch a source file of the library reacts to (variant builds pass the same defines to every file).
+extern "C" const char *bn_build_flags(void) {
+  return ""
+#ifdef BN_PHASE_TIMING
+         "BN_PHASE_TIMING "
+#endif
+#ifdef BN_PHASE_TIMING_WGRAD
+         "BN_PHASE_TIMING_WGRAD "
+#endif
+#ifdef BN_CLOCK_STAMP
+         "BN_CLOCK_STAMP "
+#endif
+#ifdef BN_CLOCK_STAMP_WGRAD
+         "BN_CLOCK_STAMP_WGRAD "
+#endif
+#ifdef BN_NO_NT_STASH
+         "BN_NO_NT_STASH "
+#endif
+#ifdef BN_NO_PINGPONG
+         "BN_NO_PINGPONG "
+#endif
+#ifdef BN_HEAD_WIDE
+         "BN_HEAD_WIDE "
+#endif
+#ifdef BN_NO_FLAT_COMPOSITE
+         "BN_NO_FLAT_COMPOSITE "
+#endif
+#ifdef BN_DPH
+         "BN_DPH "
+#endif
+#ifdef SKINNY_SPLITS
+         "SKINNY_SPLITS "
+#endif
+#ifdef BN_ABLATION_BUILD
+         "BN_ABLATION_BUILD "
+#endif
+      ;
+}
+
 static std::atomic<int> g_deterministic{0};
 int bn_deterministic() { return g_deterministic.load(std::memory_order_relaxed); }
 extern "C" int bn_set_deterministic(int on) { return g_deterministic.exchange(on ? 1 : 0); }

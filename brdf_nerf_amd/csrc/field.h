@@ -158,10 +158,10 @@ struct StashLayout {
   size_t pe;                      // T [Mpad][KP]
   size_t dirpe;                   // T [Mpad][KD]  extra-input tile rows: encoded view direction, image embedding (FieldGeom.KD)
   size_t Y[BN_MAX_LAYERS];        // T [Mpad][F]  output of trunk layer l
-  size_t D[BN_MAX_LAYERS];        // T native     d act / d z of trunk layer l
+  size_t D[BN_MAX_LAYERS];        // DTile image  d act / d z of trunk layer l: 8-bit fixed point in the 16-bit modes, fp32 native in fp32
   size_t feats;                   // T [Mpad][F]
   size_t G[BN_MAX_PASS];          // T native     head hidden activations
-  size_t DG[BN_MAX_PASS];         // T native
+  size_t DG[BN_MAX_PASS];         // DTile image (like D)
   size_t dZ[BN_MAX_LAYERS];       // T [Mpad][F]                                          (bwd-produced)
   size_t dfeats;                  // T [Mpad][F]                                          (bwd-produced)
   size_t dG[BN_MAX_PASS];         // T [Mpad][pass_N]                                     (bwd-produced)
@@ -179,6 +179,7 @@ struct StashLayout {
 };
 
 static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, int BM, size_t esz, StashLayout *s) {
+  const size_t dsz = esz == 4 ? 4 : 1;   // Elem<T>::kD8: one byte per derivative in the 16-bit modes
   int64_t Mpad = ceil_div64(n_points, BM) * BM;
   s->Mpad = Mpad;
   size_t off = 0;
@@ -192,13 +193,13 @@ static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, in
   s->pe = take((size_t)Mpad * g.KP * esz);
   s->dirpe = g.KD > 0 ? take((size_t)Mpad * g.KD * esz) : 0;
   for (int l = 0; l < g.L; ++l) s->Y[l] = take((size_t)Mpad * g.F * esz);
-  for (int l = 0; l < g.L; ++l) s->D[l] = take((size_t)Mpad * g.F * esz);
+  for (int l = 0; l < g.L; ++l) s->D[l] = take((size_t)Mpad * g.F * dsz);
   s->feats = take((size_t)Mpad * g.F * esz);
   for (int p = 0; p < BN_MAX_PASS; ++p) {
     s->G[p] = s->DG[p] = s->dG[p] = 0;
     if (p < g.n_pass) {
       s->G[p] = take((size_t)Mpad * g.F * esz);   // native images sized for a full-width phase
-      s->DG[p] = take((size_t)Mpad * g.F * esz);
+      s->DG[p] = take((size_t)Mpad * g.F * dsz);
     }
   }
   for (int l = 0; l < g.L; ++l) s->dZ[l] = take((size_t)Mpad * g.F * esz);

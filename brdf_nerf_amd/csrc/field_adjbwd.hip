@@ -46,6 +46,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.pts.n_points;
   const T *packed = (const T *)A.packed;
+  constexpr int DP = BwdDepth<T>::value;
   // fp16 mode: the chain runs scaled by gs (a power of two): gbar_PE, abar_l, zbar_l carry it (the weight-gradient jobs
   // and the primal chain remove it); sbar, an fp32 scalar per point, is stored unscaled
   const float gs = grad_scale_from(A.amax ? A.amax + 1 : nullptr, BN_GS_TARGET_ADJ);
@@ -110,13 +111,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       const size_t t0 = (size_t)(ncol0 / 32);
       const T *w_pe = packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512;
       const T *w_h = packed + A.pl.fwd_trunk[l][l == g.skip ? 1 : 0] + t0 * KSF * 512;
-      if (l == 0 || l == g.skip) gemm_seg<T, MT, NT>(acc, w_pe, KSP, PE, LDP, lane);
+      if (l == 0 || l == g.skip) gemm_seg<T, MT, NT, DP>(acc, w_pe, KSP, PE, LDP, lane);
       if (l > 0) {
         if (ride) {
           TileCopyExact<T> acopy(ACT, LDA, adst, F, F, tid, WAVES * 64);
-          gemm_seg<T, MT, NT>(acc, w_h, KSF, ACT, LDA, lane, acopy);
+          gemm_seg<T, MT, NT, DP>(acc, w_h, KSF, ACT, LDA, lane, acopy);
         } else {
-          gemm_seg<T, MT, NT>(acc, w_h, KSF, ACT, LDA, lane);
+          gemm_seg<T, MT, NT, DP>(acc, w_h, KSF, ACT, LDA, lane);
         }
       }
     }
@@ -153,20 +154,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       const float w0 = (l == 0) ? 30.f : 1.f;
       const float unscale = A.prescaled ? 6.283185307179586f / w0 : 1.f;
       const float e2 = g.act == BN_ACT_SIN ? -w0 * w0 : 0.f;      // dD/dz = -w0^2 sin(w0 z) = -w0^2 y (0 for ReLU)
-      const T *Ds = (const T *)(A.stash + A.sl.D[l]) + (size_t)tile * BM * F;
+      const float dscale = (g.act == BN_ACT_SIN) ? w0 : 1.f;      // the 16-bit modes stash the unscaled derivative (DTile)
+      const char *Ds = A.stash + A.sl.D[l] + (size_t)tile * dtile_bytes<T>(BM, F);
       const T *As = (const T *)(A.stash + A.sl.adj_a[l]) + (size_t)tile * BM * F;
       const T *Yn = (const T *)(A.stash + A.sl.Y[l]) + (size_t)tile * BM * F;        // native-order y_l (16-bit modes)
       typename Elem<T>::wide *Zs = (typename Elem<T>::wide *)(A.stash + A.sl.adj_zbar[l]) + (size_t)tile * BM * F;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
+        for (int mt = 0; mt < MT; ++mt) {
+          const int m = mt * 32 + r;
+          const DPiece<T> pc = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const int m = mt * 32 + r;
+          for (int gp = 0; gp < 2; ++gp) {
+            const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
             float dv[8], av[8], zb[8], db[8], yv[8];
-            ld8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dv);
+            dpiece_get<T>(pc, gp, dscale, dv);
             ld8(As + native_off8<MT, NT>(wave, nt, mt, gp, lane), av);
             if (NATY) {
               ld8(Yn + native_off8<MT, NT>(wave, nt, mt, gp, lane), yv);

@@ -41,6 +41,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
   const int ncol0 = wave * 32 * NT;
   const bool wave_on = ncol0 < F;
   const float *sraw = (const float *)(A.stash + A.sl.sraw);
+  constexpr int DP = BwdDepth<T>::value;
+  constexpr int NPRE = Elem<T>::kD8 ? NT : 1;    // D pieces fetched ahead of the layer's GEMM (field_bwd.hip)
+  auto dscale = [&](int lo) { return (g.act == BN_ACT_SIN && lo == 0) ? 30.f : 1.f; };   // w0 of layer lo (16-bit modes: unscaled stash)
 
   for (int i = tid; i < BM * P; i += WAVES * 64) GP[i] = 0.f;
   char *wstash = const_cast<char *>(A.stash);
@@ -49,18 +52,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
 
   // delta_{L-1} = (sigmoid(s_raw) w_sigma) (.) D_{L-1}
   if (wave_on) {
-    const T *Ds = (const T *)(A.stash + A.sl.D[g.L - 1]) + (size_t)tile * BM * F;
+    const char *Ds = A.stash + A.sl.D[g.L - 1] + (size_t)tile * dtile_bytes<T>(BM, F);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
-        const f32x4 wa = *(const f32x4 *)(A.p.sigma_w + n0), wb = *(const f32x4 *)(A.p.sigma_w + n0 + 8);
+      for (int mt = 0; mt < MT; ++mt) {
+        const DPiece<T> pc = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
+        const int m = mt * 32 + r;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int gp = 0; gp < 2; ++gp) {
+          const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
+          const f32x4 wa = *(const f32x4 *)(A.p.sigma_w + n0), wb = *(const f32x4 *)(A.p.sigma_w + n0 + 8);
           float dv[8];
-          ld8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dv);
-          const int m = mt * 32 + r;
+          dpiece_get<T>(pc, gp, dscale(g.L - 1), dv);
           float av[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) { av[e] = wa[e]; av[4 + e] = wb[e]; }      // a'_L = w_sigma (s' is applied at the end)
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
         f32x16 pacc[1][1];
         zero_acc<1, 1>(pacc);
         const size_t off = A.pl.bwd_pe[l == 0 ? 0 : 1] + (size_t)ptile * KSF * 512;
-        gemm_seg<T, 1, 1>(pacc, packed + off, KSF, ACT + (size_t)mtile * 32 * LDA, LDA, lane);
+        gemm_seg<T, 1, 1, DP>(pacc, packed + off, KSF, ACT + (size_t)mtile * 32 * LDA, LDA, lane);
         const int m = mtile * 32 + r;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
@@ -99,41 +103,38 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
     }
     if (l == 0) break;
     zero_acc<MT, NT>(acc);
-    // D_{l-1} in accumulator order, prefetched around the GEMM (n-tile 0 before it, the rest after its last MFMA)
-    const T *Ds = (const T *)(A.stash + A.sl.D[l - 1]) + (size_t)tile * BM * F;
-    typename Elem<T>::frag dpre[NT][2][MT];
+    // D_{l-1} in accumulator order (DTile pieces), fetched ahead of the GEMM and of the stash stores riding in it
+    const char *Ds = A.stash + A.sl.D[l - 1] + (size_t)tile * dtile_bytes<T>(BM, F);
+    DPiece<T> dpre[NT][MT];
     if (wave_on) {
 #pragma unroll
-      for (int gp = 0; gp < 2; ++gp)
+      for (int nt = 0; nt < NPRE; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) dpre[0][gp][mt] = stash_load((const typename Elem<T>::frag *)(Ds + native_off8<MT, NT>(wave, 0, mt, gp, lane)));
+        for (int mt = 0; mt < MT; ++mt) dpre[nt][mt] = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
       const T *w_t = packed + A.pl.bwd_trunk[l] + (size_t)(ncol0 / 32) * KSF * 512;
       if (keep && ride) {
         TileCopyExact<T> dcopy(ACT, LDA, ddst, F, F, tid, WAVES * 64);
-        gemm_seg<T, MT, NT>(acc, w_t, KSF, ACT, LDA, lane, dcopy);
+        gemm_seg<T, MT, NT, DP>(acc, w_t, KSF, ACT, LDA, lane, dcopy);
       } else {
-        gemm_seg<T, MT, NT>(acc, w_t, KSF, ACT, LDA, lane);
+        gemm_seg<T, MT, NT, DP>(acc, w_t, KSF, ACT, LDA, lane);
       }
 #pragma unroll
-      for (int nt = 1; nt < NT; ++nt)
+      for (int nt = NPRE; nt < NT; ++nt)
 #pragma unroll
-        for (int gp = 0; gp < 2; ++gp)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) dpre[nt][gp][mt] = stash_load((const typename Elem<T>::frag *)(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane)));
+        for (int mt = 0; mt < MT; ++mt) dpre[nt][mt] = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
     }
     __syncthreads();
     if (wave_on) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
+        for (int mt = 0; mt < MT; ++mt) {
+          const int m = mt * 32 + r;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
+          for (int gp = 0; gp < 2; ++gp) {
+            const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
             float dv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dv[e] = (float)dpre[nt][gp][mt][e];
-            const int m = mt * 32 + r;
+            dpiece_get<T>(dpre[nt][mt], gp, dscale(l - 1), dv);
             if (keep) {
               float av[8];
 #pragma unroll

@@ -159,35 +159,40 @@ __device__ __forceinline__ void bwd_head_dG(const BwdArgs &A, int p, T *ACT, con
   const int hl = pc0 / g.H2, hd = 2 * p + hl;
   const int nout = A.d.head_out[hd];
   const float *w2 = A.p.head_w2[hd];
-  const T *DGs = (const T *)(A.stash + A.sl.DG[p]) + (size_t)tile * BM * F;
+  const char *DGs = A.stash + A.sl.DG[p] + (size_t)tile * dtile_bytes<T>(BM, F);
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt)
+  for (int nt = 0; nt < NTW; ++nt) {
+    f32x4 wa[2][3], wb[2][3];
 #pragma unroll
     for (int gp = 0; gp < 2; ++gp) {
-      const int n0 = pc0 + nt * 32 + 16 * gp + 4 * h;
-      const int nl = n0 - hl * g.H2;
-      f32x4 wa[3], wb[3];
+      const int nl = pc0 + nt * 32 + 16 * gp + 4 * h - hl * g.H2;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        wa[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl) : f32x4{0, 0, 0, 0};
-        wb[c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl + 8) : f32x4{0, 0, 0, 0};
+        wa[gp][c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl) : f32x4{0, 0, 0, 0};
+        wb[gp][c] = c < nout ? *(const f32x4 *)(w2 + (size_t)c * g.H2 + nl + 8) : f32x4{0, 0, 0, 0};
       }
+    }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int m = mt * 32 + r;
-        const float d0 = DPH[m * BN_DPH + hd * 3 + 0], d1 = DPH[m * BN_DPH + hd * 3 + 1], d2 = DPH[m * BN_DPH + hd * 3 + 2];
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 32 + r;
+      const float d0 = DPH[m * BN_DPH + hd * 3 + 0], d1 = DPH[m * BN_DPH + hd * 3 + 1], d2 = DPH[m * BN_DPH + hd * 3 + 2];
+      const DPiece<T> pc = dpiece_load<T>(DGs + dpiece_off<T, MT, NTW>(wave, nt, mt, lane));
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const int n0 = pc0 + nt * 32 + 16 * gp + 4 * h;
         float dg[8];
-        ld8(DGs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), dg);
+        dpiece_get<T>(pc, gp, 1.f, dg);
         float va[4], vb[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          va[e] = (d0 * wa[0][e] + d1 * wa[1][e] + d2 * wa[2][e]) * dg[e];
-          vb[e] = (d0 * wb[0][e] + d1 * wb[1][e] + d2 * wb[2][e]) * dg[4 + e];
+          va[e] = (d0 * wa[gp][0][e] + d1 * wa[gp][1][e] + d2 * wa[gp][2][e]) * dg[e];
+          vb[e] = (d0 * wb[gp][0][e] + d1 * wb[gp][1][e] + d2 * wb[gp][2][e]) * dg[4 + e];
         }
         *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), va[0], va[1], va[2], va[3]);
         *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), vb[0], vb[1], vb[2], vb[3]);
       }
     }
+  }
 }
 
 template <typename T, int MT, int NT, int WAVES>
@@ -204,6 +209,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.M;
   const T *packed = (const T *)A.packed;
+  constexpr int DP = BwdDepth<T>::value;
+  // D_lo pieces fetched before the layer's GEMM (the rest right after its last MFMA): all of them when a piece is 16 bytes
+  constexpr int NPRE = Elem<T>::kD8 ? NT : 1;
   BN_PH_DECL
   BN_CLK_BEGIN
 
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
     BN_PH(3)
     const int KSp = g.pass_N[p] / 16;
     tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dG[p]) + (size_t)m0 * g.pass_N[p], g.pass_N[p], BM, g.pass_N[p]);
-    if (wave_on) gemm_seg<T, MT, NT>(acc, packed + A.pl.bwd_head[p] + (size_t)(ncol0 / 32) * KSp * 512, KSp, ACT, LDA, lane);
+    if (wave_on) gemm_seg<T, MT, NT, DP>(acc, packed + A.pl.bwd_head[p] + (size_t)(ncol0 / 32) * KSp * 512, KSp, ACT, LDA, lane);
     BN_PH(4)
     __syncthreads();
     BN_PH(5)
@@ -278,54 +286,50 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
     const bool folded_top = g.fold && l == g.L;   // the product is already in the accumulators
     if (!folded_top) zero_acc<MT, NT>(acc);
     const int lo = l - 1;  // layer whose pre-activation gradient is produced
-    // D_lo = d act / d z of that layer, read back in accumulator order.  The loads are issued around the GEMM -
-    // n-tile 0 before it (in flight while the MFMAs run), the others right after its last MFMA, when the weight and
-    // activation fragment registers are free - so the epilogue does not sit on HBM latency.
-    const T *Ds = (const T *)(A.stash + A.sl.D[lo]) + (size_t)tile * BM * F;
-    typename Elem<T>::frag dpre[NT][2][MT];
+    // D_lo = d act / d z of that layer, read back in accumulator order (DTile pieces).  The loads are issued BEFORE the
+    // GEMM - ahead of the stash stores riding in it, in flight while the MFMAs run - so the epilogue neither sits on HBM
+    // latency nor queues behind those stores (fp32 mode: only n-tile 0 fits there, the others follow the last MFMA).
+    const char *Ds = A.stash + A.sl.D[lo] + (size_t)tile * dtile_bytes<T>(BM, F);
+    DPiece<T> dpre[NT][MT];
     T *zdst = (T *)(A.stash + (l == g.L ? A.sl.dfeats : A.sl.dZ[l])) + (size_t)m0 * F;
     if (!ride && !folded_top) tile_to_global<T>(ACT, LDA, zdst, F, BM, F);
     if (wave_on) {
 #pragma unroll
-      for (int gp = 0; gp < 2; ++gp)
+      for (int nt = 0; nt < NPRE; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) dpre[0][gp][mt] = stash_load((const typename Elem<T>::frag *)(Ds + native_off8<MT, NT>(wave, 0, mt, gp, lane)));
+        for (int mt = 0; mt < MT; ++mt) dpre[nt][mt] = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
       const size_t off = (l == g.L ? A.pl.bwd_feats : A.pl.bwd_trunk[l]) + (size_t)(ncol0 / 32) * KSF * 512;
       // the row-major stash copy of the tile this GEMM reads (dFeats, then dZ_l) rides inside the GEMM
       if (folded_top) {
-#ifdef BN_AB_BWD_NATIVE_DZ   // ablation (weight gradients wrong): no riding row-major dZ copy; dZ is stored in accumulator order
-      } else if (true) {     // from the epilogue's registers instead - what a native-order dZ stash would cost the chain
-        gemm_seg<T, MT, NT>(acc, packed + off, KSF, ACT, LDA, lane);
-#endif
       } else if (ride) {
         TileCopyExact<T> zcopy(ACT, LDA, zdst, F, F, tid, WAVES * 64);
-        gemm_seg<T, MT, NT>(acc, packed + off, KSF, ACT, LDA, lane, zcopy);
+        gemm_seg<T, MT, NT, DP>(acc, packed + off, KSF, ACT, LDA, lane, zcopy);
       } else {
-        gemm_seg<T, MT, NT>(acc, packed + off, KSF, ACT, LDA, lane);
+        gemm_seg<T, MT, NT, DP>(acc, packed + off, KSF, ACT, LDA, lane);
       }
 #pragma unroll
-      for (int nt = 1; nt < NT; ++nt)
+      for (int nt = NPRE; nt < NT; ++nt)
 #pragma unroll
-        for (int gp = 0; gp < 2; ++gp)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) dpre[nt][gp][mt] = stash_load((const typename Elem<T>::frag *)(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane)));
+        for (int mt = 0; mt < MT; ++mt) dpre[nt][mt] = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
     }
     BN_PH(9)
     __syncthreads();
     BN_PH(10)
     if (wave_on) {
       const bool top = l == g.L, nlr = g.ch_normal_lr >= 0;
+      const float dscale = (g.act == BN_ACT_SIN && lo == 0) ? 30.f : 1.f;    // w0 of layer lo (the stash holds the unscaled derivative)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
+        for (int mt = 0; mt < MT; ++mt) {
+          const int m = mt * 32 + r;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const int m = mt * 32 + r;
+          for (int gp = 0; gp < 2; ++gp) {
+            const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
             float dv[8], v[8];
+            dpiece_get<T>(dpre[nt][mt], gp, Elem<T>::kD8 ? dscale : 1.f, dv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { dv[e] = (float)dpre[nt][gp][mt][e]; v[e] = acc[nt][mt][8 * gp + e]; }
+            for (int e = 0; e < 8; ++e) v[e] = acc[nt][mt][8 * gp + e];
             if (top) {  // rank-1 terms of the sigma head and the learned-normal head
               const float ds = DPT[m * 4], a0 = DPT[m * 4 + 1], a1 = DPT[m * 4 + 2], a2 = DPT[m * 4 + 3];
 #pragma unroll
@@ -352,9 +356,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
             }
             *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), v[0], v[1], v[2], v[3]);
             *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), v[4], v[5], v[6], v[7]);
-#ifdef BN_AB_BWD_NATIVE_DZ
-            st8((T *)(A.stash + A.sl.dZ[lo]) + (size_t)tile * BM * F + native_off8<MT, NT>(wave, nt, mt, gp, lane), v);
-#endif
           }
         }
     }
@@ -362,9 +363,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
     __syncthreads();
     BN_PH(12)
   }
-#ifndef BN_AB_BWD_NATIVE_DZ
   tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dZ[0]) + (size_t)m0 * F, F, BM, F);
-#endif
   BN_PH(13)
 #ifndef BN_PHASE_TIMING_WGRAD
   BN_PH_FLUSH

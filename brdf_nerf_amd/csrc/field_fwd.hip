@@ -22,6 +22,9 @@ struct FwdArgs {
 // w0/(2 pi) (bn_pack_field), so `z` already is the argument of v_sin_f32/v_cos_f32 in revolutions: one transcendental
 // per output, no range-reduction multiplies.  The parity mode keeps z = W x + b and the accurate sincos.
 #define BN_INV_2PI 0.15915494309189535f
+#ifndef BN_EPI_FENCE
+#define BN_EPI_FENCE
+#endif
 
 // sticky fault word of the forward kernels (lost LDS hand-over in the barrier-free trunk, field_kernels.h pp_wait)
 __device__ unsigned int g_fwd_fault;
@@ -30,18 +33,17 @@ static unsigned int g_fwd_launches = 0;
 
 BN_PH_DEFINE_READER(bn_debug_phase_read_fwd)
 BN_CLK_DEFINE(bn_debug_clock_read_fwd)
-template <bool FAST, int ACT> __device__ __forceinline__ void act_eval(float z, float w0, float &y, float &d) {
+// `c` is the UNSCALED derivative (cos(.) / the ReLU mask); d act / d z = w0 c for a Siren layer (DTile, field_kernels.h).
+template <bool FAST, int ACT> __device__ __forceinline__ void act_eval(float z, float w0, float &y, float &c) {
   if (ACT == BN_ACT_SIN) {
     if (FAST) {
       y = __builtin_amdgcn_sinf(z);
-      d = w0 * __builtin_amdgcn_cosf(z);
+      c = __builtin_amdgcn_cosf(z);
     } else {
-      float s, c;
-      sincos_cw(w0 * z, s, c);
-      y = s; d = w0 * c;
+      sincos_cw(w0 * z, y, c);
     }
   } else {
-    y = z > 0.f ? z : 0.f; d = z > 0.f ? 1.f : 0.f;
+    y = z > 0.f ? z : 0.f; c = z > 0.f ? 1.f : 0.f;
   }
 }
 template <bool FAST> __device__ __forceinline__ float act_prescale(int act, float w0) {
@@ -100,6 +102,7 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
 ) {
   constexpr int BM = MT * 32;
   constexpr bool FAST = Elem<T>::kFastMath;
+  constexpr int DP = FwdDepth<T, KEEP>::value;
   const FieldGeom &g = A.g;
   const int F = g.F, LDA = F + Elem<T>::kPad, KSF = F / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -128,26 +131,27 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
   }
   f32x16 acc[NTW][MT];
   zero_acc<MT, NTW>(acc);
-  if (on) gemm_seg<T, MT, NTW>(acc, (const T *)A.packed + A.pl.fwd_head[p] + (size_t)(pc0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
+  if (on) gemm_seg<T, MT, NTW, DP>(acc, (const T *)A.packed + A.pl.fwd_head[p] + (size_t)(pc0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
   BN_PH(9)
   __syncthreads();   // PRM (and the direction tile) filled
   if constexpr (DIR) {
     if (dir_on) {
       const int KSD = g.KD / 16;
       if (keep) tile_to_global<T>(DIRT, LDD, (T *)(A.stash + A.sl.dirpe) + (size_t)m0 * g.KD, g.KD, BM, g.KD);
-      if (on) gemm_seg<T, MT, NTW>(acc, (const T *)A.packed + A.pl.fwd_dir + (size_t)(pc0 / 32) * KSD * 512, KSD, DIRT, LDD, lane);
+      if (on) gemm_seg<T, MT, NTW, DP>(acc, (const T *)A.packed + A.pl.fwd_dir + (size_t)(pc0 / 32) * KSD * 512, KSD, DIRT, LDD, lane);
     }
   }
   if (on) {
     T *Gs = keep ? (T *)(A.stash + A.sl.G[p]) + (size_t)tile * BM * F : nullptr;
-    T *DGs = keep ? (T *)(A.stash + A.sl.DG[p]) + (size_t)tile * BM * F : nullptr;
+    char *DGs = keep ? A.stash + A.sl.DG[p] + (size_t)tile * dtile_bytes<T>(BM, F) : nullptr;
     float part[MT][3];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) part[mt][0] = part[mt][1] = part[mt][2] = 0.f;
     auto epilogue = [&](auto act_tag) {
       constexpr int ACTK = decltype(act_tag)::value;
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)
+      for (int nt = 0; nt < NTW; ++nt) {
+        DHalf<T> dh0[MT];     // derivative bytes of group gp = 0, stored with those of gp = 1 (one 16-byte piece per lane)
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
           const int n0 = pc0 + nt * 32 + 16 * gp + 4 * h;   // column in the pass of the first run (second: +8)
@@ -160,6 +164,7 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
           }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
+            BN_EPI_FENCE
             float y[8], dd[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -172,7 +177,8 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
             for (int e = 0; e < 8; ++e) y[e] = (float)yq[e];
             if (keep) {
               st_frag(Gs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), yq);
-              st8(DGs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), dd);
+              if (gp == 0) dh0[mt] = dhalf_make<T>(dd, 1.f);
+              else dpiece_store<T>(DGs + dpiece_off<T, MT, NTW>(wave, nt, mt, lane), dh0[mt], dhalf_make<T>(dd, 1.f));
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c)
@@ -180,6 +186,7 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
               for (int e = 0; e < 4; ++e) part[mt][c] += y[e] * wa[c][e] + y[4 + e] * wb[c][e];
           }
         }
+      }
     };
     if (g.act == BN_ACT_SIN) epilogue(std::integral_constant<int, BN_ACT_SIN>());
     else epilogue(std::integral_constant<int, BN_ACT_RELU>());
@@ -239,6 +246,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
   constexpr int PADE = Elem<T>::kPad;
   constexpr bool FAST = Elem<T>::kFastMath;
   constexpr bool NATY = Elem<T>::kNativeY;
+  constexpr int DP = FwdDepth<T, KEEP>::value;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const FieldGeom &g = A.g;
   const int F = g.F, LDA = F + PADE, KP = g.KP, LDP = KP + PADE;
@@ -325,47 +333,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
       const size_t t0 = (size_t)(ncol0 / 32);
       const T *w_pe = packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512;
       const T *w_h = packed + A.pl.fwd_trunk[l][l == g.skip ? 1 : 0] + t0 * KSF * 512;
-      if (l == 0 || l == g.skip) gemm_seg<T, MT, NT>(acc, w_pe, KSP, PE, LDP, lane);
+      if (l == 0 || l == g.skip) gemm_seg<T, MT, NT, DP>(acc, w_pe, KSP, PE, LDP, lane);
       if (l > 0) {
         if (PING) {
           const int half = KSF / 2;
-          T *ydst = (T *)(A.stash + A.sl.Y[l - 1]) + (size_t)m0 * F;
           NoSide none;
           BN_PH(1)
           pp_wait(WR + 0, 4 * l, &g_fwd_fault);                       // half 0 of Y_{l-1} is written
           if (grp == 1) pp_wait(RD + 0, 4 * l, &g_fwd_fault);         // group 0 is done with its phase 1 of this layer: the lag
           BN_PH(12)
-#ifdef BN_AB_NO_Y_COPY        // ablation (results wrong): the forward without the row-major Y copies riding in the GEMMs
-          if (false) {
-#else
-          if (keep && !NATY && grp == 0) {              // (row-major Y stash only) a group's half of the copy rides in the phase that reads it
-#endif
-            TileCopyHalf<T> ycopy(ACT, LDA, ydst, F, 0, F / 2, tid & 255);
-            gemm_range<T, MT, NT>(acc, w_h, KSF, 0, half, ACT, LDA, lane, ycopy);
-          } else {
-            gemm_range<T, MT, NT>(acc, w_h, KSF, 0, half, ACT, LDA, lane, none);
-          }
+          gemm_range<T, MT, NT, DP>(acc, w_h, KSF, 0, half, ACT, LDA, lane, none);
           BN_PH(1)
           pp_signal(RD + 0 + grp, lane);
           pp_wait(WR + 1, 4 * l, &g_fwd_fault);                       // half 1
           BN_PH(13)
-#ifdef BN_AB_NO_Y_COPY
-          if (false) {
-#else
-          if (keep && !NATY && grp == 1) {
-#endif
-            TileCopyHalf<T> ycopy(ACT, LDA, ydst, F, F / 2, F / 2, tid & 255);
-            gemm_range<T, MT, NT>(acc, w_h, KSF, half, half, ACT, LDA, lane, ycopy);
-          } else {
-            gemm_range<T, MT, NT>(acc, w_h, KSF, half, half, ACT, LDA, lane, none);
-          }
+          gemm_range<T, MT, NT, DP>(acc, w_h, KSF, half, half, ACT, LDA, lane, none);
           pp_signal(RD + 2 + grp, lane);
         } else if (keep && !NATY && ride) {
           // the row-major stash copy of Y_{l-1} (the tile this GEMM reads) rides inside the GEMM when the shape fits
           TileCopyExact<T> ycopy(ACT, LDA, (T *)(A.stash + A.sl.Y[l - 1]) + (size_t)m0 * F, F, F, tid, WAVES * 64);
-          gemm_seg<T, MT, NT>(acc, w_h, KSF, ACT, LDA, lane, ycopy);
+          gemm_seg<T, MT, NT, DP>(acc, w_h, KSF, ACT, LDA, lane, ycopy);
         } else {
-          gemm_seg<T, MT, NT>(acc, w_h, KSF, ACT, LDA, lane);
+          gemm_seg<T, MT, NT, DP>(acc, w_h, KSF, ACT, LDA, lane);
         }
       }
     }
@@ -396,12 +385,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
     }
     BN_PH(2)
     if (wave_on) {
-      T *Ds = keep ? (T *)(A.stash + A.sl.D[l]) + (size_t)tile * BM * F : nullptr;
+      char *Ds = keep ? A.stash + A.sl.D[l] + (size_t)tile * dtile_bytes<T>(BM, F) : nullptr;
       T *Ys = keep ? (T *)(A.stash + A.sl.Y[l]) + (size_t)tile * BM * F : nullptr;   // native order (16-bit modes)
       auto epilogue = [&](auto act_tag) {
         constexpr int ACTK = decltype(act_tag)::value;
+        const float dsc = ACTK == BN_ACT_SIN ? w0 : 1.f;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+          DHalf<T> dh0[MT];     // derivative bytes of group gp = 0, stored with those of gp = 1 (one 16-byte piece per lane)
 #pragma unroll
           for (int gp = 0; gp < 2; ++gp) {
             const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
@@ -424,11 +415,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
                 *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), y[0], y[1], y[2], y[3]);
                 *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), y[4], y[5], y[6], y[7]);
               }
-#ifndef BN_AB_NO_D_STASH     // ablation (results wrong): the forward without its D stash stores
-              if (keep) st8(Ds + native_off8<MT, NT>(wave, nt, mt, gp, lane), dd);
-#endif
+              if (keep) {
+                if (gp == 0) dh0[mt] = dhalf_make<T>(dd, dsc);
+                else dpiece_store<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane), dh0[mt], dhalf_make<T>(dd, dsc));
+              }
             }
           }
+        }
       };
       if (g.act == BN_ACT_SIN) epilogue(std::integral_constant<int, BN_ACT_SIN>());
       else epilogue(std::integral_constant<int, BN_ACT_RELU>());
@@ -459,8 +452,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
     zero_acc<MT, 1>(nacc);
     if (kon) {
       NoSide none;
-      gemm_range<T, MT, 1>(sacc, packed + A.pl.fwd_sigma, KSF, ks0, nks, ACT, LDA, lane, none);
-      if (nlr) gemm_range<T, MT, 1>(nacc, packed + A.pl.fwd_nlr, KSF, ks0, nks, ACT, LDA, lane, none);
+      gemm_range<T, MT, 1, DP>(sacc, packed + A.pl.fwd_sigma, KSF, ks0, nks, ACT, LDA, lane, none);
+      if (nlr) gemm_range<T, MT, 1, DP>(nacc, packed + A.pl.fwd_nlr, KSF, ks0, nks, ACT, LDA, lane, none);
     }
     if (h == 0) {                                      // accumulator rows 0..3 live in registers 0..3 of lanes 0-31
 #pragma unroll
@@ -563,9 +556,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
     const T *w_f = packed + A.pl.fwd_feats + (size_t)(ncol0 / 32) * KSF * 512;
     if (keep && !NATY && ride) {
       TileCopyExact<T> ycopy(ACT, LDA, (T *)(A.stash + A.sl.Y[g.L - 1]) + (size_t)m0 * F, F, F, tid, WAVES * 64);
-      gemm_seg<T, MT, NT>(acc, w_f, KSF, ACT, LDA, lane, ycopy);
+      gemm_seg<T, MT, NT, DP>(acc, w_f, KSF, ACT, LDA, lane, ycopy);
     } else {
-      gemm_seg<T, MT, NT>(acc, w_f, KSF, ACT, LDA, lane);
+      gemm_seg<T, MT, NT, DP>(acc, w_f, KSF, ACT, LDA, lane);
     }
   }
   BN_PH(7)

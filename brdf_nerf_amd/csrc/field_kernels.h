@@ -65,9 +65,7 @@ static __device__ unsigned long long bn_phase_clk[BN_PH_N + 1];
 // packed weights every workgroup re-reads from L2: non-temporal stores / loads keep it from evicting the weights.
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 template <typename V> __device__ __forceinline__ void stash_store(V *p, const V &v) {
-#ifdef BN_SKIP_STASH_STORES   // diagnostic variant (profiles/ab_bench.sh): what the stash writes cost (results are wrong)
-  if (p == nullptr) *p = v;
-#elif defined(BN_NO_NT_STASH)
+#ifdef BN_NO_NT_STASH      // A/B switch (results unchanged): plain stores / loads for the stash
   *p = v;
 #else
   __builtin_nontemporal_store(v, p);
@@ -147,26 +145,6 @@ template <typename T> struct TileCopyExact {
 };
 __host__ __device__ __forceinline__ bool tile_copy_exact(int F, int n_on, int waves) { return n_on == waves && F % 256 == 0; }
 
-// Ping-pong form (F = 512, 8 waves in two groups of four): a group copies ITS half (halfw columns from col0) of the
-// tile, one chunk per thread at every k-step of its 16-step own-half segment (256 threads x 16 chunks = the half tile
-// for both element types: 128 rows x 512 B in bf16, 64 rows x 1 KB in fp32).
-template <typename T> struct TileCopyHalf {
-  static constexpr int EPC = 16 / sizeof(T);
-  const T *lp;
-  T *gp;
-  int lstep, gstep;
-  __device__ __forceinline__ TileCopyHalf(const T *lds, int ld, T *g, int gld, int col0, int halfw, int tg) {
-    const int cph = halfw / EPC, row = tg / cph, col = col0 + (tg % cph) * EPC, rstep = 256 / cph;
-    lp = lds + (size_t)row * ld + col;
-    gp = g + (size_t)row * gld + col;
-    lstep = rstep * ld; gstep = rstep * gld;
-  }
-  __device__ __forceinline__ void at(int) {
-    stash_store((u32x4 *)gp, *(const u32x4 *)lp);
-    lp += lstep; gp += gstep;
-  }
-};
-
 // Flags of the two-group ping-pong (LDS ints, zeroed before first use): counters only grow; a waiter spins with
 // s_sleep until the count is reached.  LDS executes one wave's operations in issue order, so data written before a
 // signal is visible to whoever sees the signal.  The spin is bounded (a count that is never reached in a correct run):
@@ -188,19 +166,18 @@ __device__ __forceinline__ void pp_signal(int *flag, int lane) {
   if (lane == 0) __hip_atomic_fetch_add((lds_int *)flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-#ifndef BN_DEPTH_BF16
-#define BN_DEPTH_BF16 4
-#endif
-template <typename T> struct PipeDepth { static constexpr int value = 4; };
-template <> struct PipeDepth<bf16> { static constexpr int value = BN_DEPTH_BF16; };
-template <> struct PipeDepth<f16> { static constexpr int value = BN_DEPTH_BF16; };
+// Weight-fragment prefetch depth of the chain GEMM (k-steps in flight per wave), chosen per kernel instantiation
+// (profiles/r02_ablation.txt session 42: the training forward gains 1-1.7 % with 6, the backward / adjoint chains 1-3 % with 2).
+template <typename T, bool TRAIN_FWD> struct FwdDepth { static constexpr int value = 4; };
+template <> struct FwdDepth<bf16, true> { static constexpr int value = 6; };
+template <> struct FwdDepth<f16, true> { static constexpr int value = 6; };
+template <typename T> struct BwdDepth { static constexpr int value = Elem<T>::kFastMath ? 2 : 4; };
 
-template <typename T, int MT, int NTW, typename Side>
+template <typename T, int MT, int NTW, int DEPTH, typename Side>
 __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, int ks0, int nks, const T *bsrc,
                                            int ldb, int lane, Side &side) {
   // k-steps [ks0, ks0 + nks) of a packed matrix whose n-tiles are KS k-steps apart
   typedef typename Elem<T>::frag frag;
-  constexpr int DEPTH = PipeDepth<T>::value;
   static_assert(DEPTH % 2 == 0, "side jobs rely on an even pipeline depth");
   const int r = lane & 31, h = lane >> 5;
   const T *wl = wp + (size_t)lane * 8;
@@ -208,9 +185,6 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
   const int kend = ks0 + nks;
   frag A[DEPTH][NTW], Bc[MT];
   auto loadA = [&](frag(&a)[NTW], int ks) {
-#ifdef BN_SKIP_A       // diagnostic variant (profiles/ab_bench.sh): no weight stream after the prologue
-    if (ks >= ks0 + DEPTH) return;
-#endif
     ks = ks < kend ? ks : kend - 1;
     {
 #pragma unroll
@@ -221,44 +195,13 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) B[mt] = lds_frag<T>(bl + (size_t)mt * 32 * ldb + ks * 16);
   };
-#ifdef BN_AB_MFMA16
-  // Ablation (results WRONG by construction; profiles/ab_bench.sh): what would v_mfma_f32_16x16x32_bf16 buy through the
-  // clock the chip holds (MI355X_MICROARCH.md, DVFS give-back item 7)?  The same two operand registers go to two 16x16x32
-  // MFMAs per 32x32x16 one - equal FLOPs, equal matrix-pipe cycles, equal operand and accumulator register traffic per
-  // FLOP; every accumulator quad is written every second k-step - on accumulator quads held as separate 4-register values
-  // inside the loop (copied in and out around it), before fragment / accumulator / stash layouts are re-plumbed for it.
-  constexpr bool AB16 = std::is_same<T, bf16>::value;
-  f32x4 q[NTW][MT][4];
-  if (AB16) {
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) q[nt][mt][i] = f32x4{acc[nt][mt][4 * i], acc[nt][mt][4 * i + 1], acc[nt][mt][4 * i + 2], acc[nt][mt][4 * i + 3]};
-  }
-#endif
-  auto step = [&](frag(&a)[NTW], int ks, int par) {   // consumes Bc (fragments of k-step ks), leaves those of ks+1 in Bc
+  auto step = [&](frag(&a)[NTW], int ks) {   // consumes Bc (fragments of k-step ks), leaves those of ks+1 in Bc
     frag Bn[MT];
-#ifdef BN_SKIP_B       // diagnostic variant: no LDS fragment reads after the first
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) Bn[mt] = Bc[mt];
-#else
     loadB(Bn, ks + 1 < kend ? ks + 1 : ks0);
-#endif
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-#ifdef BN_AB_MFMA16
-        if constexpr (AB16) {
-          q[nt][mt][2 * par] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], Bc[mt], q[nt][mt][2 * par], 0, 0, 0);
-          q[nt][mt][2 * par + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[mt], a[nt], q[nt][mt][2 * par + 1], 0, 0, 0);
-          continue;
-        }
-#endif
-        mma32(acc[nt][mt], a[nt], Bc[mt]);
-      }
+      for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], a[nt], Bc[mt]);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) Bc[mt] = Bn[mt];
   };
@@ -270,7 +213,7 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
   for (; ks + DEPTH <= kend; ks += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      step(A[d], ks + d, d & 1);
+      step(A[d], ks + d);
       loadA(A[d], ks + d + DEPTH);
       side.at(d & 1);   // constant after unrolling
       __builtin_amdgcn_sched_barrier(0);
@@ -279,30 +222,20 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
     if (ks + d < kend) {
-      step(A[d], ks + d, d & 1);
+      step(A[d], ks + d);
       side.at(d & 1);
     }
-#ifdef BN_AB_MFMA16
-  if (AB16) {
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nt][mt][i] = q[nt][mt][i >> 2][i & 3];
-  }
-#endif
 }
-template <typename T, int MT, int NTW, typename Side>
+template <typename T, int MT, int NTW, int DEPTH, typename Side>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb,
                                          int lane, Side &side) {
-  gemm_range<T, MT, NTW, Side>(acc, wp, KS, 0, KS, bsrc, ldb, lane, side);
+  gemm_range<T, MT, NTW, DEPTH, Side>(acc, wp, KS, 0, KS, bsrc, ldb, lane, side);
 }
-template <typename T, int MT, int NTW>
+template <typename T, int MT, int NTW, int DEPTH>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb,
                                          int lane) {
   NoSide none;
-  gemm_range<T, MT, NTW, NoSide>(acc, wp, KS, 0, KS, bsrc, ldb, lane, none);
+  gemm_range<T, MT, NTW, DEPTH, NoSide>(acc, wp, KS, 0, KS, bsrc, ldb, lane, none);
 }
 
 template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NTW][MT]) {
@@ -369,6 +302,84 @@ __device__ __forceinline__ void ld8(const float *p, float (&v)[8]) {
   const f32x4 a = stash_load((const f32x4 *)p), b = stash_load((const f32x4 *)(p + 4));
 #pragma unroll
   for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+
+// ------------------------------------------------------------------ the derivative stash D_l = d act / d z  (and DG of the heads)
+// The backward chains only ever multiply by it element-wise, so it does not have to be an MFMA operand type.
+// 16-bit modes (Elem<T>::kD8): 8-bit fixed point of the UNSCALED derivative c (cos(.) of a Siren layer, 0 / 1 of a ReLU
+// layer), u = rne(127 c + 128) in [1, 255]; the consumer multiplies by the layer's w0.  Absolute error <= 1/254 of the
+// largest derivative, rms 2.3e-3 - the size of the bf16 rounding of the gradient operand it multiplies; a ReLU mask is exact
+// to 1 ulp.  Half the bytes of a 16-bit image: the forward writes 3 instead of 4 bytes per activation, the backward chains
+// read 1 instead of 2, and a layer's whole image is 32 registers per lane - all of it is prefetched BEFORE the layer's GEMM,
+// ahead of the stash stores riding in that GEMM (vmcnt retires in issue order: a load issued after them waits for them).
+// One piece = this lane's derivatives of one 32x32 accumulator tile (nt, mt): both 16-feature groups gp = 0, 1, i.e.
+// accumulator registers 0..15, 16 bytes per lane, one coalesced 1 KB access per wave instruction.
+// fp32 parity mode: the scaled derivative in fp32, 64 bytes per lane and tile.
+template <typename T> struct DPiece { u32x4 w; };
+template <> struct DPiece<float> { f32x4 v[4]; };
+template <typename T> __host__ __device__ constexpr size_t dtile_bytes(int BM, int F) { return (size_t)BM * F * (Elem<T>::kD8 ? 1 : sizeof(T)); }
+template <typename T, int MT, int NTW> __device__ __forceinline__ size_t dpiece_off(int wave, int nt, int mt, int lane) {
+  return ((((size_t)(wave * NTW + nt) * MT + mt) * 64) + lane) * (Elem<T>::kD8 ? 16 : 64);
+}
+// 8 unscaled derivatives -> 8 bytes.  127 c + 128 + 1.5 * 2^23 has the rounded integer in the low mantissa bits (ulp 1);
+// the four floats' bit patterns are combined with shifts and the bias bytes removed in one add (all mod 2^32).
+__device__ __forceinline__ unsigned int d8_pack4(float c0, float c1, float c2, float c3) {
+  const unsigned int b0 = __float_as_uint(fmaf(c0, 127.f, 12583040.f)), b1 = __float_as_uint(fmaf(c1, 127.f, 12583040.f)),
+                     b2 = __float_as_uint(fmaf(c2, 127.f, 12583040.f)), b3 = __float_as_uint(fmaf(c3, 127.f, 12583040.f));
+  return b0 + (b1 << 8) + (b2 << 16) + (b3 << 24) + 0x74C00000u;    // - 0x4B400000 * (1 + 2^8 + 2^16 + 2^24) mod 2^32
+}
+__device__ __forceinline__ void d8_unpack4(unsigned int w, float k, float (&d)[4]) {     // k = scale / 127
+  d[0] = fmaf((float)(w & 0xffu), k, -128.f * k);
+  d[1] = fmaf((float)((w >> 8) & 0xffu), k, -128.f * k);
+  d[2] = fmaf((float)((w >> 16) & 0xffu), k, -128.f * k);
+  d[3] = fmaf((float)(w >> 24), k, -128.f * k);
+}
+// Producer side: one 16-feature group (gp) at a time.  c[e] = unscaled derivative of accumulator register 8 gp + e; `scale`
+// (w0) is applied here in the fp32 mode only.  The two halves of a piece are stored together (one 16-byte store per lane).
+template <typename T> struct DHalf { unsigned int w[2]; };
+template <> struct DHalf<float> { f32x4 v[2]; };
+template <typename T> __device__ __forceinline__ DHalf<T> dhalf_make(const float (&c)[8], float scale) {
+  DHalf<T> r;
+  if constexpr (Elem<T>::kD8) {
+    r.w[0] = d8_pack4(c[0], c[1], c[2], c[3]);
+    r.w[1] = d8_pack4(c[4], c[5], c[6], c[7]);
+  } else {
+    r.v[0] = f32x4{c[0] * scale, c[1] * scale, c[2] * scale, c[3] * scale};
+    r.v[1] = f32x4{c[4] * scale, c[5] * scale, c[6] * scale, c[7] * scale};
+  }
+  return r;
+}
+template <typename T> __device__ __forceinline__ void dpiece_store(char *p, const DHalf<T> &h0, const DHalf<T> &h1) {
+  if constexpr (Elem<T>::kD8) {
+    stash_store((u32x4 *)p, u32x4{h0.w[0], h0.w[1], h1.w[0], h1.w[1]});
+  } else {
+    stash_store((f32x4 *)p, h0.v[0]); stash_store((f32x4 *)p + 1, h0.v[1]);
+    stash_store((f32x4 *)p + 2, h1.v[0]); stash_store((f32x4 *)p + 3, h1.v[1]);
+  }
+}
+template <typename T> __device__ __forceinline__ DPiece<T> dpiece_load(const char *p) {
+  DPiece<T> r;
+  if constexpr (Elem<T>::kD8) {
+    r.w = stash_load((const u32x4 *)p);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r.v[q] = stash_load((const f32x4 *)p + q);
+  }
+  return r;
+}
+// scaled derivatives of group gp (accumulator registers 8 gp .. 8 gp + 7)
+template <typename T> __device__ __forceinline__ void dpiece_get(const DPiece<T> &pc, int gp, float scale, float (&d)[8]) {
+  if constexpr (Elem<T>::kD8) {
+    const float k = scale * (1.f / 127.f);
+    float lo[4], hi[4];
+    d8_unpack4(pc.w[2 * gp], k, lo);
+    d8_unpack4(pc.w[2 * gp + 1], k, hi);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { d[e] = lo[e]; d[4 + e] = hi[e]; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { d[e] = pc.v[2 * gp][e]; d[4 + e] = pc.v[2 * gp + 1][e]; }
+  }
 }
 
 // Copy the workgroup's LDS tile [rows][width] (row stride ld) to a row-major global array [rows][gld] in 16-byte

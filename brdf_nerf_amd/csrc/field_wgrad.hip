@@ -239,7 +239,6 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   // every global load has a whole stage of MFMAs to arrive, every LDS buffer one barrier between its last read and its
   // next write.
   u32x4 ra[NC], rb[NC];
-  [[maybe_unused]] int64_t m_dbg = mb;   // diagnostic variants only
   // columns beyond a row-major operand's extent read one 16-byte block of zeros with row stride 0: the stage loop has no
   // branch (an exec-masked load per chunk split its basic block and cost 6 % of the kernel: profiles/r01_ablation.txt)
   const T *pa = a_ok ? gA + cc : (const T *)w2_zeros, *pb = b_ok ? gB + cc : (const T *)w2_zeros;
@@ -258,9 +257,6 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
     }
   };
   auto gload = [&](int64_t m) {
-#ifdef W2_SKIP_GLOAD   // diagnostic variant (profiles/ab_bench.sh): compute side only
-    if (m > mb + W2_BK) return;
-#endif
 #pragma unroll
     for (int c = 0; c < NC; ++c) gload1(m, c);
   };
@@ -277,9 +273,6 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
     }
   };
   auto sstore = [&](int buf) {
-#ifdef W2_SKIP_SSTORE
-    if (m_dbg > mb) return;
-#endif
 #pragma unroll
     for (int c = 0; c < NC; ++c) sstore1(buf, c);
   };
@@ -312,19 +305,12 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
 #pragma unroll
     for (int i = 0; i < W2_BK / 16; ++i) {
       const int cur = i & 1;
-#ifdef W2_SKIP_FRAGS
-      if (m_dbg == mb)
-#endif
       if (i + 1 < W2_BK / 16) frags(cur ^ 1, (i + 1) * 16);
       __builtin_amdgcn_sched_barrier(0);
-#ifdef W2_SKIP_MFMA    // diagnostic variant: memory side only (one MFMA keeps the fragment reads alive)
-      if (NBV == 4) mma32(acc[0][0], fa[cur][0] + fa[cur][1], fb[cur][0] + fb[cur][1] + fb[cur][2] + fb[cur][3]);
-#else
 #pragma unroll
       for (int a = 0; a < W2_RA; ++a)
 #pragma unroll
         for (int b = 0; b < NBV; ++b) mma32(acc[a][b], fa[cur][a], fb[cur][b]);
-#endif
       {   // every wave adds its A fragments up, only the owners of the bias columns store the sums: no branch in the k-loop
 #pragma unroll
         for (int a = 0; a < W2_RA; ++a)
@@ -351,10 +337,6 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   WG_PH(14)
   int buf = 0;
   for (int64_t m = mb; m < me; m += W2_BK) {
-    m_dbg = m;
-#ifdef W2_SKIP_BARRIER
-    if (m == mb)
-#endif
     __syncthreads();
     WG_PH(3)
     compute(buf, m + 2 * W2_BK);

@@ -55,6 +55,10 @@ typedef enum {
 
 int bn_abi_version(void);
 const char *bn_last_error(void);
+/* Diagnostic / A-B preprocessor switches this build of the library was compiled with, space-separated ("" for the release
+ * build).  Timing builds under profiles/ change instruction streams or drop work; the test-suite asserts that the library
+ * it validates reports none. */
+const char *bn_build_flags(void);
 /* Run-to-run reproducible parameter gradients (the reference trains with Lightning's deterministic=True, main.py:726).
  * The weight-gradient kernels of bn_field_backward split the points over workgroups that add fp32 partial sums with
  * atomics; on = 1 makes the workgroups of one output tile add in a fixed order (a turn counter per tile): bitwise
