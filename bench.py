@@ -132,7 +132,14 @@ def cpu_baseline(args, rays=1024, seconds_budget=30.0):
         if time.perf_counter() - t0 > seconds_budget * 0.6 or n >= 6:
             break
     dt = time.perf_counter() - t0
-    return dict(value=rays * n / dt, unit="rays/s", cores=cores, kind="port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.lower().startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return dict(value=rays * n / dt, unit="rays/s", cores=cores, kind="port", cpu_model=cpu_model, threads=cores,
+                host_logical_cpus=os.cpu_count(),
                 sample=f"{n} training steps of {rays} rays x {args.n_samples}+{args.guided_samples} samples (same network, fp32, "
                        f"torch CPU oracle, {cores} threads) after 1 warm-up step",
                 cross_timing="profiles/r02_cpu_cross_timing.txt (oracle vs the imported reference, build container)")
@@ -181,7 +188,8 @@ def parse_args():
                          "--rays 1024: config 4's per-GPU shape); hapke / microfacet = the two halves of config 5 (use --dtype fp16); "
                          "rpv_nlr = RPV with learned normals")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--settle-seconds", type=float, default=1.5, help="minimum time under load before the timed region")
+    ap.add_argument("--settle-seconds", type=float, default=1.5, help="minimum time of STEADY-STATE steps before the timed region")
+    ap.add_argument("--sustained-steps", type=int, default=200, help="steps of the `sustained` run after the timed region (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -189,7 +197,7 @@ def parse_args():
 def spawn_ranks(a):
     """`python bench.py --gpus N` outside torchrun: start the N ranks as fresh child processes (this parent never touches
     the GPU, and nothing is re-exec'ed), rank 0 inherits stdout for the JSON line."""
-    have = torch.cuda.device_count()           # does not initialise the GPU
+    have = torch.cuda.device_count()           # (may bring the HIP runtime up in this parent; the ranks are fresh child processes)
     share = os.environ.get("BN_BENCH_SHARE_GPU") == "1"
     if have < a.gpus and not share:
         sys.exit(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible")
@@ -264,7 +272,9 @@ def main():
     args = make_args(rays_gpu, a.samples, a.guided, a.dtype, **over)
     torch.manual_seed(0)
     model = load_model(args).to(dev)
-    trainer = FusedTrainer(model, args, lr=args.lr, ds_lambda=args.ds_lambda)
+    # own draws (strict_rng=False), as brdf_nerf_amd.train.TrainLoop runs it: the launch-lean step with in-kernel draws, replayed
+    # from a HIP graph once its inputs have kept their addresses for a few steps
+    trainer = FusedTrainer(model, args, lr=args.lr, ds_lambda=args.ds_lambda, strict_rng=False)
     if a.scaling == "weak":
         batches = [synthetic_batch(rays_gpu, 1000 * rank + i + 1, dev) for i in range(4)]
     else:       # strong: the SAME global batches on every world size, each rank takes its contiguous share
@@ -289,32 +299,73 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # ---- warm-up, then settle: keep the chip under this load until it has seen >= settle_seconds of it
-    barrier()
-    t_load = time.perf_counter()
-    for i in range(a.warmup):
-        run(i)
-    barrier()
-    est = agree_max((time.perf_counter() - t_load) / max(1, a.warmup)) if a.warmup else 0.02
-    under = time.perf_counter() - t_load
-    settle = int(agree_max(math.ceil(max(0.0, a.settle_seconds - under) / max(est, 1e-4)))) if a.settle_seconds > 0 else 0
-    settle = min(settle, 2000)
-    for i in range(settle):
-        run(a.warmup + i)
-    # ---- the timed region: exactly K steps, nothing else
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        loss, _ = run(i)
-    barrier()
-    dt = agree_max(time.perf_counter() - t0)
+    def timed(fn, n):
+        """n steps between barrier + synchronize pairs, nothing else inside; max over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        out = None
+        for i in range(n):
+            out = fn(i)
+        barrier()
+        return agree_max(time.perf_counter() - t0), out
+
+    def settle_then_time(fn, warmup, steps):
+        """W warm-up steps (lazy initialisation, allocator, graph capture), then the per-step time from two STEADY-STATE steps,
+        then settling steps until the chip has run >= settle_seconds of steady-state steps (its clock settles over seconds),
+        then exactly `steps` timed steps."""
+        barrier()
+        for i in range(warmup):
+            fn(i)
+        est, _ = timed(fn, 2)
+        est /= 2
+        n_settle = min(int(math.ceil(a.settle_seconds / max(est, 1e-5))), 20000) if a.settle_seconds > 0 else 0
+        for i in range(n_settle):
+            fn(i)
+        dt_, out = timed(fn, steps)
+        return dt_, out, n_settle
+
+    dt, (loss, _), settle = settle_then_time(run, a.warmup, a.steps)
+    # ---- sustained: a longer run after the timed region, outside `value` (does the step hold its time?)
+    sustained = None
+    if a.sustained_steps > 0:
+        ds, _ = timed(run, a.sustained_steps)
+        sustained = {"steps": a.sustained_steps, "ms_per_step": ds / a.sustained_steps * 1e3,
+                     "value": world * rays_gpu * a.sustained_steps / ds, "unit": "rays/s"}
+    # ---- N > 1, weak scaling asked: the strong-scaling answer in the same invocation - ONE 4096-ray batch split N ways, and
+    # the same batch on ONE rank's shape (every rank runs it alone, no collective) for the speed-up, both timed in this run
+    strong = None
+    if world > 1 and a.scaling == "weak" and a.rays % world == 0:
+        from brdf_nerf_amd.distributed import shard_bounds
+        lo, hi = shard_bounds(a.rays, rank, world)
+        args_s = make_args(hi - lo, a.samples, a.guided, a.dtype, **over)
+        torch.manual_seed(0)
+        tr_s = FusedTrainer(load_model(args_s).to(dev), args_s, lr=args_s.lr, ds_lambda=args_s.ds_lambda, strict_rng=False)
+        tr_s.ray_offset = lo
+        bs = [{k: v[lo:hi].contiguous() for k, v in synthetic_batch(a.rays, i + 1, dev).items()} for i in range(4)]
+        run_s = lambda i: tr_s.step(bs[i % 4]["rays"], bs[i % 4]["rgbs"], valid_depth=bs[i % 4]["valid_depth"], depths=bs[i % 4]["depths"],
+                                    depth_std=bs[i % 4]["depth_std"], near_far=(0.0, 2.0), **flags)
+        dt_s, _, _ = settle_then_time(run_s, a.warmup, a.steps)
+        torch.manual_seed(0)
+        tr_1 = FusedTrainer(load_model(args).to(dev), args, lr=args.lr, ds_lambda=args.ds_lambda, strict_rng=False, data_parallel=False)
+        b1 = [synthetic_batch(a.rays, i + 1, dev) for i in range(4)]
+        run_1 = lambda i: tr_1.step(b1[i % 4]["rays"], b1[i % 4]["rgbs"], valid_depth=b1[i % 4]["valid_depth"], depths=b1[i % 4]["depths"],
+                                    depth_std=b1[i % 4]["depth_std"], near_far=(0.0, 2.0), **flags)
+        dt_1, _, _ = settle_then_time(run_1, a.warmup, a.steps)
+        strong = {"rays_per_global_step": a.rays, "rays_per_gpu": hi - lo, "ms_per_step": dt_s / a.steps * 1e3,
+                  "value": a.rays * a.steps / dt_s, "unit": "rays/s",
+                  "n1_shape_ms_per_step": dt_1 / a.steps * 1e3, "speedup_vs_n1_ms": dt_1 / dt_s,
+                  "note": "one 4096-ray batch split over the ranks (gradient all-reduce in two overlapped buckets) against the same "
+                          "batch on one rank's shape, every rank running it alone, both timed in this invocation"}
+        del tr_s, tr_1
     # ---- separate pass: per-kernel durations from HIP events around every launch (on the launch stream)
     prof_steps = max(10, min(a.steps, 20))
+    trainer.use_graph = False            # a graph replay does not pass through the library's launch sites: this pass runs eagerly
     _lib.prof_enable(True)
     for i in range(prof_steps):
         run(i)
     torch.cuda.synchronize()
     _lib.prof_enable(False)
+    trainer.use_graph = True
     prof = _lib.prof_collect()
     dropped = trainer.dropped_grad_elems()
     if rank != 0:
@@ -402,6 +453,8 @@ def main():
         "step_tflops_executed": flops_step[True] / step_s / 1e12, "step_frac_of_peak_executed": flops_step[True] / step_s / 1e12 / peak,
         "step_tflops_reference_accounting": flops_ref / step_s / 1e12,
         "kernels": kernels, "final_loss": float(loss), "dropped_nonfinite_grad_elems": list(dropped),
+        "sustained": sustained, "strong": strong,
+        "launches_per_step": sum(k["launches_per_step"] for k in kernels.values()),
     }
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)

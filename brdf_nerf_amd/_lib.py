@@ -50,6 +50,19 @@ class Points(C.Structure):
                 ("n_points", C.c_int64), ("dirs", fptr), ("t_embed", fptr)]
 
 
+class FoldDesc(C.Structure):          # bn_fold_desc
+    _fields_ = [("n_heads", C.c_int32), ("F", C.c_int32), ("rows", C.c_int32), ("wf", fptr), ("bf", fptr),
+                ("w1", fptr * BN_MAX_HEADS), ("w1_ld", C.c_int64 * BN_MAX_HEADS), ("b1", fptr * BN_MAX_HEADS),
+                ("w_fold", fptr * BN_MAX_HEADS), ("b_fold", fptr * BN_MAX_HEADS), ("m", fptr * BN_MAX_HEADS), ("s", fptr * BN_MAX_HEADS),
+                ("d_w1", fptr * BN_MAX_HEADS), ("d_w1_ld", C.c_int64 * BN_MAX_HEADS), ("d_b1", fptr * BN_MAX_HEADS),
+                ("d_wf", fptr), ("d_bf", fptr)]
+
+
+BN_STATE_BYTES, BN_STATE_LOSS_OFF, BN_STATE_LOSS_SLOTS, BN_STATE_POW_OFF, BN_STATE_PART_OFF = 1024, 64, 64, 320, 512
+BN_RNG_COARSE, BN_RNG_GUIDED, BN_RNG_GUIDED_TARGET = 1, 2, 3
+BN_BWD_CHAIN, BN_BWD_WGRAD_TRUNK, BN_BWD_WGRAD_HEADS, BN_BWD_SKINNY, BN_BWD_ALL = 1, 2, 4, 8, 15
+
+
 class LibraryMissing(RuntimeError):
     pass
 
@@ -69,6 +82,8 @@ _SIGS = {
                                    fptr]),
     "bn_field_backward": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), fptr, C.POINTER(Points), fptr, fptr,
                                     fptr, C.POINTER(FieldGrads), fptr]),
+    "bn_field_backward_parts": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), fptr, C.POINTER(Points), fptr, fptr,
+                                          fptr, C.POINTER(FieldGrads), C.c_int32, fptr]),
     "bn_field_normals": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), fptr, C.POINTER(Points), fptr, fptr, fptr,
                                    C.c_int32, fptr]),
     "bn_composite_forward": (C.c_int, [fptr, fptr, C.c_int64, fptr, C.c_float, fptr, C.c_int64, C.c_int32, C.c_int64,
@@ -91,6 +106,22 @@ _SIGS = {
     "bn_adam_step": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_int32, C.c_float, fptr]),
     "bn_count_nonfinite": (C.c_int, [fptr, C.c_int64, fptr, fptr]),
+    "bn_stratified_z_rng": (C.c_int, [fptr, fptr, C.c_int64, fptr, C.c_uint32, C.c_int64, C.c_int64, C.c_int32, fptr, fptr]),
+    "bn_rng_uniform": (C.c_int, [fptr, C.c_uint32, C.c_int64, fptr, fptr]),
+    "bn_composite_guided": (C.c_int, [fptr, fptr, C.c_int64, C.c_int64, C.c_int32, C.c_int32, fptr, C.c_float, fptr, C.c_int64,
+                                      fptr, C.c_int64, fptr, C.c_int64, fptr, fptr, fptr, C.c_uint32, C.c_uint32, C.c_int64, fptr, fptr,
+                                      fptr, fptr, fptr, fptr]),
+    "bn_merged_composite_forward": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, fptr,
+                                              fptr, fptr, fptr, fptr]),
+    "bn_merged_composite_backward": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, fptr,
+                                               fptr, fptr, fptr, fptr, fptr]),
+    "bn_lambert_tail": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, C.c_int64, fptr,
+                                  C.c_int64, fptr, C.c_int64, fptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, fptr, fptr,
+                                  C.c_int32, fptr, fptr, fptr, fptr, fptr, fptr]),
+    "bn_fold_heads": (C.c_int, [fptr, fptr]),
+    "bn_unfold_heads": (C.c_int, [fptr, fptr]),
+    "bn_adam_multi": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, fptr, fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_float, C.c_int32, fptr, fptr]),
     "bn_device_faults": (C.c_int, [C.POINTER(C.c_uint), fptr]),
     "bn_prof_enable": (C.c_int, [C.c_int]),
     "bn_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
@@ -117,16 +148,20 @@ def exported_symbols():
     return sorted(_SIGS)
 
 
-def load(path):
-    """dlopen one build of the library and bind every declared entry point (no fallback: raises if absent)."""
+def load(path, baseline=False):
+    """dlopen one build of the library and bind every declared entry point (no fallback: raises if absent).
+    baseline=True (measurement harnesses only, profiles/ab_kernels.py): a library built from an EARLIER commit - entry points
+    it lacks stay unbound and the ABI number is not checked; the caller keeps to the calls that library has."""
     if not os.path.exists(path):
         raise LibraryMissing(f"{path} not found: build the HIP extension first "
                              f"(python -m brdf_nerf_amd.build). There is no CPU fallback.")
     L = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
+        if baseline and not hasattr(L, name):
+            continue
         fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if L.bn_abi_version() != 3:
+    if not baseline and L.bn_abi_version() != 4:
         raise LibraryMissing(f"{path}: ABI version mismatch; rebuild")
     return L
 
@@ -145,6 +180,15 @@ def set_deterministic(on=True):
     main.py:726): the split weight-gradient sums are added in a fixed order.  Also switched on by BRDFNERF_DETERMINISTIC=1.
     Returns the previous setting."""
     return bool(lib().bn_set_deterministic(1 if on else 0))
+
+
+def deterministic():
+    """Current setting of the deterministic mode (read back through the library)."""
+    L = lib()
+    prev = L.bn_set_deterministic(0)
+    if prev:
+        L.bn_set_deterministic(1)
+    return bool(prev)
 
 
 def use(handle):

@@ -56,6 +56,15 @@ extern "C" const char *bn_build_flags(void) {
 #ifdef BN_ABLATION_BUILD
          "BN_ABLATION_BUILD "
 #endif
+#ifdef BN_FWD_DEPTH_TRAIN
+         "BN_FWD_DEPTH_TRAIN "
+#endif
+#ifdef BN_BWD_DEPTH
+         "BN_BWD_DEPTH "
+#endif
+#ifdef BN_PRIO_YOUNG
+         "BN_PRIO_YOUNG "
+#endif
       ;
 }
 

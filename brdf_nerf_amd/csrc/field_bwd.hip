@@ -387,10 +387,18 @@ template <typename T, int MT, int NT, int WAVES> static int launch_bwd(const Bwd
 extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
                                  const bn_points *pts, const float *out, const float *d_out, void *stash,
                                  const bn_field_grads *G, void *stream) {
+  return bn_field_backward_parts(desc, params, packed, pts, out, d_out, stash, G, BN_BWD_ALL, stream);
+}
+
+extern "C" int bn_field_backward_parts(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
+                                       const bn_points *pts, const float *out, const float *d_out, void *stash,
+                                       const bn_field_grads *G, int32_t parts, void *stream) {
   BwdArgs a;
   if (int e = bn_make_geom(desc, &a.g)) return e;
   a.an = desc->normal_an ? 1 : 0;
   BN_REQUIRE(pts && pts->n_points > 0 && packed && out && d_out && stash && G, "field_backward: null argument");
+  BN_REQUIRE(parts > 0 && (parts & ~BN_BWD_ALL) == 0, "field_backward: parts=%d", parts);
+  BN_REQUIRE(parts == BN_BWD_ALL || !bn_deterministic(), "field_backward: the deterministic mode runs the whole backward in one call");
   const FieldGeom &g = a.g;
   a.d = *desc; a.p = *params; a.packed = packed; a.M = pts->n_points; a.out = out; a.d_out = d_out; a.stash = (char *)stash;
   bn_make_packed_layout(g, &a.pl);
@@ -406,6 +414,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   float *amax = f16m ? (float *)((char *)stash + a.sl.gscale) : nullptr;
   a.amax = amax;
   const unsigned amax_grid = (unsigned)(ceil_div64(pts->n_points, 256) < 1024 ? ceil_div64(pts->n_points, 256) : 1024);
+  if (parts & BN_BWD_CHAIN) {
   if (f16m) {
     if (hipMemsetAsync(amax, 0, 16, st) != hipSuccess) { bn_set_error("field_backward: memset failed"); return BN_ELAUNCH; }
     if (a.an) {
@@ -423,6 +432,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   }
   rc = [&]() -> int { BN_DISPATCH_TILE(desc->dtype, g, launch_bwd, (a, tiles, st)); }();
   if (rc) return rc;
+  }
 
   // ---- weight gradients
   const StashLayout &sl = a.sl;
@@ -432,8 +442,9 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   w.n_jobs = 0; w.Mpad = sl.Mpad; w.tile0[0] = 0; w.amax = amax;
   int scale_sel = 1;   // gradient operand of the jobs added next: 1 = primal chain (dZ_l, dG), 2 = adjoint chain (gbar_PE, abar_l)
   int b_native = 0;    // B operand of the jobs added next: a native-order layer-output stash (16-bit modes) or a row-major array
+  int part = BN_BWD_WGRAD_TRUNK;   // which part of the backward the jobs added next belong to (bn_field_backward_parts)
   auto add = [&](const void *A_, int lda, int a0, const void *B_, int ldb, int b0, float *C, int ldc, float *bias, int N, int K) {
-    if (!C) return;
+    if (!C || !(parts & part)) return;
     WgradJob &j = w.job[w.n_jobs];
     j.scale_sel = scale_sel;
     j.b_native = b_native; j.b_bm = BM; j.b_F = F; j.b_bm_shift = BM == 128 ? 7 : 6;
@@ -456,7 +467,9 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     }
   }
   b_native = naty;
+  part = BN_BWD_WGRAD_HEADS;
   if (!g.fold) add(S + sl.dfeats, F, 0, S + sl.Y[g.L - 1], F, 0, G->feats_w, F, G->feats_b, F, F);
+  part = BN_BWD_WGRAD_TRUNK;
   b_native = 0;
   if (a.an) {  // dW_l += delta_l^T [gbar_PE ; abar_l]  (delta_l is a forward quantity: the scale rides on gbar_PE / abar_l)
     scale_sel = 2;
@@ -470,6 +483,7 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
     }
   }
   scale_sel = 1;
+  part = BN_BWD_WGRAD_HEADS;
   for (int hd = 0; hd < g.n_heads; ++hd) {
     const int p = hd / 2, hl = hd % 2;
     // folded: the head's first layer reads Y_{L-1}; the gradient is that of the folded matrix (bn_field_desc.fold_feats)
@@ -492,7 +506,8 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
   if (det) BN_HIP_CHECK(hipMemsetAsync(tickets, 0, BN_DET_TICKETS * sizeof(unsigned int), st), "field_backward: ticket memset");
   auto launch_wgrad = [&](WgradArgs &wv, unsigned int *tk) -> int { return bn_launch_wgrad(wv, tk, bf, f16m, sl.Mpad, st); };
   if (!det) {
-    if (int e = launch_wgrad(w, nullptr)) return e;
+    if (w.n_jobs > 0)
+      if (int e = launch_wgrad(w, nullptr)) return e;
   } else {
     // jobs that add into the same matrix (same C: the primal and the analytic-normal term of a trunk layer) take separate,
     // stream-ordered launches, each job list in its original order
@@ -509,11 +524,16 @@ extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_param
         gen.job[gen.n_jobs++] = w.job[j];
         left[j] = false; --n_left;
       }
+      // capacity BEFORE the launch indexes the turn counters (an upper bound: the launcher's tiles are 128 x 128 or larger)
+      unsigned int need = 0;
+      for (int q = 0; q < gen.n_jobs; ++q) need += (unsigned int)(((gen.job[q].N + 127) / 128) * ((gen.job[q].K + 127) / 128));
+      BN_REQUIRE(tk_used + need <= BN_DET_TICKETS / 2, "field_backward: too many output tiles for the deterministic mode");
       if (int e = launch_wgrad(gen, tickets + tk_used)) return e;
       tk_used += (unsigned int)gen.tile0[gen.n_jobs];
       BN_REQUIRE(tk_used <= BN_DET_TICKETS / 2, "field_backward: too many output tiles for the deterministic mode");
     }
   }
+  if (!(parts & BN_BWD_SKINNY)) return 0;
   SkinnyArgs s;
   s.n_jobs = 0; s.Mpad = sl.Mpad; s.amax = amax;
   for (int i = 0; i < BN_MAX_SKINNY_JOBS; ++i) { s.job[i].scale_sel = 0; s.job[i].unit_dpre = 0; }   // X = forward activations unless noted

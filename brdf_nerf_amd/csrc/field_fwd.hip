@@ -326,6 +326,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
 #endif
   int *WR = (int *)RED, *RD = WR + 2;   // RD[2 * h + g]
   const int grp = wave >> 2;
+#ifdef BN_PRIO_YOUNG      // A/B switch: static priority for the later-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
   for (int l = 0; l < g.L; ++l) {
     zero_acc<MT, NT>(acc);
     if (keep && !NATY && !ride && l > 0) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.Y[l - 1]) + (size_t)m0 * F, F, BM, F);
@@ -774,7 +777,10 @@ template <typename T, int MT, int NT, int WAVES, bool KEEP, bool DIR> static int
     BN_LAUNCH_CHECK("field_fwd");
   }
   // mirror the device fault word to the host now and then: asynchronous, no synchronisation on the hot path
-  if ((g_fwd_launches++ & 63u) == 0u) {
+  // (never inside a stream capture: a graph would replay the copy with every launch)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+  if (cap == hipStreamCaptureStatusNone && (g_fwd_launches++ & 63u) == 0u) {
     if (!g_fwd_fault_host && hipHostMalloc((void **)&g_fwd_fault_host, sizeof(unsigned int), hipHostMallocDefault) == hipSuccess)
       *g_fwd_fault_host = 0u;
     if (g_fwd_fault_host) (void)hipMemcpyFromSymbolAsync(g_fwd_fault_host, HIP_SYMBOL(g_fwd_fault), sizeof(unsigned int), 0, hipMemcpyDeviceToHost, st);

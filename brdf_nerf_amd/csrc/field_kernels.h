@@ -168,10 +168,16 @@ __device__ __forceinline__ void pp_signal(int *flag, int lane) {
 
 // Weight-fragment prefetch depth of the chain GEMM (k-steps in flight per wave), chosen per kernel instantiation
 // (profiles/r02_ablation.txt session 42: the training forward gains 1-1.7 % with 6, the backward / adjoint chains 1-3 % with 2).
+#ifndef BN_FWD_DEPTH_TRAIN      // A/B switches (results unchanged; reported by bn_build_flags)
+#define BN_FWD_DEPTH_TRAIN 6
+#endif
+#ifndef BN_BWD_DEPTH
+#define BN_BWD_DEPTH 2
+#endif
 template <typename T, bool TRAIN_FWD> struct FwdDepth { static constexpr int value = 4; };
-template <> struct FwdDepth<bf16, true> { static constexpr int value = 6; };
-template <> struct FwdDepth<f16, true> { static constexpr int value = 6; };
-template <typename T> struct BwdDepth { static constexpr int value = Elem<T>::kFastMath ? 2 : 4; };
+template <> struct FwdDepth<bf16, true> { static constexpr int value = BN_FWD_DEPTH_TRAIN; };
+template <> struct FwdDepth<f16, true> { static constexpr int value = BN_FWD_DEPTH_TRAIN; };
+template <typename T> struct BwdDepth { static constexpr int value = Elem<T>::kFastMath ? BN_BWD_DEPTH : 4; };
 
 template <typename T, int MT, int NTW, int DEPTH, typename Side>
 __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, int ks0, int nks, const T *bsrc,

@@ -21,9 +21,40 @@ __device__ __forceinline__ float linspace_at(float start, float end, int steps, 
   return i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - i - 1);
 }
 
+// ------------------------------------------------------------------------------------------ in-kernel random draws
+// Philox4x32-10 (Salmon et al., SC'11) keyed by a seed, counter = (element index, draw stream id, step counter).  The fused
+// training step (strict_rng = False) draws its uniforms in the kernels that consume them instead of launching one ATen
+// fill per draw; seed and step counter live in device memory (rng[0], rng[1]) so that a captured HIP graph replays with
+// fresh numbers - the step's last kernel (bn_adam_multi) advances the counter.  The reference-replaying paths (render_rays,
+// strict_rng = True) keep taking torch's draws as arrays.
+__device__ __forceinline__ void philox_round(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
+  const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+  const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (unsigned int)p1; c[3] = (unsigned int)p0; c[0] = n0; c[2] = n2;
+}
+__device__ __forceinline__ void philox4(unsigned long long seed, unsigned long long step, unsigned int stream, unsigned long long index,
+                                        unsigned int (&out)[4]) {
+  unsigned int c[4] = {(unsigned int)index, (unsigned int)(index >> 32), stream, (unsigned int)step};
+  unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32) ^ (unsigned int)(step >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+// uniform in [0, 1) with 24 random bits, like torch.rand for float32
+__device__ __forceinline__ float philox_uniform(const unsigned long long *rng, unsigned int stream, unsigned long long index) {
+  unsigned int o[4];
+  philox4(rng[0], rng[1], stream, index >> 2, o);
+  return (float)(o[index & 3] >> 8) * 5.9604644775390625e-08f;
+}
+
 // ------------------------------------------------------------------------------------------ stratified z
-__global__ void stratified_z_kernel(const float *near, const float *far, int64_t nf_stride, const float *u, int64_t R,
-                                    int S, float *z) {
+__global__ void stratified_z_kernel(const float *near, const float *far, int64_t nf_stride, const float *u,
+                                    const unsigned long long *rng, unsigned int rng_stream, int64_t draw_offset, int64_t R, int S,
+                                    float *z) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= R * S) return;
   const int64_t ray = i / S;
@@ -36,7 +67,7 @@ __global__ void stratified_z_kernel(const float *near, const float *far, int64_t
   const float zi = zc(s);
   const float lower = s == 0 ? zi : 0.5f * (zc(s - 1) + zi);
   const float upper = s == S - 1 ? zi : 0.5f * (zi + zc(s + 1));
-  z[i] = lower + (upper - lower) * u[i];
+  z[i] = lower + (upper - lower) * (u ? u[i] : philox_uniform(rng, rng_stream, (unsigned long long)(i + draw_offset)));
 }
 
 extern "C" int bn_stratified_z(const float *near, const float *far, int64_t nf_stride, const float *u, int64_t R,
@@ -44,8 +75,30 @@ extern "C" int bn_stratified_z(const float *near, const float *far, int64_t nf_s
   BN_REQUIRE(near && far && u && z && R > 0 && S >= 2, "stratified_z: bad arguments");
   const int64_t n = R * S;
   BnProfScope prof_(BN_K_STRATIFIED, (hipStream_t)stream);
-  stratified_z_kernel<<<dim3((unsigned)ceil_div64(n, 256)), 256, 0, (hipStream_t)stream>>>(near, far, nf_stride, u, R, S, z);
+  stratified_z_kernel<<<dim3((unsigned)ceil_div64(n, 256)), 256, 0, (hipStream_t)stream>>>(near, far, nf_stride, u, nullptr, 0u, 0, R, S, z);
   BN_LAUNCH_CHECK("stratified_z");
+  return 0;
+}
+
+extern "C" int bn_stratified_z_rng(const float *near, const float *far, int64_t nf_stride, const unsigned long long *rng,
+                                   uint32_t rng_stream, int64_t ray_offset, int64_t R, int32_t S, float *z, void *stream) {
+  BN_REQUIRE(near && far && rng && z && R > 0 && S >= 2, "stratified_z_rng: bad arguments");
+  const int64_t n = R * S;
+  BnProfScope prof_(BN_K_STRATIFIED, (hipStream_t)stream);
+  stratified_z_kernel<<<dim3((unsigned)ceil_div64(n, 256)), 256, 0, (hipStream_t)stream>>>(near, far, nf_stride, nullptr, rng, rng_stream, ray_offset * S, R, S, z);
+  BN_LAUNCH_CHECK("stratified_z_rng");
+  return 0;
+}
+
+// fill u[n] with the uniforms stream `rng_stream` would hand to element 0 .. n-1 (tests: the in-kernel draws as an array)
+__global__ void rng_uniform_kernel(const unsigned long long *rng, unsigned int rng_stream, int64_t n, float *u) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) u[i] = philox_uniform(rng, rng_stream, (unsigned long long)i);
+}
+extern "C" int bn_rng_uniform(const unsigned long long *rng, uint32_t rng_stream, int64_t n, float *u, void *stream) {
+  BN_REQUIRE(rng && u && n > 0, "rng_uniform: bad arguments");
+  rng_uniform_kernel<<<dim3((unsigned)ceil_div64(n, 256)), 256, 0, (hipStream_t)stream>>>(rng, rng_stream, n, u);
+  BN_LAUNCH_CHECK("rng_uniform");
   return 0;
 }
 
@@ -451,6 +504,12 @@ struct GuidedArgs {
   float *z2_sorted, *z_all;
   int64_t *sort_idx;
   const float *near_far;   // device [2] (near0, far0), e.g. &rays[0][6]; overrides the two scalars when set (no host read)
+  // fused-step extensions (bn_composite_guided): element strides of the per-ray prior arrays (depths[:, 0] of an [R][2] table)
+  // and in-kernel draws (u == nullptr: Philox streams rng_u / rng_ut of rng)
+  int64_t td_stride, ts_stride, ut_stride;
+  const unsigned long long *rng;
+  unsigned int rng_u, rng_ut;
+  int64_t ray_offset;      // in-kernel draws are indexed by ray_offset + ray: a sharded batch draws what the whole batch would
 };
 
 // in-LDS bitonic sort of n2 (power of two) (key, index) pairs by one wave; ties broken by index (= stable).
@@ -472,35 +531,30 @@ __device__ __forceinline__ void wave_bitonic(float *key, int *idx, int n2, int l
     }
 }
 
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void guided_kernel(const GuidedArgs A) {
-  __shared__ float s_edges[WAVES_PER_BLOCK][BN_MAX_G];
-  __shared__ float s_cdf[WAVES_PER_BLOCK][BN_MAX_G];
-  __shared__ float s_key[WAVES_PER_BLOCK][BN_MAX_SG];
-  __shared__ int s_idx[WAVES_PER_BLOCK][BN_MAX_SG];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv;
-  if (ray >= A.R) return;
+// One ray, one wave.  `wrow` = the ray's S pass-1 weights (global memory or the wave's LDS slice), `centre0` its pass-1 depth.
+__device__ __forceinline__ void guided_ray(const GuidedArgs &A, int64_t ray, int lane, const float *z, const float *wrow,
+                                           float centre0, float *edges, float *cdf, float *key, int *idx) {
   const int S = A.S, G = A.G;
-  float *edges = s_edges[wv], *cdf = s_cdf[wv], *key = s_key[wv];
-  int *idx = s_idx[wv];
-  const float *z = A.z + ray * S;
-
   // 1. centre and spread (train_utils.py:35-39), or the ground-truth depth prior (rendering.py:135-145)
   float centre, std;
-  const float *u;
-  if (A.use_target && A.use_target[ray] > 0.f) {
-    centre = A.target_depth[ray];
-    std = A.target_std[ray];
-    u = A.u_target + (A.target_row ? (int64_t)A.target_row[ray] : ray) * G;   // no row table: u_target has one row per ray
+  const float *u = nullptr;
+  unsigned int rstream = A.rng_u;
+  int64_t urow = ray;
+  if (A.use_target && A.use_target[ray * A.ut_stride] > 0.f) {
+    centre = A.target_depth[ray * A.td_stride];
+    std = A.target_std[ray * A.ts_stride];
+    urow = A.target_row ? (int64_t)A.target_row[ray] : ray;      // no row table: u_target has one row per ray
+    if (A.u_target) u = A.u_target + urow * G;
+    rstream = A.rng_ut;
   } else {
-    centre = A.depth[ray];
+    centre = centre0;
     float acc = 0.f;
     for (int s = lane; s < S; s += 64) {
       const float dz = z[s] - centre;
-      acc += dz * dz * A.weights[ray * S + s];
+      acc += dz * dz * wrow[s];
     }
     std = sqrtf(wave_sum(acc));
-    u = A.u + ray * G;
+    if (A.u) u = A.u + ray * G;
   }
   // 2. symmetric 3-sigma window inside [near0, far0] (rendering.py:76-83)
   float lo = centre - A.d_range * std, hi = centre + A.d_range * std;
@@ -547,7 +601,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void guided_kernel(const Guid
   for (int j = lane; j < n2g; j += 64) {
     float smp = INFINITY;
     if (j < G) {
-      const float uu = u[j];
+      const float uu = u ? u[j] : philox_uniform(A.rng, rstream, (unsigned long long)((urow + A.ray_offset) * G + j));
       int lo_i = 0, hi_i = G;  // first index with cdf[i] > uu
       while (lo_i < hi_i) {
         const int mid = (lo_i + hi_i) >> 1;
@@ -593,6 +647,72 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void guided_kernel(const Guid
   }
 }
 
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void guided_kernel(const GuidedArgs A) {
+  __shared__ float s_edges[WAVES_PER_BLOCK][BN_MAX_G];
+  __shared__ float s_cdf[WAVES_PER_BLOCK][BN_MAX_G];
+  __shared__ float s_key[WAVES_PER_BLOCK][BN_MAX_SG];
+  __shared__ int s_idx[WAVES_PER_BLOCK][BN_MAX_SG];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv;
+  if (ray >= A.R) return;
+  guided_ray(A, ray, lane, A.z + ray * A.S, A.weights + ray * A.S, A.depth[ray], s_edges[wv], s_cdf[wv], s_key[wv], s_idx[wv]);
+}
+
+// Pass-1 compositing (cal_weight, sigma = channel 3 of the pass-1 field output, no noise) + depth-guided resampling + merge in
+// ONE launch, one wave per ray: the pass-1 weights never leave the CU (LDS slice of the wave).  Fused training step only.
+struct CompGuidedArgs {
+  GuidedArgs g;
+  const float *sigma;        // [R][S] with element stride sigma_stride
+  int64_t sigma_stride;
+  float *weights, *depth;    // optional copies of the pass-1 weights / depth (nullable)
+};
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void composite_guided_kernel(const CompGuidedArgs A) {
+  __shared__ float s_edges[WAVES_PER_BLOCK][BN_MAX_G];
+  __shared__ float s_cdf[WAVES_PER_BLOCK][BN_MAX_G];
+  __shared__ float s_key[WAVES_PER_BLOCK][BN_MAX_SG];
+  __shared__ int s_idx[WAVES_PER_BLOCK][BN_MAX_SG];
+  __shared__ float s_w[WAVES_PER_BLOCK][64 * BN_MAX_CPL];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv;
+  if (ray >= A.g.R) return;
+  const int S = A.g.S, cpl = (S + 63) / 64;
+  const float *z = A.g.z + ray * S;
+  float zv[BN_MAX_CPL], al[BN_MAX_CPL], u[BN_MAX_CPL];
+  float lp = 1.f;
+#pragma unroll
+  for (int j = 0; j < BN_MAX_CPL; ++j) {
+    zv[j] = 0.f; al[j] = 0.f; u[j] = 1.f;
+    const int s = lane * cpl + j;
+    if (j < cpl && s < S) {
+      zv[j] = z[s];
+      const float delta = s == S - 1 ? 1e10f : z[s + 1] - zv[j];
+      const float sg = A.sigma[(ray * S + s) * A.sigma_stride];
+      const float rs = sg > 0.f ? sg : 0.f;
+      al[j] = 1.f - expf(-delta * rs);
+      u[j] = 1.f - al[j] + 1e-10f;
+      lp *= u[j];
+    }
+  }
+  float T = wave_excl_prod(lp, lane);
+  float dsum = 0.f;
+  float *wl = s_w[wv];
+#pragma unroll
+  for (int j = 0; j < BN_MAX_CPL; ++j) {
+    const int s = lane * cpl + j;
+    if (j < cpl && s < S) {
+      const float w = al[j] * T;
+      wl[s] = w;
+      if (A.weights) A.weights[ray * S + s] = w;
+      dsum += w * zv[j];
+    }
+    T *= u[j];
+  }
+  dsum = wave_sum(dsum);
+  if (lane == 0 && A.depth) A.depth[ray] = dsum;
+  lds_wave_sync();
+  guided_ray(A.g, ray, lane, z, wl, dsum, s_edges[wv], s_cdf[wv], s_key[wv], s_idx[wv]);
+}
+
 static int guided_samples_impl(const float *z, const float *weights, const float *depth, const float *u, int64_t R,
                                int32_t S, int32_t G, float near0, float far0, const float *near_far, float d_range,
                                const float *use_target, const float *target_depth, const float *target_std,
@@ -602,7 +722,7 @@ static int guided_samples_impl(const float *z, const float *weights, const float
   BN_REQUIRE(G >= 3 && G <= BN_MAX_G && S >= 1 && S + G <= BN_MAX_SG, "guided_samples: S=%d G=%d unsupported", S, G);
   BN_REQUIRE(!use_target || (target_depth && target_std && u_target), "guided_samples: target arrays");
   GuidedArgs a = {z, weights, depth, u, use_target, target_depth, target_std, u_target, target_row, R, S, G,
-                  near0, far0, d_range, z2_sorted, z_all, sort_idx, near_far};
+                  near0, far0, d_range, z2_sorted, z_all, sort_idx, near_far, 1, 1, 1, nullptr, 0u, 0u, 0};
   BnProfScope prof_(BN_K_GUIDED, (hipStream_t)stream);
   guided_kernel<<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
   BN_LAUNCH_CHECK("guided_samples");
@@ -626,4 +746,291 @@ extern "C" int bn_guided_samples_nf(const float *z, const float *weights, const 
   BN_REQUIRE(near_far, "guided_samples_nf: near_far is null");
   return guided_samples_impl(z, weights, depth, u, R, S, G, 0.f, 0.f, near_far, d_range, use_target, target_depth, target_std,
                              u_target, target_row, z2_sorted, z_all, sort_idx, stream);
+}
+
+extern "C" int bn_composite_guided(const float *z, const float *sigma, int64_t sigma_stride, int64_t R, int32_t S, int32_t G,
+                                   const float *near_far, float d_range, const float *use_target, int64_t ut_stride,
+                                   const float *target_depth, int64_t td_stride, const float *target_std, int64_t ts_stride,
+                                   const float *u, const float *u_target, const unsigned long long *rng, uint32_t rng_u,
+                                   uint32_t rng_ut, int64_t ray_offset, float *z2_sorted, float *z_all, int64_t *sort_idx, float *weights,
+                                   float *depth, void *stream) {
+  BN_REQUIRE(z && sigma && near_far && z2_sorted && R > 0, "composite_guided: null argument");
+  BN_REQUIRE(G >= 3 && G <= BN_MAX_G && S >= 1 && S <= 64 * BN_MAX_CPL && S + G <= BN_MAX_SG, "composite_guided: S=%d G=%d unsupported", S, G);
+  BN_REQUIRE(!use_target || (target_depth && target_std && (u_target || rng)), "composite_guided: target arrays");
+  BN_REQUIRE(u || rng, "composite_guided: neither draws nor an rng state");
+  CompGuidedArgs a;
+  a.g = GuidedArgs{z, nullptr, nullptr, u, use_target, target_depth, target_std, u_target, nullptr, R, S, G,
+                   0.f, 0.f, d_range, z2_sorted, z_all, sort_idx, near_far, td_stride, ts_stride, ut_stride, rng, rng_u, rng_ut, ray_offset};
+  a.sigma = sigma; a.sigma_stride = sigma_stride; a.weights = weights; a.depth = depth;
+  BnProfScope prof_(BN_K_GUIDED, (hipStream_t)stream);
+  composite_guided_kernel<<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
+  BN_LAUNCH_CHECK("composite_guided");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ merged-set compositing
+// Pass 2 of the fused training step composites the depth-sorted union of the S1 coarse samples (field output out1, evaluated
+// once in pass 1 and reused) and the G guided samples (out2): sample s of ray r is row idx[r][s] of cat[out1[r], out2[r]]
+// (sort_idx of the merge, rendering.py:271-272).  These kernels read the rows through that index - no cat / gather copy of
+// the field outputs - and the backward writes each sample's gradient row straight to d_out1 / d_out2 (no scatter / split).
+// One wave per ray; lane l owns samples [l cpl, (l+1) cpl).  MODE 0: forward (alphas, transparency, weights, depth, acc).
+// MODE 1: Lambertian tail - forward, shading + SNerfLoss + DepthLoss (bn_lambert_loss) and the backward of all of it in one
+// pass over the ray.  MODE 2: backward from d_weights / d_depth / d_acc.
+struct MergedArgs {
+  const float *z;
+  const int64_t *idx;           // nullptr: identity (a single source block out1 with S1 = S2)
+  const float *out1, *out2;
+  int S1, S2, C;
+  int64_t R;
+  float *alphas, *trans, *weights, *depth, *acc, *wsum;
+  // MODE 1
+  const float *rgbs, *valid, *tdepth, *tweight, *tstd;
+  int64_t v_stride, td_stride, tw_stride, ts_stride;
+  float pad, lambda_rgb, lambda_ds;
+  int usealldepth;
+  float *ray_loss, *rgb, *loss_acc;
+  int loss_slots;                  // the rays' loss terms are added to loss_acc[ray % loss_slots] (spread: same-address atomics serialise)
+  // MODE 2
+  const float *d_weights, *d_depth, *d_acc, *d_wsum;
+  // MODE 1, 2
+  float *d_out1, *d_out2;
+  unsigned long long *nonfinite;   // nullable: zero non-finite gradient elements and count them ([0] NaN, [1] Inf)
+};
+
+// C4 (C == 4 and 16-byte aligned blocks: the Lambertian model): a sample's row is ONE 16-byte load kept in registers for the
+// forward sums and the backward dot products, and one 16-byte store of its gradient row.
+template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void merged_composite_kernel(const MergedArgs A) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv;
+  if (ray >= A.R) return;
+  const int S = A.S2, C = A.C, cpl = (S + 63) / 64, S1 = A.S1, Sg = S - S1;
+  const float *z = A.z + ray * S;
+  float zv[BN_MAX_CPL], al[BN_MAX_CPL], u[BN_MAX_CPL], dad[BN_MAX_CPL];
+  int64_t roff[BN_MAX_CPL];      // element offset of the sample's row; >= 0: in out1, < 0: ~offset in out2
+  f32x4 rv[C4 ? BN_MAX_CPL : 1];
+  float lp = 1.f;
+  auto rowp = [&](int64_t o) { return o >= 0 ? A.out1 + o : A.out2 + ~o; };
+  auto chan = [&](int j, int c) { return C4 ? rv[C4 ? j : 0][c] : rowp(roff[j])[c]; };
+#pragma unroll
+  for (int j = 0; j < BN_MAX_CPL; ++j) {
+    zv[j] = 0.f; al[j] = 0.f; u[j] = 1.f; dad[j] = 0.f; roff[j] = 0;
+    const int s = lane * cpl + j;
+    if (j < cpl && s < S) {
+      const int64_t i = A.idx ? A.idx[ray * S + s] : (int64_t)s;
+      roff[j] = i < S1 ? (ray * S1 + i) * C : ~((ray * Sg + (i - S1)) * C);
+      zv[j] = z[s];
+      const float delta = s == S - 1 ? 1e10f : z[s + 1] - zv[j];
+      if (C4) rv[C4 ? j : 0] = *(const f32x4 *)rowp(roff[j]);
+      const float sg = chan(j, 3);
+      const float rs = sg > 0.f ? sg : 0.f;
+      const float e = expf(-delta * rs);
+      al[j] = 1.f - e;
+      u[j] = 1.f - al[j] + 1e-10f;
+      dad[j] = sg > 0.f ? delta * e : 0.f;
+      lp *= u[j];
+    } else if (C4) {
+      rv[C4 ? j : 0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  float T = wave_excl_prod(lp, lane);
+  float tr[BN_MAX_CPL], w[BN_MAX_CPL];
+#pragma unroll
+  for (int j = 0; j < BN_MAX_CPL; ++j) {
+    tr[j] = T;
+    w[j] = al[j] * T;
+    T *= u[j];
+  }
+  float dd = 0.f, dws = 0.f;         // d loss / d depth, d loss / d (sum_s w_s)
+  float dacc[BN_MAX_CH];             // MODE 1: channels 0..2 only
+  if (MODE != 2) {
+    float dsum = 0.f, ws = 0.f;
+#pragma unroll
+    for (int j = 0; j < BN_MAX_CPL; ++j) {
+      const int s = lane * cpl + j;
+      if (j < cpl && s < S) {
+        const int64_t o = ray * S + s;
+        if (A.alphas) A.alphas[o] = al[j];
+        if (A.trans) A.trans[o] = tr[j];
+        if (A.weights) A.weights[o] = w[j];
+        dsum += w[j] * zv[j];
+        ws += w[j];
+      }
+    }
+    dsum = wave_sum(dsum);
+    ws = wave_sum(ws);
+    if (lane == 0 && A.depth) A.depth[ray] = dsum;
+    if (lane == 0 && A.wsum) A.wsum[ray] = ws;
+    const int nacc = MODE == 1 ? 3 : C;
+    float a3[3] = {0.f, 0.f, 0.f};
+    if (MODE == 1 || A.acc) {
+      for (int c = 0; c < nacc; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < BN_MAX_CPL; ++j) {
+          const int s = lane * cpl + j;
+          if (j < cpl && s < S) a += w[j] * chan(j, c);
+        }
+        a = wave_sum(a);
+        if (lane == 0 && A.acc) A.acc[ray * C + c] = a;
+        if (MODE == 1 && c < 3) a3[c] = a;
+      }
+      if (MODE == 1 && A.acc && lane == 0) A.acc[ray * C + 3] = 0.f;
+    }
+    if (MODE == 0) return;
+    // ---- Lambertian shading + SNerfLoss + DepthLoss and their gradients (lambert_loss_kernel)
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < BN_MAX_CPL; ++j) {
+      const int s = lane * cpl + j;
+      if (j < cpl && s < S) { const float dz = zv[j] - dsum; var += dz * dz * w[j]; }
+    }
+    var = wave_sum(var);
+    const float invn = 1.f / (3.f * (float)A.R);
+    float loss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float x = a3[c] * (1.f + 2.f * A.pad) - A.pad * ws;
+      const float y = fminf(fmaxf(x, 0.f), 1.f);
+      const float e = y - A.rgbs[ray * 3 + c];
+      loss += A.lambda_rgb * e * e * invn;
+      const float dy = (x >= 0.f && x <= 1.f) ? A.lambda_rgb * 2.f * e * invn : 0.f;
+      dacc[c] = dy * (1.f + 2.f * A.pad);
+      dws -= dy * A.pad;
+      if (lane == 0 && A.rgb) A.rgb[ray * 3 + c] = y;
+    }
+    if (A.tdepth && A.valid[ray * A.v_stride] > 0.f) {
+      const float td = A.tdepth[ray * A.td_stride], tw = A.tweight[ray * A.tw_stride], ts = A.tstd[ray * A.ts_stride];
+      const bool apply = A.usealldepth || (fabsf(dsum - td) - ts > 0.f) || (ts < sqrtf(var));
+      if (apply) {
+        const float k = A.lambda_ds / 3.f / (float)A.R;
+        loss += k * tw * (dsum - td) * (dsum - td);
+        dd = k * 2.f * tw * (dsum - td);
+      }
+    }
+    if (lane == 0) {
+      if (A.ray_loss) A.ray_loss[ray] = loss;
+      if (A.loss_acc) atomicAdd(A.loss_acc + (int)(ray % A.loss_slots), loss);
+    }
+  } else {
+    dd = A.d_depth ? A.d_depth[ray] : 0.f;
+    dws = A.d_wsum ? A.d_wsum[ray] : 0.f;
+    for (int c = 0; c < C; ++c) dacc[c] = (A.d_acc && c != 3) ? A.d_acc[ray * C + c] : 0.f;
+  }
+  // ---- backward: g_s = dL/dw_s; dL/dalpha_s = g_s T_s - (1/u_s) sum_{k>s} g_k w_k   
+  const int ng = MODE == 1 ? 3 : C;
+  float g[BN_MAX_CPL], gw = 0.f;
+#pragma unroll
+  for (int j = 0; j < BN_MAX_CPL; ++j) {
+    g[j] = 0.f;
+    const int s = lane * cpl + j;
+    if (j < cpl && s < S) {
+      float gg = dd * zv[j] + dws;
+      if (MODE == 2 && A.d_weights) gg += A.d_weights[ray * S + s];
+      for (int c = 0; c < ng; ++c)
+        if (c != 3) gg += dacc[c] * chan(j, c);
+      g[j] = gg;
+      gw += gg * w[j];
+    }
+  }
+  float suffix = wave_excl_sum_rev(gw, lane);
+  unsigned int n_nan = 0, n_inf = 0;
+#pragma unroll
+  for (int j = BN_MAX_CPL - 1; j >= 0; --j) {
+    const int s = lane * cpl + j;
+    if (j < cpl && s < S) {
+      const float dalpha = g[j] * tr[j] - suffix / u[j];
+      suffix += g[j] * w[j];
+      float *drow = roff[j] >= 0 ? A.d_out1 + roff[j] : A.d_out2 + ~roff[j];
+      if (C4) {
+        f32x4 o = {w[j] * dacc[0], w[j] * dacc[1], w[j] * dacc[2], dalpha * dad[j]};
+        if (A.nonfinite) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (isnan(o[c])) { ++n_nan; o[c] = 0.f; }
+            else if (isinf(o[c])) { ++n_inf; o[c] = 0.f; }
+          }
+        }
+        *(f32x4 *)drow = o;
+      } else {
+        for (int c = 0; c < C; ++c) {
+          float v = c == 3 ? dalpha * dad[j] : (c < ng ? w[j] * dacc[c] : 0.f);
+          if (A.nonfinite) {
+            if (isnan(v)) { ++n_nan; v = 0.f; }
+            else if (isinf(v)) { ++n_inf; v = 0.f; }
+          }
+          drow[c] = v;
+        }
+      }
+    }
+  }
+  if (A.nonfinite) {
+    n_nan = (unsigned int)wave_sum((float)n_nan);      // counts <= 64 * 8 * 32 per wave: exact in fp32
+    n_inf = (unsigned int)wave_sum((float)n_inf);
+    if (lane == 0 && n_nan) atomicAdd(A.nonfinite, (unsigned long long)n_nan);
+    if (lane == 0 && n_inf) atomicAdd(A.nonfinite + 1, (unsigned long long)n_inf);
+  }
+}
+
+static int merged_check(const MergedArgs &a, const char *what) {
+  BN_REQUIRE(a.z && a.out1 && a.R > 0 && a.S2 >= 1 && a.S2 <= 64 * BN_MAX_CPL && a.S1 >= 1 && a.S1 <= a.S2, "%s: bad arguments (S1=%d S2=%d)", what, a.S1, a.S2);
+  BN_REQUIRE(a.C >= 4 && a.C <= BN_MAX_CH, "%s: C=%d unsupported", what, a.C);
+  BN_REQUIRE(a.S1 == a.S2 || (a.idx && a.out2), "%s: a merged set needs sort_idx and the second block", what);
+  return 0;
+}
+#define MERGED_GRID(R) dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream
+static bool merged_c4(const MergedArgs &a) {
+  return a.C == 4 && ((uintptr_t)a.out1 | (uintptr_t)a.out2 | (uintptr_t)a.d_out1 | (uintptr_t)a.d_out2) % 16 == 0;
+}
+
+extern "C" int bn_merged_composite_forward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
+                                           int32_t S2, int32_t C, int64_t R, float *alphas, float *trans, float *weights, float *depth,
+                                           float *acc, float *wsum, void *stream) {
+  MergedArgs a = {};
+  a.z = z; a.idx = sort_idx; a.out1 = out1; a.out2 = out2; a.S1 = S1; a.S2 = S2; a.C = C; a.R = R;
+  a.alphas = alphas; a.trans = trans; a.weights = weights; a.depth = depth; a.acc = acc; a.wsum = wsum;
+  if (int e = merged_check(a, "merged_composite_forward")) return e;
+  BnProfScope prof_(BN_K_COMPOSITE_FWD, (hipStream_t)stream);
+  if (merged_c4(a)) merged_composite_kernel<0, true><<<MERGED_GRID(R)>>>(a);
+  else merged_composite_kernel<0, false><<<MERGED_GRID(R)>>>(a);
+  BN_LAUNCH_CHECK("merged_composite_forward");
+  return 0;
+}
+
+extern "C" int bn_merged_composite_backward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
+                                            int32_t S2, int32_t C, int64_t R, const float *d_weights, const float *d_depth,
+                                            const float *d_acc, const float *d_wsum, float *d_out1, float *d_out2,
+                                            unsigned long long *nonfinite, void *stream) {
+  MergedArgs a = {};
+  a.z = z; a.idx = sort_idx; a.out1 = out1; a.out2 = out2; a.S1 = S1; a.S2 = S2; a.C = C; a.R = R;
+  a.d_weights = d_weights; a.d_depth = d_depth; a.d_acc = d_acc; a.d_wsum = d_wsum; a.d_out1 = d_out1; a.d_out2 = d_out2;
+  a.nonfinite = nonfinite;
+  if (int e = merged_check(a, "merged_composite_backward")) return e;
+  BN_REQUIRE(d_out1 && (S1 == S2 || d_out2), "merged_composite_backward: null gradient buffer");
+  BnProfScope prof_(BN_K_COMPOSITE_BWD, (hipStream_t)stream);
+  if (merged_c4(a)) merged_composite_kernel<2, true><<<MERGED_GRID(R)>>>(a);
+  else merged_composite_kernel<2, false><<<MERGED_GRID(R)>>>(a);
+  BN_LAUNCH_CHECK("merged_composite_backward");
+  return 0;
+}
+
+extern "C" int bn_lambert_tail(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1, int32_t S2,
+                               int32_t C, int64_t R, const float *rgbs, const float *valid_depth, int64_t v_stride,
+                               const float *target_depth, int64_t td_stride, const float *target_weight, int64_t tw_stride,
+                               const float *target_std, int64_t ts_stride, float rgb_padding, float lambda_rgb, float lambda_ds,
+                               int32_t usealldepth, float *ray_loss, float *loss_acc, int32_t loss_slots, float *rgb,
+                               float *weights, float *depth, float *d_out1, float *d_out2, void *stream) {
+  MergedArgs a = {};
+  a.z = z; a.idx = sort_idx; a.out1 = out1; a.out2 = out2; a.S1 = S1; a.S2 = S2; a.C = C; a.R = R;
+  a.rgbs = rgbs; a.valid = valid_depth; a.tdepth = target_depth; a.tweight = target_weight; a.tstd = target_std;
+  a.v_stride = v_stride; a.td_stride = td_stride; a.tw_stride = tw_stride; a.ts_stride = ts_stride;
+  a.pad = rgb_padding; a.lambda_rgb = lambda_rgb; a.lambda_ds = lambda_ds; a.usealldepth = usealldepth;
+  a.ray_loss = ray_loss; a.loss_acc = loss_acc; a.loss_slots = loss_slots > 0 ? loss_slots : 1; a.rgb = rgb; a.weights = weights; a.depth = depth; a.d_out1 = d_out1; a.d_out2 = d_out2;
+  if (int e = merged_check(a, "lambert_tail")) return e;
+  BN_REQUIRE(rgbs && d_out1 && (S1 == S2 || d_out2), "lambert_tail: null argument");
+  BN_REQUIRE(!target_depth || (valid_depth && target_weight && target_std), "lambert_tail: incomplete depth prior");
+  BnProfScope prof_(BN_K_COMPOSITE_BWD, (hipStream_t)stream);
+  if (merged_c4(a)) merged_composite_kernel<1, true><<<MERGED_GRID(R)>>>(a);
+  else merged_composite_kernel<1, false><<<MERGED_GRID(R)>>>(a);
+  BN_LAUNCH_CHECK("lambert_tail");
+  return 0;
 }

@@ -123,39 +123,57 @@ class FieldSpec:
             s.head1_wt, s.head1_wt_ld = w.data_ptr() + 4 * self.feat, w.shape[1]
         return s
 
-    @torch.no_grad()
-    def fold(self, named):
-        """(W1 Wf, W1 bf + b1) per head, refreshed whenever the weights are re-packed."""
-        wf, bf = named["feats_from_xyz.weight"].detach(), named["feats_from_xyz.bias"].detach()
-        for name, _, _ in self.heads:
-            w1, b1 = named[f"{name}.0.weight"].detach()[:, :self.feat], named[f"{name}.0.bias"].detach()
+    def _fold_desc(self, named, named_grads=None, with_accumulators=True):
+        """bn_fold_desc over this spec's heads (functions.fold / unfold_grads)."""
+        d = L.FoldDesc()
+        wf, bf = named["feats_from_xyz.weight"], named["feats_from_xyz.bias"]
+        assert wf.is_contiguous() and wf.dtype == torch.float32
+        d.n_heads, d.F = len(self.heads), self.feat
+        d.wf, d.bf = wf.data_ptr(), bf.data_ptr()
+        keep = [wf, bf]
+        for i, (name, _, _) in enumerate(self.heads):
+            w1, b1 = named[f"{name}.0.weight"], named[f"{name}.0.bias"]
+            assert w1.is_contiguous() and w1.dtype == torch.float32
+            d.rows = w1.shape[0]
+            d.w1[i], d.w1_ld[i], d.b1[i] = w1.data_ptr(), w1.shape[1], b1.data_ptr()
             ent = self.folded.get(name)
             if ent is None or ent[0].device != w1.device:
                 ent = (torch.empty(w1.shape[0], self.feat, dtype=torch.float32, device=w1.device), torch.empty_like(b1))
                 self.folded[name] = ent
-            torch.matmul(w1, wf, out=ent[0])
-            torch.addmv(b1, w1, bf, out=ent[1])
+            d.w_fold[i], d.b_fold[i] = ent[0].data_ptr(), ent[1].data_ptr()
+            acc = self.fold_grads.get(name) if with_accumulators else None
+            d.m[i], d.s[i] = (acc[0].data_ptr(), acc[1].data_ptr()) if acc is not None else (None, None)
+            if named_grads is not None:
+                dw1, db1 = named_grads[f"{name}.0.weight"], named_grads[f"{name}.0.bias"]
+                assert dw1.stride(-1) == 1
+                d.d_w1[i], d.d_w1_ld[i], d.d_b1[i] = dw1.data_ptr(), dw1.stride(0), db1.data_ptr()
+        if named_grads is not None:
+            d.d_wf, d.d_bf = named_grads["feats_from_xyz.weight"].data_ptr(), named_grads["feats_from_xyz.bias"].data_ptr()
+        return d, keep
 
     @torch.no_grad()
-    def unfold_grads(self, named, named_grads):
+    def fold(self, named):
+        """(W1 Wf, W1 bf + b1) per head, refreshed whenever the weights are re-packed (bn_fold_heads: one launch; it also
+        clears the folded-gradient accumulators, which the weight-gradient kernels add to)."""
+        named = {k: v.detach() for k, v in named.items()}
+        d, _keep = self._fold_desc(named)
+        L.check(L.lib().bn_fold_heads(C.byref(d), _stream()), "bn_fold_heads")
+
+    @torch.no_grad()
+    def unfold_grads(self, named, named_grads, zero=True):
         """Chain rule from the folded first layers back to the three factors (accumulating, like the library):
-        dW1 += M Wf^T + s bf^T, db1 += s, dWf += W1^T M, dbf += W1^T s, with M = dL/d(W1 Wf), s = dL/d(W1 bf + b1)."""
-        wf, bf = named["feats_from_xyz.weight"].detach(), named["feats_from_xyz.bias"].detach()
-        dwf, dbf = named_grads["feats_from_xyz.weight"], named_grads["feats_from_xyz.bias"]
-        for name, _, _ in self.heads:
-            ent = self.fold_grads.get(name)
-            if ent is None:
-                continue
-            m, sv = ent
-            w1 = named[f"{name}.0.weight"].detach()[:, :self.feat]
-            dw1, db1 = named_grads[f"{name}.0.weight"][:, :self.feat], named_grads[f"{name}.0.bias"]
-            dw1.addmm_(m, wf.t())
-            dw1.addr_(sv, bf)
-            db1.add_(sv)
-            dwf.addmm_(w1.t(), m)
-            dbf.addmv_(w1.t(), sv)
-            m.zero_()
-            sv.zero_()
+        dW1 += M Wf^T + s bf^T, db1 += s, dWf += W1^T M, dbf += W1^T s, with M = dL/d(W1 Wf), s = dL/d(W1 bf + b1)
+        (bn_unfold_heads: one launch).  zero: clear M, s afterwards (callers that re-fold before the next backward - the fused
+        step - skip it: bn_fold_heads clears them)."""
+        if not self.fold_grads:
+            return
+        named = {k: v.detach() for k, v in named.items()}
+        d, _keep = self._fold_desc(named, named_grads)
+        L.check(L.lib().bn_unfold_heads(C.byref(d), _stream()), "bn_unfold_heads")
+        if zero:
+            for m, sv in self.fold_grads.values():
+                m.zero_()
+                sv.zero_()
 
     def used_param_names(self):
         names = []
@@ -374,15 +392,17 @@ def field_forward_raw(spec, named_params, packed, out, stash, xyz=None, rays=Non
     return out
 
 
-def field_backward_raw(spec, named_params, named_grads, packed, out, d_out, stash, xyz=None, rays=None, z=None, unfold=True):
+def field_backward_raw(spec, named_params, named_grads, packed, out, d_out, stash, xyz=None, rays=None, z=None, unfold=True,
+                       zero_folded=True, parts=L.BN_BWD_ALL):
     """unfold=False leaves the folded first-layer gradients in spec.fold_grads (they keep accumulating): a caller that
-    back-propagates several batches before the optimizer step unfolds once, on the last call."""
+    back-propagates several batches before the optimizer step unfolds once, on the last call.  parts: bn_field_backward_parts
+    (a caller that overlaps the all-reduce of the trunk's gradient with the rest of the backward)."""
     pts = make_points(xyz, rays, z)
     ps, gs = spec.params_struct(named_params), spec.params_struct(named_grads, grads=True)
-    L.check(L.lib().bn_field_backward(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(out), _p(d_out), _p(stash),
-                                      C.byref(gs), _stream()), "bn_field_backward")
+    L.check(L.lib().bn_field_backward_parts(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(out), _p(d_out), _p(stash),
+                                            C.byref(gs), int(parts), _stream()), "bn_field_backward")
     if spec.fold_feats and unfold:
-        spec.unfold_grads(named_params, named_grads)
+        spec.unfold_grads(named_params, named_grads, zero=zero_folded)
 
 
 def field_stash_bytes(spec, n_points):
@@ -443,6 +463,139 @@ def guided_samples(z, weights, depth, u, near0, far0, d_range, use_target=None, 
                                       float(d_range), _p(use_target), _p(target_depth), _p(target_std), _p(u_target),
                                       _p(target_row), _p(z2), _p(z_all), _p(idx), _stream()), "bn_guided_samples")
     return z2, z_all, idx
+
+
+# ----------------------------------------------------------------------------------------- launch-lean fused step
+def new_step_state(device, seed, lr):
+    """Device-resident bn_step_state (include/brdfnerf_hip.h): draw seed / counter, learning rate, Adam step counts, loss ring."""
+    st = torch.zeros(L.BN_STATE_BYTES // 8, dtype=torch.int64, device=device)
+    st[0] = int(seed) & 0x7FFFFFFFFFFFFFFF
+    st.view(torch.float32)[4] = float(lr)
+    st.view(torch.float64)[L.BN_STATE_POW_OFF // 8:L.BN_STATE_POW_OFF // 8 + 8] = 1.0          # beta^0
+    return st
+
+
+def set_adam_steps(state, steps, betas=(0.9, 0.999)):
+    """Write the per-group optimiser step counts (and the beta powers that go with them) into a step state."""
+    steps = list(steps) + [0] * (4 - len(steps))
+    state.view(torch.int32)[6:10] = torch.tensor(steps, dtype=torch.int32)
+    pw = [float(betas[0]) ** s for s in steps] + [float(betas[1]) ** s for s in steps]
+    state.view(torch.float64)[L.BN_STATE_POW_OFF // 8:L.BN_STATE_POW_OFF // 8 + 8] = torch.tensor(pw, dtype=torch.float64)
+
+
+def state_views(state):
+    """(rng_step 0-d int64, lr 0-d float32, adam_step int32[4], loss_ring float32[64]) views of a step state."""
+    f, i = state.view(torch.float32), state.view(torch.int32)
+    return state[1], f[4], i[6:10], f[L.BN_STATE_LOSS_OFF // 4:L.BN_STATE_LOSS_OFF // 4 + L.BN_STATE_LOSS_SLOTS]
+
+
+def state_loss_partials(state):
+    """The 64 partial sums bn_lambert_tail adds the running step's loss terms to (bn_adam_multi folds them into the ring)."""
+    return state.view(torch.float32)[L.BN_STATE_PART_OFF // 4:L.BN_STATE_PART_OFF // 4 + L.BN_STATE_LOSS_SLOTS]
+
+
+def stratified_z_rng(rays, S, state, z=None, ray_offset=0):
+    """Stratified depths from rays[:, 6], rays[:, 7] with in-kernel uniforms (stream BN_RNG_COARSE of `state`)."""
+    R = rays.shape[0]
+    assert rays.is_contiguous() and rays.dtype == torch.float32 and rays.shape[1] >= 8
+    if z is None:
+        z = torch.empty(R, S, dtype=torch.float32, device=rays.device)
+    base = rays.data_ptr()
+    L.check(L.lib().bn_stratified_z_rng(C.c_void_p(base + 24), C.c_void_p(base + 28), rays.shape[1], _p(state), L.BN_RNG_COARSE,
+                                        int(ray_offset), R, S, _p(z), _stream()), "bn_stratified_z_rng")
+    return z
+
+
+def rng_uniform(state, stream_id, n):
+    u = torch.empty(n, dtype=torch.float32, device=state.device)
+    L.check(L.lib().bn_rng_uniform(_p(state), int(stream_id), n, _p(u), _stream()), "bn_rng_uniform")
+    return u
+
+
+def _strided(t):
+    """(pointer, element stride) of a 1-d float32 view (e.g. depths[:, 0]); None -> (None, 1)."""
+    if t is None:
+        return None, 1
+    assert t.dtype == torch.float32 and t.dim() == 1 and t.is_cuda
+    return C.c_void_p(t.data_ptr()), t.stride(0) if t.shape[0] > 1 else 1
+
+
+def composite_guided(z, out1, G, near_far, d_range, use_target=None, target_depth=None, target_std=None, u=None, u_target=None,
+                     state=None, bufs=None, want_pass1=False, ray_offset=0):
+    """Pass-1 compositing of out1 [R][S][C] (sigma = channel 3) + depth-guided resampling + merge in one launch.
+    Draws: arrays u / u_target [R][G], or the in-kernel streams of `state`.  -> z2 [R][G], z_all [R][S+G], sort_idx [R][S+G]
+    (+ pass-1 weights, depth when want_pass1)."""
+    R, S = z.shape
+    Cc = out1.shape[-1]
+    dev = z.device
+    b = bufs if bufs is not None else {}
+    mk = lambda k, shape, dt=torch.float32: b[k] if k in b else torch.empty(shape, dtype=dt, device=dev)
+    z2, z_all, idx = mk("z2", (R, G)), mk("z_all", (R, S + G)), mk("idx", (R, S + G), torch.int64)
+    w1 = mk("w1", (R, S)) if want_pass1 else None
+    d1 = mk("d1", (R,)) if want_pass1 else None
+    ut_p, ut_s = _strided(use_target)
+    td_p, td_s = _strided(target_depth)
+    ts_p, ts_s = _strided(target_std)
+    L.check(L.lib().bn_composite_guided(_p(z), C.c_void_p(out1.data_ptr() + 12), Cc, R, S, G, C.c_void_p(near_far.data_ptr()),
+                                        float(d_range), ut_p, ut_s, td_p, td_s, ts_p, ts_s, _p(u), _p(u_target), _p(state),
+                                        L.BN_RNG_GUIDED, L.BN_RNG_GUIDED_TARGET, int(ray_offset), _p(z2), _p(z_all), _p(idx), _p(w1), _p(d1),
+                                        _stream()), "bn_composite_guided")
+    return (z2, z_all, idx, w1, d1) if want_pass1 else (z2, z_all, idx)
+
+
+def merged_composite_forward(z_all, idx, out1, out2, bufs=None, want=("weights", "depth", "acc")):
+    """Compositing of the depth-sorted union of out1 [R][S1][C] and out2 [R][G][C] read through sort_idx (no cat / gather).
+    -> dict with the requested entries of alphas, trans, weights, depth, acc, wsum."""
+    R, S2 = z_all.shape
+    S1, Cc = out1.shape[1], out1.shape[2]
+    dev = z_all.device
+    b = bufs if bufs is not None else {}
+    shapes = dict(alphas=(R, S2), trans=(R, S2), weights=(R, S2), depth=(R,), acc=(R, Cc), wsum=(R,))
+    o = {k: (b[k] if k in b else torch.empty(shapes[k], dtype=torch.float32, device=dev)) for k in want}
+    g = lambda k: _p(o.get(k))
+    L.check(L.lib().bn_merged_composite_forward(_p(z_all), _p(idx), _p(out1), _p(out2), S1, S2, Cc, R, g("alphas"), g("trans"),
+                                                g("weights"), g("depth"), g("acc"), g("wsum"), _stream()), "bn_merged_composite_forward")
+    return o
+
+
+def merged_composite_backward(z_all, idx, out1, out2, d_weights, d_depth, d_acc, d_out1, d_out2, d_wsum=None, nonfinite=None):
+    """Gradient rows in the SOURCE layouts (d_out1 [R][S1][C], d_out2 [R][G][C]); channel 3 receives d sigma."""
+    R, S2 = z_all.shape
+    S1, Cc = out1.shape[1], out1.shape[2]
+    L.check(L.lib().bn_merged_composite_backward(_p(z_all), _p(idx), _p(out1), _p(out2), S1, S2, Cc, R, _p(d_weights), _p(d_depth),
+                                                 _p(d_acc), _p(d_wsum), _p(d_out1), _p(d_out2), _p(nonfinite), _stream()),
+            "bn_merged_composite_backward")
+
+
+def lambert_tail(z_all, idx, out1, out2, rgbs, rgb_padding, lambda_rgb, d_out1, d_out2, valid_depth=None, target_depth=None,
+                 target_weight=None, target_std=None, lambda_ds=0.0, usealldepth=False, ray_loss=None, loss_acc=None, rgb=None,
+                 weights=None, depth=None):
+    """Ray-level tail of a Lambertian step in one launch (bn_lambert_tail): merged compositing + shading + SNerfLoss +
+    DepthLoss + the backward of all of it, gradient rows written to d_out1 / d_out2."""
+    R, S2 = z_all.shape
+    S1, Cc = out1.shape[1], out1.shape[2]
+    use = target_depth is not None and lambda_ds > 0
+    vp, vs = _strided(valid_depth if use else None)
+    tdp, tds = _strided(target_depth if use else None)
+    twp, tws = _strided(target_weight if use else None)
+    tsp, tss = _strided(target_std if use else None)
+    L.check(L.lib().bn_lambert_tail(_p(z_all), _p(idx), _p(out1), _p(out2), S1, S2, Cc, R, _p(rgbs), vp, vs, tdp, tds, twp, tws,
+                                    tsp, tss, float(rgb_padding), float(lambda_rgb), float(lambda_ds if use else 0.0),
+                                    int(bool(usealldepth)), _p(ray_loss), _p(loss_acc), 0 if loss_acc is None else loss_acc.numel(),
+                                    _p(rgb), _p(weights), _p(depth),
+                                    _p(d_out1), _p(d_out2), _stream()), "bn_lambert_tail")
+
+
+def adam_multi(param, grad, exp_avg, exp_avg_sq, groups, active, state, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+               grad_scale=1.0, zero_grad=True):
+    """Adam over the (lo, hi) groups of one flat buffer in one launch; step counts / lr / draw counter from `state`."""
+    n = len(groups)
+    lo = (C.c_int64 * n)(*[g[0] for g in groups])
+    hi = (C.c_int64 * n)(*[g[1] for g in groups])
+    act = (C.c_int32 * n)(*[int(bool(a)) for a in active])
+    L.check(L.lib().bn_adam_multi(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, lo, hi, act, float(betas[0]), float(betas[1]),
+                                  float(eps), float(weight_decay), float(grad_scale), int(bool(zero_grad)), _p(state), _stream()),
+            "bn_adam_multi")
 
 
 # ----------------------------------------------------------------------------------------- BRDFs

@@ -90,11 +90,22 @@ def inference(model, args, rays_xyz, z_vals, rays_d=None, sun_d=None, rays_t=Non
         raise NotImplementedError("single-sample pass 2 is undefined in the reference (SURVEY quirk 4)")
     alphas, transparency, weights, depth, acc = Fn.composite(z_vals, out, noise_arg, args.noise_std)
     return shade(model, args, spec, out, z_vals, alphas, transparency, weights, depth, acc, rays_d, sun_d, apply_brdf,
-                 cos_irra_on, sort_idx, z_vals_unsort, sun_res)
+                 cos_irra_on, sort_idx, z_vals_unsort, sun_res, rows, cols)
+
+
+def ref_sphere(rows, cols, R, S, like):
+    """models/spsbrdfnerf.py:404-412 (validation visualisation of the view sphere).  The reference tiles rows / cols (R, 1) S
+    times along the RAY axis and reads them back as (R, S)[:, 0]: ray r gets element (r * S) mod R of the input - reproduced as is."""
+    sel = lambda t: t.reshape(-1).repeat(S).reshape(R, S)[:, 0]
+    out = torch.ones(R, 1, 3, dtype=like.dtype, device=like.device)
+    out[:, 0, 0] = sel(cols)
+    out[:, 0, 1] = -sel(rows)
+    out[:, 0, 2] = sel(torch.sqrt(torch.abs(1 - rows * rows - cols * cols)))
+    return out
 
 
 def shade(model, args, spec, out, z_vals, alphas, transparency, weights, depth, acc, rays_d, sun_d, apply_brdf,
-          cos_irra_on, sort_idx=None, z_vals_unsort=None, sun_res=None):
+          cos_irra_on, sort_idx=None, z_vals_unsort=None, sun_res=None, rows=None, cols=None):
     """Ray-level part of inference() (models/spsbrdfnerf.py:198-416) from the composited sums `acc` = sum_s w * out."""
     R, S = z_vals.shape
     nr_lr = spec.normal_lr
@@ -202,7 +213,45 @@ def shade(model, args, spec, out, z_vals, alphas, transparency, weights, depth, 
         result["rays_d"] = view.reshape(R, 1, 3)
     if sun_d is not None:
         result["sun_d"] = sun_d.reshape(R, 1, 3)
+    if rows is not None and cols is not None:
+        result["ref_sphere"] = ref_sphere(rows.to(rays_d), cols.to(rays_d), R, S, rays_d)
     return result, brdf_type
+
+
+def shade_ray(model, args, spec, z_vals, weights, depth, acc, rays_d, sun_d, apply_brdf, cos_irra_on):
+    """The part of shade() a training loss reads when every ray has ONE BRDF and no per-sample irradiance (MultiBRDF == 0, no
+    sun-visibility pass): rgb from the composited sums alone (models/spsbrdfnerf.py:259-357), without the per-sample entries
+    of the result dict.  Used by the launch-lean fused step, whose merged sample set is never materialised."""
+    normal_c0 = None
+    if spec.normal_an:
+        normal_c0 = spec.ch_normal_an
+    if spec.normal_lr:                              # learned wins when both are present (spsbrdfnerf.py:234-239)
+        normal_c0 = spec.ch_normal_lr
+    pad = model.rgb_padding
+    wsum = weights.sum(-1, keepdim=True)
+    albedo_s = acc[:, :3] * (1 + 2 * pad) - pad * wsum
+    irr_ray = sun_d[:, 2:3].abs() if (cos_irra_on and normal_c0 is not None) else None
+    rgb = albedo_s if irr_ray is None else albedo_s * irr_ray
+    heads = spec.heads[1:]
+    if normal_c0 is None and not heads:
+        return {"rgb": rgb.clamp(0.0, 1.0)}, "Lambertian"
+    shell = getattr(args, "shell_hapke", 0)
+    kind = None
+    if model.roughness and apply_brdf:
+        kind = "Microfacet"
+    elif model.RPV and apply_brdf:
+        kind = "RPV"
+    elif (apply_brdf and args.b == True) or shell > 0:  # noqa: E712
+        kind = "Hapke"
+    if kind is None:
+        return {"rgb": rgb.clamp(0.0, 1.0)}, "Lambertian"
+    if normal_c0 is None:
+        raise RuntimeError("BRDF shading needs a normal field (--normal learned | analystic | analystic_learned)")
+    normal_s = l2_normalize(acc[:, normal_c0:normal_c0 + 3])
+    sums = {name: acc[:, c0:c0 + wdt] for (name, _, _), (c0, wdt) in zip(spec.heads[1:], spec.head_cols[1:])}
+    brdf, _ = _per_ray_brdf(model, args, kind, sun_d, -rays_d, normal_s, albedo_s, sums)
+    rgb = brdf if irr_ray is None else irr_ray * brdf
+    return {"rgb": rgb.clamp(0.0, 1.0)}, kind
 
 
 def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_depths=None, target_std=None,
@@ -218,8 +267,6 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
         # (probed in the build container).  There is no upstream behaviour to reproduce.
         raise NotImplementedError("n_importance > 0: the reference itself raises AttributeError in its fine pass for --model "
                                   "spsbrdf-nerf (rendering.py:327-330: spsbrdfnerf.inference returns a tuple); nothing to mirror")
-    if rows is not None or cols is not None:
-        raise NotImplementedError("ref_sphere visualisation is out of the hot-path scope")
     model = models["coarse"]
     G, S = args.guided_samples, args.n_samples
     if G <= 0:
@@ -293,7 +340,7 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
     if gsam_only:
         result, brdf_type = inference(model, args, None, z2, rays_d=rays_d, sun_d=sun_d, rays_t=rays_t, z_vals_unsort=z2, apply_brdf=apply_brdf,
                                       bTestNormal=bTestNormal, sun_res=sun_res, sort_idx=None, mode=mode, apply_theta=apply_theta,
-                                      cos_irra_on=cos_irra_on, _rays=rays, _packed=packed)
+                                      cos_irra_on=cos_irra_on, _rays=rays, _packed=packed, rows=rows, cols=cols)
         return {f"{k}_coarse": v for k, v in result.items()}, brdf_type
     z_unsort = torch.cat([z_vals, z2], -1)
     out2 = model.evaluate(spec, packed, rays=rays, z=z2, t_embed=rays_t).view(R, G, C)
@@ -301,5 +348,5 @@ def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_de
     noise2 = torch.randn(R, S + G, device=rays.device)
     alphas, transparency, weights, depth, acc = Fn.composite(z_all, out, noise2 if noise_on else None, args.noise_std)
     result, brdf_type = shade(model, args, spec, out, z_all, alphas, transparency, weights, depth, acc, rays_d, sun_d, apply_brdf,
-                              cos_irra_on, idx, z_unsort)
+                              cos_irra_on, idx, z_unsort, rows=rows, cols=cols)
     return {f"{k}_coarse": v for k, v in result.items()}, brdf_type

@@ -48,6 +48,8 @@ class TrainLoop:
                                     nr_reg_an_lambda=g("nr_reg_an_lambda"), nr_reg_lr_lambda=g("nr_reg_lr_lambda"),
                                     hs_lambda=g("hs_lambda"), nr_spv_lambda=g("nr_spv_lambda") if g("nr_spv_type", 1) == 1 else 0.0)
         self.schedule = StageSchedule(args, len(table), self.world)
+        self._lambda_rgb = float(g("lambda_rgb", 1.0))
+        self._trusted_ckpts = bool(trusted_ckpts)
         self.global_step = 0
         self.last = {}
 
@@ -64,6 +66,9 @@ class TrainLoop:
         a, tr, sch = self.args, self.trainer, self.schedule
         flags = sch.begin_step()
         tr.lr = sch.lr(self.global_step)
+        # --beta: for the first two epochs the reference scores with SNerfLoss(lambda_sc) - lambda_rgb = 1 - and only then with
+        # SNerfLoss(lambda_rgb=args.lambda_rgb) (main.py:82-86, 237-238: 'beta_coarse' in results and epoch < 2)
+        tr.lambda_rgb = 1.0 if (getattr(a, "beta", False) and flags["epoch"] < 2) else self._lambda_rgb
         b = self.table.next_batch(a.batch_size * self.world, self.rank, self.world)
         has_depth = "depths" in b
         depths = b.get("depths")
@@ -92,14 +97,34 @@ class TrainLoop:
         n = self.schedule.max_steps - self.global_step if n_steps is None else n_steps
         for i in range(n):
             out = self.step()
+            if log_every and (i + 1) % log_every == 0:
+                self.check_device_faults()
             if log_every and (i + 1) % log_every == 0 and self.rank == 0:
                 nan, inf = self.trainer.dropped_grad_elems()
                 print(f"step {self.global_step} epoch {out['epoch']} loss {float(out['loss']):.5f} "
                       f"psnr {float(out['psnr']):.2f} lr {out['lr']:.2e} dropped non-finite gradient elements {nan}+{inf}", flush=True)
         return self.last
 
+    def check_device_faults(self):
+        """The library's sticky device fault word, read synchronously (log / checkpoint time): bit 0 = a forward launch lost an
+        LDS hand-over (its results are invalid: raise); bit 1 = a deterministic-mode turn wait timed out - the sums are still
+        right, their order is no longer the fixed one (warn: bitwise reproducibility is lost for this run)."""
+        import ctypes
+        import warnings
+        from . import _lib as L
+        from .functions import _stream
+        w = ctypes.c_uint(0)
+        L.check(L.lib().bn_device_faults(ctypes.byref(w), _stream()), "bn_device_faults")
+        if w.value & 1:
+            raise RuntimeError("brdf_nerf_amd: a fused forward launch lost an LDS hand-over (device fault word bit 0); its results are invalid")
+        if w.value & 2:
+            warnings.warn("brdf_nerf_amd: a deterministic-mode turn wait timed out (device fault word bit 1): gradients are correct "
+                          "but no longer bitwise reproducible in this run; the word is sticky until the process ends")
+        return w.value
+
     # ------------------------------------------------------------------ checkpoints
     def save(self, ckpts_dir, logs_dir=None):
+        self.check_device_faults()
         """`<ckpts_dir>/epoch=<e>.ckpt` in the reference's layout + resume state; `opts.json` in logs_dir (opt.py)."""
         os.makedirs(ckpts_dir, exist_ok=True)
         tr = self.trainer
@@ -109,7 +134,7 @@ class TrainLoop:
         ckpt = {"state_dict": sd,
                 "epoch": self.schedule.epoch, "global_step": self.global_step,
                 "fused_trainer": {"exp_avg": tr.exp_avg.clone(), "exp_avg_sq": tr.exp_avg_sq.clone(),
-                                  "adam_steps": dict(tr.adam_steps)},
+                                  "adam_steps": dict(tr.adam_steps), "rng": tr.state[:2].clone()},   # (draw seed, draw counter)
                 "schedule": self.schedule.state_dict(), "ray_table": self.table.state_dict()}
         path = os.path.join(ckpts_dir, f"epoch={self.schedule.epoch}.ckpt")
         torch.save(ckpt, path)
@@ -120,11 +145,19 @@ class TrainLoop:
                           f, indent=2)
         return path
 
-    def resume(self, path):
-        ckpt = torch.load(path, map_location=self.trainer.flat_param.device, weights_only=False)
-        load_ckpt(self.model, path, model_name="nerf_coarse")
+    def resume(self, path, trusted=None):
+        """Checkpoints written by save() hold tensors, numbers and dicts only: the safe unpickler loads them (weights_only=True);
+        trusted=True (or the constructor's trusted_ckpts) is the explicit opt-in for files with pickled objects."""
+        trusted = self._trusted_ckpts if trusted is None else bool(trusted)
+        ckpt = torch.load(path, map_location=self.trainer.flat_param.device, weights_only=not trusted)
+        pick = lambda prefix: {k[len(prefix) + 1:]: v for k, v in ckpt["state_dict"].items() if k.startswith(prefix + ".")}
+        sd = self.model.state_dict()
+        sd.update(pick("nerf_coarse"))
+        self.model.load_state_dict(sd)
         if self.embedding_t is not None:
-            load_ckpt(self.embedding_t, path, model_name="embedding_t")
+            sd = self.embedding_t.state_dict()
+            sd.update(pick("embedding_t"))
+            self.embedding_t.load_state_dict(sd)
         tr = self.trainer
         ft = ckpt["fused_trainer"]
         tr.exp_avg.copy_(ft["exp_avg"]); tr.exp_avg_sq.copy_(ft["exp_avg_sq"])
@@ -132,6 +165,9 @@ class TrainLoop:
             tr.adam_steps.update({k: int(v) for k, v in ft["adam_steps"].items() if k in tr.adam_steps})
         else:                                        # round-1 checkpoints: two counters (base / everything else)
             tr.adam_steps = {k: int(ft["steps_a"] if k == "base" else ft["steps_b"]) for k in tr.adam_steps}
+        if "rng" in ft:                               # the in-kernel draws resume where they stopped
+            tr.state[:2].copy_(ft["rng"])
+            tr._rng_step = int(ft["rng"][1])
         self.schedule.load_state_dict(ckpt["schedule"])
         self.table.load_state_dict(ckpt["ray_table"])
         self.global_step = int(ckpt["global_step"])

@@ -10,9 +10,10 @@ collective are single launches over ~10 MB.
 import torch
 
 from . import functions as Fn
+from . import _lib as L
 from . import losses
 from .distributed import allreduce_sum_
-from .rendering import shade, get_z_vals, inference, sun_far
+from .rendering import shade, shade_ray, get_z_vals, inference, sun_far
 
 
 class FusedTrainer:
@@ -41,6 +42,19 @@ class FusedTrainer:
         self.nr_an = model.normal in ("analystic_learned", "analystic")
         self._flatten()
         self._bufs = {}
+        # Launch-lean step (round 3; own draws only): in-kernel draws, pass-1 compositing fused with the resampling, the merged
+        # sample set composited through its sort index, one-launch Lambertian tail, fold / unfold kernels, one Adam launch for
+        # all groups - and, for a step whose inputs keep their addresses, replayed from a captured HIP graph.
+        self.lean = True
+        self.overlap_allreduce = True   # world > 1: all-reduce the trunk's gradient while the rest of the backward still runs
+        self.ray_offset = 0             # index of this rank's first ray in the global batch: in-kernel draws are taken per GLOBAL ray
+        self.keep_grads = False         # True: the optimiser launch leaves the step's gradient in flat_grad (tests, diagnostics)
+        self.use_graph = True
+        self.graph_after = 3            # eager steps with an unchanged signature before the step is captured
+        self._graphs, self._sig_seen, self._nf_dev = {}, {}, {}
+        self.state = Fn.new_step_state(self.flat_param.device, torch.initial_seed(), lr)
+        self._rng_step, self._state_lr, self._grads_clean = 0, float(lr), True
+        self._state_adam = [0, 0, 0, 0]
         # sanitize_grads bookkeeping: NaN / Inf elements of d(loss)/d(per-sample outputs) zeroed so far, counted on the
         # device (bn_count_nonfinite, no host round trip); read it with dropped_grad_elems()
         self._nonfinite = torch.zeros(2, dtype=torch.int64, device=self.flat_param.device)
@@ -68,6 +82,10 @@ class FusedTrainer:
             if tot > lo:
                 self.groups.append((gname, lo, tot))
         self.n_base = self.groups[0][2]
+        # the trunk's parameters (fc_net.*) as a leading, contiguous range of the flat buffer: the first all-reduce bucket
+        trunk = [n for n in named if n.startswith("fc_net.")]
+        ends = [offs[n] + (named[n].numel() + 3) // 4 * 4 for n in trunk]
+        self.n_trunk = max(ends) if trunk and max(ends) <= min([offs[n] for n in named if n not in trunk] + [tot]) else 0
         self.adam_steps = {gname: 0 for gname, _, _ in self.groups}
         dev = next(model.parameters()).device
         self.flat_param = torch.zeros(tot, dtype=torch.float32, device=dev)
@@ -118,6 +136,16 @@ class FusedTrainer:
         R = rays.shape[0]
         dev = rays.device
         spec = model.spec(apply_brdf, apply_theta, self.nr_lr, self.nr_an, beta=False)   # (field.py spec(): the loss never reads beta)
+        reg0 = self.reg if regularisers else {}
+        # (a loss that reads per-sample channels of the merged set - MultiBRDF, the normal regularisers - keeps the general path)
+        per_sample0 = (bool(model.MultiBRDF) and apply_brdf) or any(reg0.get(k, 0) > 0 for k in ("nr_an", "nr_lr")) or \
+            abs(reg0.get("nr_spv", 0)) > 1e-5
+        if (self.lean and not self.strict_rng and args.noise_std == 0 and not gsam_only and self.reuse_coarse and not per_sample0
+                and not (getattr(model, "sun_v", "none") == "analystic" and apply_brdf)
+                and rays.dtype == torch.float32 and rays.is_contiguous() and rays.shape[1] >= 8 and S + G <= 512):
+            return self._step_lean(spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, apply_theta, cos_irra_on,
+                                   depth_loss_on, near_far, regularisers)
+        self._grads_clean = False
         named = model.named()
         packed = model.repack(spec)
         near, far = rays[:, 6:7], rays[:, 7:8]
@@ -271,6 +299,167 @@ class FusedTrainer:
                 allreduce_sum_(self.flat_grad, self.pg)       # RCCL over xGMI: ONE collective over the ~10 MB flat buffer
             self._adam(apply_brdf, apply_theta)
         return loss.detach(), res["rgb"].detach()
+
+    # ------------------------------------------------------------------ launch-lean step
+    def _near_far(self, rays, near_far):
+        if near_far is None:
+            return rays[0, 6:8]
+        key = (float(near_far[0]), float(near_far[1]))
+        t = self._nf_dev.get(key)
+        if t is None:
+            t = self._nf_dev[key] = torch.tensor(key, dtype=torch.float32, device=rays.device)
+        return t
+
+    def _sync_state(self, on):
+        """Host-side hyper-parameters -> device step state, only when they changed (learning-rate decay, a step taken on the
+        other path)."""
+        _, lr_v, steps_v, _ = Fn.state_views(self.state)
+        if float(self.lr) != self._state_lr:
+            lr_v.fill_(float(self.lr))
+            self._state_lr = float(self.lr)
+        want = [self.adam_steps[g] for g, _, _ in self.groups] + [0] * (4 - len(self.groups))
+        if want != self._state_adam:
+            Fn.set_adam_steps(self.state, want, self.betas)
+            self._state_adam = list(want)
+
+    def _step_lean(self, spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, apply_theta, cos_irra_on, depth_loss_on,
+                   near_far, regularisers):
+        model, args = self.model, self.args
+        reg = self.reg if regularisers else {}
+        lambertian = (len(spec.heads) == 1 and not spec.normal_an and not spec.normal_lr and reg.get("hs", 0) <= 0)
+        if not self._grads_clean:          # the general path leaves its gradient in the flat buffer
+            self.flat_grad.zero_()
+            self._grads_clean = True
+        f32 = lambda t: t if (t is None or (t.dtype == torch.float32)) else t.float()
+        rgbs = f32(rgbs).contiguous()
+        use_ds = self.ds_lambda > 0 and depth_loss_on and valid_depth is not None
+        valid_depth, depths = f32(valid_depth), f32(depths)
+        depth_std = None if depth_std is None else f32(depth_std).reshape(-1)
+        nf = self._near_far(rays, near_far)
+        on = {"base": True, "brdf": bool(apply_brdf), "theta": bool(apply_brdf and apply_theta)}
+        active = [on[g] for g, _, _ in self.groups]
+        self._sync_state(on)
+        slot = self._rng_step % 64
+        body = lambda: self._lean_body(spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, cos_irra_on, use_ds, nf, reg,
+                                       lambertian, active)
+        res = None
+        if self.use_graph and self.world == 1 and lambertian:
+            sig = (spec.key(), rays.shape, rays.data_ptr(), rgbs.data_ptr(), None if valid_depth is None else valid_depth.data_ptr(),
+                   None if depths is None else depths.data_ptr(), None if depth_std is None else depth_std.data_ptr(),
+                   nf.data_ptr(), use_ds, tuple(active), float(self.ds_lambda), float(self.lambda_rgb), bool(self.usealldepth),
+                   L.deterministic(), int(self.ray_offset), bool(self.keep_grads))
+            ent = self._graphs.get(sig)
+            if ent is not None:
+                ent[0].replay()
+                res = ent[1]
+            else:
+                n = self._sig_seen.get(sig, 0) + 1
+                self._sig_seen[sig] = n
+                if n > self.graph_after and len(self._graphs) < 16:
+                    # keep the inputs alive with the graph: their addresses are baked into it
+                    keep = (rays, rgbs, valid_depth, depths, depth_std, nf)
+                    g = torch.cuda.CUDAGraph()
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g):
+                        out = body()
+                    self._graphs[sig] = (g, out, keep)
+                    g.replay()            # the capture itself does not execute: this is the step
+                    res = out
+        if res is None:
+            res = body()
+        self._grads_clean = not self.keep_grads
+        self._rng_step += 1
+        for (gname, _, _), a in zip(self.groups, active):
+            if a:
+                self.adam_steps[gname] += 1
+        self._state_adam = [self.adam_steps[g] for g, _, _ in self.groups] + [0] * (4 - len(self.groups))
+        loss, rgb = res
+        if loss is None:
+            loss = Fn.state_views(self.state)[3][slot]
+        return loss.detach(), rgb.detach()
+
+    def _lean_body(self, spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, cos_irra_on, use_ds, nf, reg, lambertian,
+                   active):
+        model, args = self.model, self.args
+        S, G = args.n_samples, args.guided_samples
+        R, C = rays.shape[0], spec.out_channels
+        st = self.state
+        named = model.named()
+        with torch.no_grad():
+            packed = model.repack(spec)                                   # fold + pack: 2 launches
+            z = Fn.stratified_z_rng(rays, S, st, self._buf("z", (R, S)), ray_offset=self.ray_offset)
+            out1 = self._buf("out1", (R * S, C))
+            stash1 = self._buf("stash1", (Fn.field_stash_bytes(spec, R * S),), torch.uint8)
+            Fn.field_forward_raw(spec, named, packed, out1, stash1, rays=rays, z=z)
+            out1v = out1.view(R, S, C)
+            bufs = {"z2": self._buf("z2", (R, G)), "z_all": self._buf("z_all", (R, S + G)),
+                    "idx": self._buf("idx", (R, S + G), torch.int64)}
+            has_t = valid_depth is not None
+            z2, z_all, idx = Fn.composite_guided(z, out1v, G, nf, args.std_range, valid_depth if has_t else None,
+                                                 depths[:, 0] if has_t else None, depth_std if has_t else None, state=st, bufs=bufs,
+                                                 ray_offset=self.ray_offset)
+            out2 = self._buf("out2", (R * G, C))
+            stash2 = self._buf("stash2", (Fn.field_stash_bytes(spec, R * G),), torch.uint8)
+            Fn.field_forward_raw(spec, named, packed, out2, stash2, rays=rays, z=z2)
+            out2v = out2.view(R, G, C)
+            d1o, d2o = self._buf("d1o", (R, S, C)), self._buf("d2o", (R, G, C))
+        loss = None
+        if lambertian:
+            rgb = self._buf("rgb", (R, 3))
+            det = L.deterministic()        # the reported loss too: a fixed-order sum of the per-ray terms instead of atomics
+            ray_loss = self._buf("ray_loss", (R,)) if det else None
+            with torch.no_grad():
+                Fn.lambert_tail(z_all, idx, out1v, out2v, rgbs, model.rgb_padding, self.lambda_rgb, d1o, d2o,
+                                valid_depth if use_ds else None, depths[:, 0] if use_ds else None, depths[:, 1] if use_ds else None,
+                                depth_std if use_ds else None, self.ds_lambda if use_ds else 0.0, self.usealldepth,
+                                ray_loss=ray_loss, loss_acc=None if det else Fn.state_loss_partials(st), rgb=rgb)
+                if det:
+                    loss = ray_loss.sum()
+        else:
+            with torch.no_grad():
+                o = Fn.merged_composite_forward(z_all, idx, out1v, out2v,
+                                                {k: self._buf("m_" + k, sh) for k, sh in (("weights", (R, S + G)), ("depth", (R,)),
+                                                                                          ("acc", (R, C)))})
+            acc_l, depth_l, weights_l = o["acc"].requires_grad_(True), o["depth"].requires_grad_(True), o["weights"].requires_grad_(True)
+            rays_d = rays[:, 3:6]
+            sun_d = rays[:, 8:11] if args.data == "sat" else torch.ones_like(rays[:, 0:3])
+            res, _ = shade_ray(model, args, spec, z_all, weights_l, depth_l, acc_l, rays_d, sun_d, apply_brdf, cos_irra_on)
+            loss = losses.snerf_loss(res["rgb"], rgbs, self.lambda_rgb)
+            if use_ds:
+                loss = loss + losses.depth_loss(z_all, depth_l, weights_l, depths[:, 0], depths[:, 1], valid_depth, depth_std,
+                                                self.ds_lambda, self.usealldepth)
+            if reg.get("hs", 0) > 0:
+                loss = loss + losses.hard_surface_loss(z_all, depth_l, weights_l, reg["hs"])
+            d_acc, d_depth, d_weights = torch.autograd.grad(loss, [acc_l, depth_l, weights_l], allow_unused=True)
+            rgb = res["rgb"]
+            with torch.no_grad():
+                cg = lambda t: None if t is None else t.contiguous()
+                Fn.merged_composite_backward(z_all, idx, out1v, out2v, cg(d_weights), cg(d_depth), cg(d_acc), d1o, d2o,
+                                             nonfinite=self._nonfinite if self.sanitize_grads else None)
+        with torch.no_grad():
+            Fn.field_backward_raw(spec, named, self.grad_views, packed, out1, d1o.view(R * S, C), stash1, rays=rays, z=z, unfold=False)
+            if self.world > 1 and self.overlap_allreduce and 0 < self.n_trunk < self.flat_grad.numel() and not L.deterministic():
+                # Two buckets (the reference: DDP's bucketed all-reduce overlapped with backward, main.py:720-731): the trunk's
+                # gradient is final after the second backward's trunk weight-gradient launch - its all-reduce (RCCL's own
+                # stream, ordered behind this one) runs under the head / skinny weight gradients and the unfold launch
+                import torch.distributed as dist
+                Fn.field_backward_raw(spec, named, self.grad_views, packed, out2, d2o.view(R * G, C), stash2, rays=rays, z=z2,
+                                      unfold=False, parts=L.BN_BWD_CHAIN | L.BN_BWD_WGRAD_TRUNK)
+                wa = dist.all_reduce(self.flat_grad[:self.n_trunk], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                Fn.field_backward_raw(spec, named, self.grad_views, packed, out2, d2o.view(R * G, C), stash2, rays=rays, z=z2,
+                                      zero_folded=False, parts=L.BN_BWD_WGRAD_HEADS | L.BN_BWD_SKINNY)
+                wb = dist.all_reduce(self.flat_grad[self.n_trunk:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                wa.wait()
+                wb.wait()
+            else:
+                Fn.field_backward_raw(spec, named, self.grad_views, packed, out2, d2o.view(R * G, C), stash2, rays=rays, z=z2,
+                                      zero_folded=False)      # (bn_fold_heads of the next step clears the folded accumulators)
+                if self.world > 1:
+                    allreduce_sum_(self.flat_grad, self.pg)
+            keep = self.keep_grads       # test hook: leave the gradient in the flat buffer
+            Fn.adam_multi(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, [(lo, hi) for _, lo, hi in self.groups],
+                          active, st, self.betas, self.eps, self.wd, 1.0 / self.world, zero_grad=not keep)
+        return loss, rgb
 
     def _adam(self, apply_brdf, apply_theta=False):
         scale = 1.0 / self.world          # DDP averages gradients

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BN_ABI_VERSION 3
+#define BN_ABI_VERSION 4
 #define BN_MAX_LAYERS 12
 #define BN_MAX_HEADS 6 /* rgb (+ beta) + up to 3 BRDF heads evaluated together, two per pass */
 
@@ -179,6 +179,18 @@ int bn_field_backward(const bn_field_desc *desc, const bn_field_params *params, 
                       const bn_points *pts, const float *out, const float *d_out, void *stash,
                       const bn_field_grads *grads, void *stream);
 
+/* bn_field_backward in parts (a bit mask), for callers that overlap the gradient all-reduce with the rest of the backward
+ * (the reference: Lightning DDP's bucketed all-reduce, main.py:720-731): BN_BWD_CHAIN = the dX chain(s) that fill the
+ * stash with the pre-activation gradients; BN_BWD_WGRAD_TRUNK = the weight gradients of the trunk layers (the leading,
+ * contiguous share of a flat parameter buffer in state_dict order); BN_BWD_WGRAD_HEADS = those of the (folded) head first
+ * layers, the feats layer and the extra-input columns; BN_BWD_SKINNY = the one- to four-row matrices (sigma head, learned
+ * normal, second head layers) and d_t_embed.  The parts of one backward are called in this order on one stream; the
+ * deterministic mode takes BN_BWD_ALL only. */
+enum { BN_BWD_CHAIN = 1, BN_BWD_WGRAD_TRUNK = 2, BN_BWD_WGRAD_HEADS = 4, BN_BWD_SKINNY = 8, BN_BWD_ALL = 15 };
+int bn_field_backward_parts(const bn_field_desc *desc, const bn_field_params *params, const void *packed,
+                            const bn_points *pts, const float *out, const float *d_out, void *stash,
+                            const bn_field_grads *grads, int32_t parts, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Alpha compositing (cal_weight, models/spsbrdfnerf.py:50-69) fused with the per-ray weighted
  * sums of inference() (:198,:242,:271,:275,:292,:314-317,:326-338).
@@ -269,6 +281,107 @@ int bn_brdf_microfacet_backward(const float *l, const float *v, const float *n, 
 int bn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                  float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
                  void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Launch-lean fused training step (round 3).  The reference's step is ~150 ATen launches of glue around the field
+ * evaluations (rendering.py:168-291, models/spsbrdfnerf.py:198-416, metrics.py:39-161, main.py:147-168); these entry points
+ * fold that glue into a handful of per-ray kernels so that a Lambertian step is <= 20 launches and can be captured in a
+ * HIP graph (no argument changes from step to step: draws, step counters and the learning rate live in device memory).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Device-resident state of the fused step (bn_step_state, 512 bytes, 16-byte aligned; the caller allocates and zero-fills
+ * it, sets rng_seed / lr, and may rewrite lr between steps):
+ *   [0]  u64 rng_seed      Philox key of the in-kernel draws
+ *   [8]  u64 rng_step      Philox counter word, advanced by bn_adam_multi (one per training step)
+ *   [16] f32 lr            learning rate read by bn_adam_multi
+ *   [20] u32 done          internal (completion ticket of bn_adam_multi)
+ *   [24] i32 adam_step[4]  optimiser step count per parameter group (torch.optim.Adam keeps one per parameter)
+ *   [64] f32 loss_ring[64] loss of step t at slot t % 64 (written by bn_adam_multi from the partial sums)
+ *   [320] f64 beta1_pow[4], [352] f64 beta2_pow[4]   beta^adam_step per group (1.0 at step 0): the bias corrections
+ *   [512] f32 loss_part[64] partial sums of the running step's loss (bn_lambert_tail adds ray r's term to slot r % 64;
+ *                           bn_adam_multi folds them into the ring and clears them) */
+#define BN_STATE_BYTES 1024
+#define BN_STATE_LOSS_OFF 64
+#define BN_STATE_LOSS_SLOTS 64
+#define BN_STATE_POW_OFF 320
+#define BN_STATE_PART_OFF 512
+#define BN_ADAM_MAX_GROUPS 4
+/* in-kernel draw streams of one step */
+enum { BN_RNG_COARSE = 1, BN_RNG_GUIDED = 2, BN_RNG_GUIDED_TARGET = 3 };
+
+/* bn_stratified_z with in-kernel uniforms (stream `rng_stream` of the state at `rng` = &state[0]).  The draw of sample s of
+ * ray r is element (ray_offset + r) * S + s of the stream: a rank that holds rays [ray_offset, ray_offset + R) of a global
+ * batch draws exactly what a single process would draw for them. */
+int bn_stratified_z_rng(const float *near, const float *far, int64_t nf_stride, const unsigned long long *rng,
+                        uint32_t rng_stream, int64_t ray_offset, int64_t R, int32_t S, float *z, void *stream);
+/* The uniforms an in-kernel stream hands to elements 0..n-1, as an array (tests, and callers that want to replay a step). */
+int bn_rng_uniform(const unsigned long long *rng, uint32_t rng_stream, int64_t n, float *u, void *stream);
+
+/* Pass-1 compositing (cal_weight on sigma [R][S], element stride sigma_stride, no noise) + bn_guided_samples_nf in one
+ * launch.  Per-ray prior arrays carry an element stride (depths[:, 0] of the [R][2] table, satellite_rgb_dep.py:339).
+ * Draws: arrays u [R][G] / u_target [R][G] (one row per ray), or - when u == NULL - the in-kernel streams rng_u / rng_ut
+ * of `rng`.  weights [R][S] / depth [R] (nullable) receive the pass-1 weights and depth. */
+int bn_composite_guided(const float *z, const float *sigma, int64_t sigma_stride, int64_t R, int32_t S, int32_t G,
+                        const float *near_far, float d_range, const float *use_target, int64_t ut_stride,
+                        const float *target_depth, int64_t td_stride, const float *target_std, int64_t ts_stride,
+                        const float *u, const float *u_target, const unsigned long long *rng, uint32_t rng_u,
+                        uint32_t rng_ut, int64_t ray_offset, float *z2_sorted, float *z_all, int64_t *sort_idx, float *weights,
+                        float *depth, void *stream);
+
+/* Compositing of the depth-sorted union of two field outputs without materialising it: sample s of ray r is row
+ * sort_idx[r][s] of cat[out1[r] ([S1][C]), out2[r] ([S2-S1][C])] (rendering.py:263-272; sigma = channel 3).  sort_idx ==
+ * NULL: out1 alone (S1 == S2).  Forward: cal_weight + the weighted sums acc [R][C] (acc[:, 3] is not defined), wsum [R] =
+ * sum_s w.  Backward: from d_weights [R][S2], d_depth [R], d_acc [R][C] (d_acc[:, 3] ignored), d_wsum [R] (all nullable)
+ * to the gradient rows d_out1 / d_out2 in the SOURCE layouts (channel 3 = d sigma).  nonfinite (nullable): NaN / Inf
+ * gradient elements are written as 0 and counted ([0] NaN, [1] Inf) - FusedTrainer.sanitize_grads without extra passes. */
+int bn_merged_composite_forward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
+                                int32_t S2, int32_t C, int64_t R, float *alphas, float *trans, float *weights, float *depth,
+                                float *acc, float *wsum, void *stream);
+int bn_merged_composite_backward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
+                                 int32_t S2, int32_t C, int64_t R, const float *d_weights, const float *d_depth,
+                                 const float *d_acc, const float *d_wsum, float *d_out1, float *d_out2,
+                                 unsigned long long *nonfinite, void *stream);
+/* Ray-level tail of a Lambertian step in ONE launch: bn_merged_composite_forward + bn_lambert_loss (shading, SNerfLoss,
+ * DepthLoss; metrics.py:39-61,82-161) + bn_merged_composite_backward.  The prior arrays carry element strides.  ray_loss [R]
+ * (nullable) and/or loss_acc (nullable): ray r's term is atomically added to loss_acc[r % loss_slots] - partial sums the
+ * caller adds up (4096 atomics on ONE word serialise to ~50 us; the step state's 64 partials are folded into its loss ring
+ * by bn_adam_multi). */
+int bn_lambert_tail(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1, int32_t S2,
+                    int32_t C, int64_t R, const float *rgbs, const float *valid_depth, int64_t v_stride,
+                    const float *target_depth, int64_t td_stride, const float *target_weight, int64_t tw_stride,
+                    const float *target_std, int64_t ts_stride, float rgb_padding, float lambda_rgb, float lambda_ds,
+                    int32_t usealldepth, float *ray_loss, float *loss_acc, int32_t loss_slots, float *rgb,
+                    float *weights, float *depth, float *d_out1, float *d_out2, void *stream);
+
+/* Folding of the linear feats layer into the heads' first layers (bn_field_desc.fold_feats) and the chain rule back, as
+ * two launches of exact-fp32 MFMA tiles:
+ *   bn_fold_heads:    w_fold[h] = w1[h][:, :F] wf ;  b_fold[h] = w1[h][:, :F] bf + b1[h] ;  m[h] = 0, s[h] = 0
+ *   bn_unfold_heads:  d_w1[h][:, :F] += m[h] wf^T + s[h] bf^T ;  d_b1[h] += s[h] ;  d_wf += sum_h w1[h]^T m[h] ;  d_bf += sum_h w1[h]^T s[h]
+ * m[h] [rows][F] / s[h] [rows] are the gradients of the folded first layers that bn_field_backward accumulates. */
+typedef struct {
+  int32_t n_heads, F, rows;              /* rows = hidden width of the heads (F / 2) */
+  const float *wf, *bf;                  /* feats_from_xyz [F][F], [F] */
+  const float *w1[BN_MAX_HEADS];         /* first-layer weights [rows][w1_ld], columns [0, F) used */
+  int64_t w1_ld[BN_MAX_HEADS];
+  const float *b1[BN_MAX_HEADS];
+  float *w_fold[BN_MAX_HEADS], *b_fold[BN_MAX_HEADS];   /* [rows][F], [rows] */
+  float *m[BN_MAX_HEADS], *s[BN_MAX_HEADS];             /* folded-gradient accumulators (nullable: inference) */
+  float *d_w1[BN_MAX_HEADS];
+  int64_t d_w1_ld[BN_MAX_HEADS];
+  float *d_b1[BN_MAX_HEADS];
+  float *d_wf, *d_bf;
+} bn_fold_desc;
+int bn_fold_heads(const bn_fold_desc *d, void *stream);
+int bn_unfold_heads(const bn_fold_desc *d, void *stream);
+
+/* Adam over the parameter groups of one flat buffer in ONE launch (torch.optim.Adam semantics per group, main.py:147-168):
+ * group g = elements [lo[g], hi[g]) (multiples of 4), stepped only when active[g] (a group that is not in this step's graph
+ * has grad None upstream and is skipped).  Step counts, the learning rate and the draw counter live in `state`
+ * (bn_step_state): the kernel uses adam_step[g] + 1 and, when its last workgroup finishes, increments the active groups'
+ * counts and rng_step and folds the loss partials into the loss ring.  zero_grad != 0: the gradient elements it read are set to 0. */
+int bn_adam_multi(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t n_groups, const int64_t *lo,
+                  const int64_t *hi, const int32_t *active, float beta1, float beta2, float eps, float weight_decay,
+                  float grad_scale, int32_t zero_grad, void *state, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Debug hook replacing the reference's check_nan / checknan / check_nan_parms (train_utils.py:14-78,

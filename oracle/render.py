@@ -126,9 +126,20 @@ def guided_samples(depth, weights, z, n_guided, near0, far0, rnd, d_range=3.0, m
     return z2, inds, inds_gt
 
 
+def ref_sphere(rows, cols, R, S, like):
+    """spsbrdfnerf.py:404-412.  rows / cols (R, 1) in [-1, 1] are tiled S times along the ray axis and read back as (R, S)[:, 0]:
+    ray r gets element (r * S) mod R of the input, not element r - restated as written upstream."""
+    sel = lambda t: t.reshape(-1).repeat(S).reshape(R, S)[:, 0]
+    out = torch.ones(R, 1, 3, dtype=like.dtype)
+    out[:, 0, 0] = sel(cols)
+    out[:, 0, 1] = -sel(rows)
+    out[:, 0, 2] = sel(torch.sqrt(torch.abs(1 - rows * rows - cols * cols)))
+    return out
+
+
 def inference(params, cfg, xyz, z, rays_d, sun_d, rnd, sigma_only=False, apply_brdf=False,
               apply_theta=False, cos_irra_on=False, sort_idx=None, z_unsort=None, bTestNormal=False, sun_res=None,
-              rays_t=None):
+              rays_t=None, rows=None, cols=None):
     """inference (spsbrdfnerf.py:71-416) for sun_v in ('none', 'analystic').  Returns (dict, brdf_type).
     rays_t (R, t_dim): per-ray image embedding for --beta (repeated per sample, :98)."""
     R, S = z.shape
@@ -271,12 +282,14 @@ def inference(params, cfg, xyz, z, rays_d, sun_d, rnd, sigma_only=False, apply_b
         result.update(extra)
     result["rays_d"] = view.reshape(R, 1, 3)
     result["sun_d"] = sun_d.reshape(R, 1, 3)
+    if rows is not None and cols is not None:                    # (:404-412; not reached by the Lambertian early return)
+        result["ref_sphere"] = ref_sphere(rows, cols, R, S, rays_d)
     return result, brdf_type
 
 
 def render_rays(params, cfg, rays, rnd, mode="test", valid_depth=None, target_depths=None, target_std=None,
                 apply_brdf=False, apply_theta=False, cos_irra_on=False, gsam_only=False, bTestNormal=False,
-                bTestSun_v=False, rays_t=None):
+                bTestSun_v=False, rays_t=None, rows=None, cols=None):
     """render_rays, spsbrdf-nerf branch (rendering.py:168-291), guided_samples>0, sun_v in ('none', 'analystic').
     rays_t = models['t'](ts) (rendering.py:226-229), needed with cfg.beta."""
     o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
@@ -318,7 +331,7 @@ def render_rays(params, cfg, rays, rnd, mode="test", valid_depth=None, target_de
     xyz = o.unsqueeze(1) + d.unsqueeze(1) * z_all.unsqueeze(2)
     res, brdf_type = inference(params, cfg, xyz, z_all, d, sun_d, rnd, apply_brdf=apply_brdf,
                                apply_theta=apply_theta, cos_irra_on=cos_irra_on, sort_idx=idx,
-                               z_unsort=z_unsort, bTestNormal=bTestNormal, sun_res=sun_res, rays_t=rays_t)
+                               z_unsort=z_unsort, bTestNormal=bTestNormal, sun_res=sun_res, rays_t=rays_t, rows=rows, cols=cols)
     out = {f"{k}_coarse": v for k, v in res.items()}
     out["_pass1"] = res1
     out["_guided_inds"] = inds

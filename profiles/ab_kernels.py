@@ -23,6 +23,7 @@ def main():
     tags = [a for a in sys.argv[1:] if not a.startswith("--")]
     opt = dict(a[2:].split("=", 1) for a in sys.argv[1:] if a.startswith("--") and "=" in a)
     config, dtype, rounds = opt.get("config", "lambert"), opt.get("dtype", "bf16"), int(opt.get("rounds", 5))
+    n_rays = int(opt.get("rays", 4096))
     dev = torch.device("cuda", 0)
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     variants = {}
@@ -31,14 +32,15 @@ def main():
             os.path.join(here, "brdf_nerf_amd", "build", tag, "libbrdfnerf_hip.so")
         h = L.load(path)
         L.use(h)
-        args = bench.make_args(4096, 64, 64, dtype, **bench.CONFIG_FLAGS[config][0])
+        args = bench.make_args(n_rays, 64, 64, dtype, **bench.CONFIG_FLAGS[config][0])
         torch.manual_seed(0)
         model = load_model(args).to(dev)
         tr = FusedTrainer(model, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+        tr.use_graph = False              # the per-kernel events live in the library's launch sites: eager steps
         variants[tag] = (h, args, model, tr)
-    b = bench.synthetic_batch(4096, 1, dev)
+    b = bench.synthetic_batch(n_rays, 1, dev)
     flags = bench.CONFIG_FLAGS[config][1]
-    z = torch.sort(torch.rand(4096, 128, device=dev) * 2, -1)[0]
+    z = torch.sort(torch.rand(n_rays, 128, device=dev) * 2, -1)[0]
     times = {tag: {} for tag in tags}
     for rnd in range(rounds + 1):                       # round 0 = warm-up
         for tag in tags:
@@ -59,8 +61,28 @@ def main():
                 continue
             for k, (ms, n) in prof.items():
                 times[tag].setdefault(k, []).append(ms / n)
-    keys = ["field_fwd_sigma", "field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad", "field_adjoint", "field_adjoint_bwd"]
-    print(f"config {config} dtype {dtype}: ms per launch, median (min) over {rounds} alternating rounds")
+    # whole steps, graph replay where the trainer captures one: wall time of 30 steps per variant, alternating
+    import time
+    step_ms = {tag: [] for tag in tags}
+    for rnd in range(rounds + 1):
+        for tag in tags:
+            h, args, model, tr = variants[tag]
+            L.use(h)
+            tr.use_graph = True
+            for _ in range(6):
+                tr.step(b["rays"], b["rgbs"], valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"],
+                        near_far=(0.0, 2.0), **flags)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                tr.step(b["rays"], b["rgbs"], valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"],
+                        near_far=(0.0, 2.0), **flags)
+            torch.cuda.synchronize()
+            if rnd:
+                step_ms[tag].append((time.perf_counter() - t0) / 30 * 1e3)
+    keys = ["pack", "field_fwd_sigma", "field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad", "field_adjoint", "field_adjoint_bwd",
+            "composite_fwd", "composite_bwd", "guided_samples", "stratified_z", "adam"]
+    print(f"config {config} dtype {dtype} rays {n_rays}: ms per launch, median (min) over {rounds} alternating rounds")
     print(f"{'kernel':>18} " + " ".join(f"{t[:26]:>26}" for t in tags))
     for k in keys:
         if not any(k in times[t] for t in tags):
@@ -70,6 +92,7 @@ def main():
             v = times[t].get(k)
             row.append(f"{statistics.median(v):.4f} ({min(v):.4f})" if v else "-")
         print(f"{k:>18} " + " ".join(f"{c:>26}" for c in row))
+    print(f"{'step (wall, ms)':>18} " + " ".join(f"{statistics.median(step_ms[t]):.4f} ({min(step_ms[t]):.4f})".rjust(26) for t in tags))
 
 
 if __name__ == "__main__":

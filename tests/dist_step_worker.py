@@ -40,11 +40,17 @@ def main():
     u_t_row = torch.rand(1, G, generator=g)
     draws_full = [torch.rand(R, S, generator=g), torch.rand(R, G, generator=g), u_t_row.expand(R, G).contiguous()]
 
+    lean = os.environ.get("BN_DIST_LEAN", "1") == "1"
+
     def run(lo, hi, data_parallel):
         torch.manual_seed(0)
         model = load_model(args).to(dev)
+        torch.manual_seed(5)               # the step state's draw key: the same on every rank
         tr = FusedTrainer(model, args, lr=5e-4, ds_lambda=10.0, strict_rng=False, data_parallel=data_parallel)
-        feed = [d[lo:hi].to(dev) for d in draws_full]
+        tr.lean = lean
+        tr.keep_grads = True
+        tr.ray_offset = lo                 # lean step: in-kernel draws per GLOBAL ray - a shard draws what the whole batch would
+        feed = [d[lo:hi].to(dev) for d in draws_full] if not lean else []
         orig = torch.rand
 
         def rand(*size, **k):

@@ -372,6 +372,43 @@ def gen_render(ref):
          **arrays)
 
 
+BRANCHES = {     # round 3: branches of inference() that no fixture reached ("unpinned branches")
+    # funcH == 2: rhoc := albedo, no rhoc head (models/spsbrdfnerf.py:306,317), per ray and per sample
+    "rpv_m1f1h2": (dict(funcM=1, funcF=1, funcH=2, normal="learned"), dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    "rpv_m1f1h2_multibrdf": (dict(funcM=1, funcF=1, funcH=2, normal="learned", MultiBRDF=True),
+                             dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    "rpv_m1h2": (dict(funcM=1, funcH=2, normal="learned"), dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    # shell_hapke > 0 shades with the Hapke shell even with apply_brdf=False (:320,348,383)
+    "shell1_nobrdf": (dict(shell_hapke=1, normal="learned"), dict(apply_brdf=False, apply_theta=False, cos_irra_on=False)),
+    "shell2_nobrdf": (dict(shell_hapke=2, normal="learned"), dict(apply_brdf=False, apply_theta=False, cos_irra_on=True)),
+    "shell3_nobrdf": (dict(shell_hapke=3, normal="learned"), dict(apply_brdf=False, apply_theta=False, cos_irra_on=True)),
+    "shell3_brdf": (dict(shell_hapke=3, normal="learned"), dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+}
+
+
+def gen_branches(ref):
+    R = 48
+    rays = sat_rays(R, 3)
+    for name, (kw, flags) in BRANCHES.items():
+        cfg = mini(**kw)
+        model, csum = build_ref_model(ref, cfg, seed=11)
+        res, brdf_type, rlog = run_render(ref, cfg, model, rays, "test", flags)
+        arrays = {f"out/{k}": v for k, v in res.items()}
+        arrays.update({f"rand{i}": t for i, t in enumerate(rlog)})
+        save(f"render_{name}_test", rays=rays, brdf_type=np.array(brdf_type), param_checksum=csum, param_seed=11, **arrays)
+    # rows / cols -> ref_sphere (:404-412; visualisation of the view sphere in validation, main.py:451-555)
+    g = torch.Generator().manual_seed(6)
+    rows, cols = (torch.rand(R, 1, generator=g) * 1.2 - 0.6), (torch.rand(R, 1, generator=g) * 1.2 - 0.6)
+    cfg = mini(funcM=1, funcF=1, funcH=1, normal="learned")
+    model, csum = build_ref_model(ref, cfg, seed=11)
+    res, brdf_type, rlog = run_render(ref, cfg, model, rays, "test", dict(apply_brdf=True, apply_theta=True, cos_irra_on=True,
+                                                                            rows=rows, cols=cols))
+    arrays = {f"out/{k}": v for k, v in res.items()}
+    arrays.update({f"rand{i}": t for i, t in enumerate(rlog)})
+    save("render_rpv111_nlr_refsphere_test", rays=rays, rows=rows, cols=cols, brdf_type=np.array(brdf_type), param_checksum=csum,
+         param_seed=11, **arrays)
+
+
 def gen_render_sunv(ref, rays=None, targets=None):
     """Sun-visibility pass (--sun_v analystic, rendering.py:244-259) with gsam_only=True - the only combination the
     reference's pass 2 accepts - and cos_irra_on=False so the visibility IS the irradiance."""
@@ -587,6 +624,9 @@ if __name__ == "__main__":
     if "--only-render" in sys.argv:
         gen_render(ref)
         sys.exit(0)
+    if "--only-branches" in sys.argv:
+        gen_branches(ref)
+        sys.exit(0)
     gen_field(ref)
     gen_field_variants(ref)
     gen_composite(ref)
@@ -598,3 +638,4 @@ if __name__ == "__main__":
     gen_init(ref)
     gen_viewdir(ref)
     gen_beta(ref)
+    gen_branches(ref)

@@ -35,6 +35,12 @@ def draw_config(rng):
         kw.update(funcM=int(rng.random() < 0.7), funcF=int(rng.random() < 0.7), funcH=int(rng.random() < 0.7), dim_RPV=int(rng.choice([1, 3])))
         if not (kw["funcM"] or kw["funcF"] or kw["funcH"]):
             kw["funcM"] = 1
+        # funcH == 2 (rhoc := albedo, no rhoc head; spsbrdfnerf.py:306,317) for a third of the draws without a rhoc head - chosen
+        # from values already drawn, so the random stream of the other cases is the one of round 2
+        if kw["funcH"] == 0 and (feat // 64 + layers) % 3 == 0:
+            kw["funcH"] = 2
+            if not (kw["funcM"] or kw["funcF"]):
+                kw["funcM"] = 1
     elif family == "hapke":
         kw.update(b=1, c=int(rng.random() < 0.7), theta=int(rng.random() < 0.5))
     elif family == "microfacet":

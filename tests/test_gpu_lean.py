@@ -1,0 +1,400 @@
+"""GPU tests of the launch-lean fused step (round 3): the in-kernel draws, the fused per-ray kernels against the validated
+unfused ones (which are held to the reference's goldens in test_gpu_parity.py) and against the reference's render golden,
+the fold / unfold and multi-group Adam kernels against torch, and the lean FusedTrainer step - eager and replayed from a HIP
+graph - against the general path fed with the same draws."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle.config import FieldConfig  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _sat_rays(R, g):
+    o = torch.cat([torch.rand(R, 2, generator=g) * 2 - 1, 1.0 + 0.02 * torch.rand(R, 1, generator=g)], -1)
+    d = torch.tensor([0.15, 0.2, -0.96]).expand(R, 3)
+    sun = torch.tensor([-0.37, 0.44, 0.82]).expand(R, 3)
+    return torch.cat([o, d, torch.zeros(R, 1), torch.full((R, 1), 2.0), sun], -1).contiguous()
+
+
+def _field_like(R, S, C, g):
+    """Random per-sample field outputs with a realistic density channel (many zeros, a few large values)."""
+    out = torch.rand(R, S, C, generator=g)
+    sig = torch.rand(R, S, generator=g)
+    out[..., 3] = torch.where(sig < 0.5, torch.zeros_like(sig), 40.0 * (sig - 0.5) ** 2)
+    return out.to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------ draws
+def test_in_kernel_draws_are_uniform_and_step_dependent():
+    from brdf_nerf_amd import functions as Fn
+    st = Fn.new_step_state(DEV, 1234, 5e-4)
+    n = 1 << 20
+    u = Fn.rng_uniform(st, 1, n)
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0
+    assert abs(float(u.mean()) - 0.5) < 2e-3 and abs(float(u.var()) - 1 / 12) < 1e-3
+    hist = torch.histc(u, bins=64, min=0, max=1)
+    assert float((hist / (n / 64) - 1).abs().max()) < 0.03
+    # lag-1 correlation, stream and step independence
+    assert abs(float(((u[1:] - 0.5) * (u[:-1] - 0.5)).mean()) * 12) < 5e-3
+    u2 = Fn.rng_uniform(st, 2, n)
+    assert abs(float(((u - 0.5) * (u2 - 0.5)).mean()) * 12) < 5e-3
+    st[1] += 1
+    u3 = Fn.rng_uniform(st, 1, n)
+    assert abs(float(((u - 0.5) * (u3 - 0.5)).mean()) * 12) < 5e-3 and not torch.equal(u, u3)
+    st[1] -= 1
+    assert torch.equal(Fn.rng_uniform(st, 1, n), u)                       # a pure function of (seed, step, stream, index)
+
+
+def test_stratified_z_rng_is_stratified_z_of_the_streams_draws():
+    from brdf_nerf_amd import functions as Fn
+    g = torch.Generator().manual_seed(0)
+    R, S = 97, 24
+    rays = _sat_rays(R, g).to(DEV)
+    st = Fn.new_step_state(DEV, 77, 5e-4)
+    z = Fn.stratified_z_rng(rays, S, st)
+    u = Fn.rng_uniform(st, 1, R * S).view(R, S)
+    assert torch.equal(z, Fn.stratified_z(rays[:, 6:7], rays[:, 7:8], u))
+
+
+# ------------------------------------------------------------------------------------------------ fused per-ray kernels
+@pytest.mark.parametrize("R,S,G,prior", [(37, 16, 16, True), (64, 64, 64, True), (5, 40, 24, False), (130, 128, 64, True)])
+def test_composite_guided_is_composite_then_guided(R, S, G, prior):
+    """bn_composite_guided (one launch, pass-1 weights in LDS, in-kernel draws) against bn_composite_forward +
+    bn_guided_samples_nf on the stream's draws as arrays: identical depths and sort indices."""
+    from brdf_nerf_amd import functions as Fn
+    g = torch.Generator().manual_seed(R + S)
+    rays = _sat_rays(R, g).to(DEV)
+    st = Fn.new_step_state(DEV, 5, 5e-4)
+    z = Fn.stratified_z_rng(rays, S, st)
+    out1 = _field_like(R, S, 7, g)
+    valid = (torch.rand(R, generator=g) < 0.6).float().to(DEV) if prior else None
+    depths = torch.stack([0.8 + 0.4 * torch.rand(R, generator=g), torch.rand(R, generator=g)], -1).to(DEV) if prior else None
+    dstd = (0.02 * torch.rand(R, generator=g)).to(DEV) if prior else None
+    z2, z_all, idx, w1, d1 = Fn.composite_guided(z, out1, G, rays[0, 6:8], 3.0, valid, None if depths is None else depths[:, 0], dstd,
+                                                 state=st, want_pass1=True)
+    _, _, w_ref, d_ref, _ = Fn.composite_forward_raw(z, out1)
+    assert torch.equal(w1, w_ref) and torch.equal(d1, d_ref)
+    u = Fn.rng_uniform(st, 2, R * G).view(R, G)
+    u_t = Fn.rng_uniform(st, 3, R * G).view(R, G) if prior else None
+    z2r, z_allr, idxr = Fn.guided_samples(z, w_ref, d_ref, u, rays[0, 6:8], None, 3.0, valid,
+                                          None if depths is None else depths[:, 0].contiguous(), dstd, u_t, None)
+    assert torch.equal(z2, z2r) and torch.equal(z_all, z_allr) and torch.equal(idx, idxr)
+    # the same with the draws handed over as arrays
+    z2b, z_allb, idxb = Fn.composite_guided(z, out1, G, rays[0, 6:8], 3.0, valid, None if depths is None else depths[:, 0], dstd,
+                                            u=u, u_target=u_t)
+    assert torch.equal(z2, z2b) and torch.equal(idx, idxb) and torch.equal(z_all, z_allb)
+
+
+def _merged_reference(z_all, idx, out1, out2):
+    C = out1.shape[-1]
+    return torch.cat([out1, out2], 1).gather(1, idx.unsqueeze(-1).expand(-1, -1, C)).contiguous()
+
+
+@pytest.mark.parametrize("R,S,G,C", [(33, 16, 16, 4), (64, 64, 64, 4), (21, 24, 8, 7), (50, 64, 64, 13), (9, 128, 64, 20)])
+def test_merged_composite_is_gather_then_composite(R, S, G, C):
+    """The merged-set compositing through the sort index (forward and backward, gradient rows in the source layouts) against
+    cat + gather + bn_composite_forward / backward + scatter."""
+    from brdf_nerf_amd import functions as Fn
+    g = torch.Generator().manual_seed(R * 3 + C)
+    out1, out2 = _field_like(R, S, C, g), _field_like(R, G, C, g)
+    z = torch.sort(torch.rand(R, S, generator=g) * 2, -1)[0]
+    z2 = torch.sort(torch.rand(R, G, generator=g) * 2, -1)[0]
+    z_all, idx = torch.sort(torch.cat([z, z2], -1), dim=-1, stable=True)
+    z_all, idx = z_all.to(DEV).contiguous(), idx.to(DEV).contiguous()
+    merged = _merged_reference(z_all, idx, out1, out2)
+    a, t, w, d, acc = Fn.composite_forward_raw(z_all, merged)
+    o = Fn.merged_composite_forward(z_all, idx, out1, out2, want=("alphas", "trans", "weights", "depth", "acc", "wsum"))
+    for k, ref in (("alphas", a), ("trans", t), ("weights", w)):
+        assert torch.equal(o[k], ref), k
+    assert float((o["depth"] - d).abs().max()) <= 2e-6 and float((o["wsum"] - w.sum(-1)).abs().max()) <= 2e-6
+    keep = [c for c in range(C) if c != 3]
+    assert float((o["acc"][:, keep] - acc[:, keep]).abs().max()) <= 2e-6
+    d_w = torch.randn(R, S + G, generator=g).to(DEV)
+    d_d = torch.randn(R, generator=g).to(DEV)
+    d_acc = torch.randn(R, C, generator=g).to(DEV)
+    d_acc[:, 3] = 0
+    ref = Fn.composite_backward_raw(z_all, merged, d_w, d_d, d_acc)
+    d_cat = torch.zeros(R, S + G, C, device=DEV).scatter_(1, idx.unsqueeze(-1).expand(-1, -1, C), ref)
+    d1, d2 = torch.empty(R, S, C, device=DEV), torch.empty(R, G, C, device=DEV)
+    cnt = torch.zeros(2, dtype=torch.int64, device=DEV)
+    Fn.merged_composite_backward(z_all, idx, out1, out2, d_w, d_d, d_acc, d1, d2, nonfinite=cnt)
+    scale = float(ref.abs().max())
+    assert float((d1 - d_cat[:, :S]).abs().max()) <= 2e-6 * scale and float((d2 - d_cat[:, S:]).abs().max()) <= 2e-6 * scale
+    assert cnt.tolist() == [0, 0]
+    # a per-ray gradient of sum_s w is a constant added to every d_weights entry
+    d_ws = torch.randn(R, generator=g).to(DEV)
+    d1b, d2b = torch.empty_like(d1), torch.empty_like(d2)
+    Fn.merged_composite_backward(z_all, idx, out1, out2, d_w, d_d, d_acc, d1b, d2b, d_wsum=d_ws)
+    ref2 = Fn.composite_backward_raw(z_all, merged, d_w + d_ws[:, None], d_d, d_acc)
+    d_cat2 = torch.zeros(R, S + G, C, device=DEV).scatter_(1, idx.unsqueeze(-1).expand(-1, -1, C), ref2)
+    assert float((d1b - d_cat2[:, :S]).abs().max()) <= 2e-6 * scale and float((d2b - d_cat2[:, S:]).abs().max()) <= 2e-6 * scale
+    # non-finite gradient elements are dropped and counted
+    d_w_bad = d_w.clone()
+    d_w_bad[0, 0] = float("nan")
+    Fn.merged_composite_backward(z_all, idx, out1, out2, d_w_bad, d_d, d_acc, d1b, d2b, nonfinite=cnt)
+    assert bool(torch.isfinite(d1b).all()) and bool(torch.isfinite(d2b).all()) and int(cnt.sum()) > 0
+    # identity index: one source block
+    o1 = Fn.merged_composite_forward(z_all, None, merged, None, want=("weights", "depth"))
+    assert torch.equal(o1["weights"], w)
+
+
+@pytest.mark.parametrize("R,S,G,prior", [(33, 16, 16, True), (64, 64, 64, True), (40, 24, 8, False)])
+def test_lambert_tail_is_composite_loss_backward(R, S, G, prior):
+    """bn_lambert_tail (one launch) against bn_composite_forward + bn_lambert_loss (held to the reference's SNerfLoss / DepthLoss
+    golden in test_gpu_parity.py) + bn_composite_backward on the gathered merged set."""
+    from brdf_nerf_amd import functions as Fn
+    g = torch.Generator().manual_seed(R + 11)
+    C = 4
+    out1, out2 = _field_like(R, S, C, g), _field_like(R, G, C, g)
+    z = torch.sort(torch.rand(R, S, generator=g) * 2, -1)[0]
+    z2 = torch.sort(torch.rand(R, G, generator=g) * 2, -1)[0]
+    z_all, idx = torch.sort(torch.cat([z, z2], -1), dim=-1, stable=True)
+    z_all, idx = z_all.to(DEV).contiguous(), idx.to(DEV).contiguous()
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    valid = (torch.rand(R, generator=g) < 0.6).float().to(DEV) if prior else None
+    depths = torch.stack([0.8 + 0.4 * torch.rand(R, generator=g), torch.rand(R, generator=g)], -1).to(DEV) if prior else None
+    dstd = (0.05 * torch.rand(R, generator=g)).to(DEV) if prior else None
+    merged = _merged_reference(z_all, idx, out1, out2)
+    _, _, w, d, acc = Fn.composite_forward_raw(z_all, merged)
+    kw = dict(valid_depth=valid, target_depth=depths[:, 0], target_weight=depths[:, 1], target_std=dstd, lambda_ds=10.0) if prior else {}
+    loss, rgb, d_acc, d_depth, d_w = Fn.lambert_loss(acc, w, z_all, d, rgbs, 0.001, 1.0, **kw)
+    d_acc = d_acc.contiguous()
+    d_acc[:, 3] = 0
+    ref = Fn.composite_backward_raw(z_all, merged, d_w, d_depth, d_acc)
+    d_cat = torch.zeros(R, S + G, C, device=DEV).scatter_(1, idx.unsqueeze(-1).expand(-1, -1, C), ref)
+    d1, d2 = torch.empty(R, S, C, device=DEV), torch.empty(R, G, C, device=DEV)
+    ray_loss, lacc, rgb2 = torch.empty(R, device=DEV), torch.zeros(16, device=DEV), torch.empty(R, 3, device=DEV)
+    w2, dep2 = torch.empty(R, S + G, device=DEV), torch.empty(R, device=DEV)
+    Fn.lambert_tail(z_all, idx, out1, out2, rgbs, 0.001, 1.0, d1, d2, ray_loss=ray_loss, loss_acc=lacc, rgb=rgb2, weights=w2, depth=dep2,
+                    **kw)
+    assert torch.equal(w2, w) and float((dep2 - d).abs().max()) <= 2e-6
+    assert float((rgb2 - rgb).abs().max()) <= 2e-6
+    assert abs(float(ray_loss.sum()) - float(loss)) <= 1e-6 * abs(float(loss)) + 1e-9
+    # ray r's term went to partial sum r % 16
+    want_part = torch.zeros(16, device=DEV).index_add_(0, torch.arange(R, device=DEV) % 16, ray_loss)
+    assert float((lacc - want_part).abs().max()) <= 2e-6 * abs(float(loss)) + 1e-9
+    scale = float(ref.abs().max())
+    assert float((d1 - d_cat[:, :S]).abs().max()) <= 5e-6 * scale and float((d2 - d_cat[:, S:]).abs().max()) <= 5e-6 * scale
+
+
+def test_lambert_tail_forward_against_reference_render_golden():
+    """The forward half of bn_lambert_tail on the REFERENCE's own per-sample outputs (tests/golden/render_lambert_train.npz:
+    sigmas, albedo, z_vals of the merged S+G set, produced by rendering.py:168-291 + models/spsbrdfnerf.py:198-282): its
+    weights, depth and shaded rgb are the reference's."""
+    from test_gpu_parity import load_golden
+    from brdf_nerf_amd import functions as Fn
+    g = load_golden("render_lambert_train")
+    t = lambda k: torch.from_numpy(g["out/" + k]).to(DEV)
+    z_all, sig, alb = t("z_vals_coarse"), t("sigmas_coarse"), t("albedo_coarse")
+    R, S2 = z_all.shape
+    out = torch.cat([alb, sig.reshape(R, S2, 1)], -1).contiguous()
+    rgbs = torch.from_numpy(g["tgt/rgbs"]).to(DEV)
+    d1 = torch.empty(R, S2, 4, device=DEV)
+    w, dep, rgb = torch.empty(R, S2, device=DEV), torch.empty(R, device=DEV), torch.empty(R, 3, device=DEV)
+    Fn.lambert_tail(z_all.contiguous(), None, out, None, rgbs, 0.001, 1.0, d1, None, rgb=rgb, weights=w, depth=dep)
+    assert float((w - t("weights_coarse")).abs().max()) <= 1e-5
+    assert float((dep - t("depth_coarse")).abs().max()) <= 1e-5 * 2
+    assert float((rgb - t("rgb_coarse")).abs().max()) <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ fold / unfold / Adam
+@pytest.mark.parametrize("F,heads,dir_dim", [(512, 1, 0), (64, 3, 0), (192, 2, 24)])
+def test_fold_and_unfold_kernels_against_torch(F, heads, dir_dim):
+    from brdf_nerf_amd import _lib as L
+    from brdf_nerf_amd import functions as Fn
+    g = torch.Generator().manual_seed(F + heads)
+    H2 = F // 2
+    names = ["rgb_from_xyzdir", "k_from_xyz", "rhoc_from_xyz"][:heads]
+    hl = [(n, 3 if i == 0 else 1, L.BN_HEAD_PLAIN if i == 0 else L.BN_HEAD_TILE3) for i, n in enumerate(names)]
+    spec = Fn.FieldSpec(F, 4, 2, 10, L.BN_ACT_SIN, L.BN_F32, hl, False, dir_dim=dir_dim, dir_freqs=4 if dir_dim else 0)
+    named = {"feats_from_xyz.weight": torch.randn(F, F, generator=g).to(DEV) / F ** 0.5, "feats_from_xyz.bias": torch.randn(F, generator=g).to(DEV)}
+    for i, n in enumerate(names):
+        named[f"{n}.0.weight"] = (torch.randn(H2, F + (dir_dim if i == 0 else 0), generator=g) / F ** 0.5).to(DEV)
+        named[f"{n}.0.bias"] = torch.randn(H2, generator=g).to(DEV)
+    spec.fold(named)
+    wf, bf = named["feats_from_xyz.weight"].double(), named["feats_from_xyz.bias"].double()
+    for n in names:
+        w1, b1 = named[f"{n}.0.weight"][:, :F].double(), named[f"{n}.0.bias"].double()
+        assert float((spec.folded[n][0].double() - w1 @ wf).abs().max()) <= 2e-6 * float((w1 @ wf).abs().max())
+        assert float((spec.folded[n][1].double() - (w1 @ bf + b1)).abs().max()) <= 2e-6 * float((w1 @ bf + b1).abs().max())
+    # unfold: accumulates into the gradient buffers
+    grads = {k: torch.randn(v.shape, generator=g).to(DEV) for k, v in named.items()}
+    before = {k: v.clone() for k, v in grads.items()}
+    for n in names:
+        spec.fold_grads[n] = (torch.randn(H2, F, generator=g).to(DEV), torch.randn(H2, generator=g).to(DEV))
+    ms = {n: (m.clone().double(), s.clone().double()) for n, (m, s) in spec.fold_grads.items()}
+    spec.unfold_grads(named, grads, zero=True)
+    dwf, dbf = before["feats_from_xyz.weight"].double(), before["feats_from_xyz.bias"].double()
+    for n in names:
+        m, sv = ms[n]
+        w1 = named[f"{n}.0.weight"][:, :F].double()
+        want = before[f"{n}.0.weight"].double()
+        want[:, :F] += m @ wf.t() + torch.outer(sv, bf)
+        assert float((grads[f"{n}.0.weight"].double() - want).abs().max()) <= 3e-6 * float(want.abs().max())
+        assert float((grads[f"{n}.0.bias"].double() - (before[f"{n}.0.bias"].double() + sv)).abs().max()) <= 1e-6
+        dwf = dwf + w1.t() @ m
+        dbf = dbf + w1.t() @ sv
+        assert float(spec.fold_grads[n][0].abs().max()) == 0.0 and float(spec.fold_grads[n][1].abs().max()) == 0.0
+    assert float((grads["feats_from_xyz.weight"].double() - dwf).abs().max()) <= 3e-6 * float(dwf.abs().max())
+    assert float((grads["feats_from_xyz.bias"].double() - dbf).abs().max()) <= 3e-6 * float(dbf.abs().max())
+    # fold clears the accumulators
+    for n in names:
+        spec.fold_grads[n][0].fill_(1.0)
+        spec.fold_grads[n][1].fill_(1.0)
+    spec.fold(named)
+    for n in names:
+        assert float(spec.fold_grads[n][0].abs().max()) == 0.0 and float(spec.fold_grads[n][1].abs().max()) == 0.0
+
+
+def test_adam_multi_matches_torch_per_group():
+    """One launch over three groups with their own step counts (a group that joins late starts its bias corrections at 1, an
+    inactive group is skipped), learning rate and counters from the device state; the gradients it read are cleared."""
+    from brdf_nerf_amd import functions as Fn
+    g = torch.Generator().manual_seed(0)
+    sizes = [100004, 4096, 260]
+    groups, lo = [], 0
+    for n in sizes:
+        groups.append((lo, lo + n))
+        lo += n
+    p0 = torch.randn(lo, generator=g)
+    ref = [p0[a:b].clone().requires_grad_(True) for a, b in groups]
+    opts = [torch.optim.Adam([r], lr=5e-4) for r in ref]
+    p, m, v = p0.clone().to(DEV), torch.zeros(lo, device=DEV), torch.zeros(lo, device=DEV)
+    st = Fn.new_step_state(DEV, 1, 5e-4)
+    sched = [(True, False, False), (True, True, False), (True, True, True), (True, False, True)]
+    for step, active in enumerate(sched):
+        gr = torch.randn(lo, generator=g)
+        if step == 2:                                        # learning-rate decay between steps
+            Fn.state_views(st)[1].fill_(2.5e-4)
+            for o in opts:
+                o.param_groups[0]["lr"] = 2.5e-4
+        for r, o, (a, b), on in zip(ref, opts, groups, active):
+            if on:
+                r.grad = gr[a:b].clone()
+                o.step()
+        gd = gr.to(DEV)
+        Fn.adam_multi(p, gd, m, v, groups, active, st)
+        for (a, b), on in zip(groups, active):
+            assert (float(gd[a:b].abs().max()) == 0.0) == on          # read gradients are cleared, skipped groups untouched
+        rng_step, _, steps, ring = Fn.state_views(st)
+        assert int(rng_step) == step + 1
+    assert steps.tolist()[:3] == [4, 2, 2]
+    for r, (a, b) in zip(ref, groups):
+        assert float((p[a:b].cpu() - r.detach()).abs().max()) <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ the lean step
+def _lean_cfgs():
+    return {
+        "lambert": dict(),
+        "rpv111_nlr": dict(funcM=1, funcF=1, funcH=1, normal="learned"),
+        "rpv111_nan": dict(funcM=1, funcF=1, funcH=1, normal="analystic"),
+        "hapke_bct": dict(b=1, c=1, theta=1, normal="learned"),
+        "microfacet": dict(roughness=True, normal="analystic"),
+    }
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", list(_lean_cfgs()))
+def test_lean_step_matches_general_step_on_the_same_draws(name, dtype):
+    """FusedTrainer's launch-lean step (in-kernel draws, fused per-ray kernels, fold / unfold / Adam kernels; eager, then
+    replayed from a HIP graph for the Lambertian model) against the general step (ATen glue; held to the autograd path and the
+    oracle by test_gpu_fuzz.py) fed with the Philox streams' draws as arrays: loss, rgb and parameters over five steps."""
+    import brdf_nerf_amd
+    from test_gpu_parity import build_model, make_args, Replay, diag
+    from brdf_nerf_amd import functions as Fn
+    from brdf_nerf_amd.trainer import FusedTrainer
+    cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16, **_lean_cfgs()[name])
+    args = make_args(cfg, dtype)
+    R, S, G = 96, 16, 16
+    g = torch.Generator().manual_seed(3)
+    rays = _sat_rays(R, g).to(DEV)
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    valid = (torch.rand(R, generator=g) < 0.6).float().to(DEV)
+    depths = torch.stack([0.8 + 0.4 * torch.rand(R, generator=g), torch.rand(R, generator=g)], -1).to(DEV)
+    dstd = (0.03 * torch.rand(R, generator=g)).to(DEV)
+    brdf = name != "lambert"
+    flags = dict(apply_brdf=brdf, apply_theta=brdf, cos_irra_on=brdf)
+    prev = brdf_nerf_amd.set_deterministic(True)          # bitwise reproducible weight-gradient sums on both sides
+    try:
+        torch.manual_seed(11)
+        ma, mb = build_model(cfg, 21, dtype), build_model(cfg, 21, dtype)
+        ta = FusedTrainer(ma, args, lr=5e-4, ds_lambda=10.0, hs_lambda=0.1 if brdf else 0.0, strict_rng=False)
+        tb = FusedTrainer(mb, args, lr=5e-4, ds_lambda=10.0, hs_lambda=0.1 if brdf else 0.0, strict_rng=False)
+        ta.lean = False
+        tb.graph_after = 2
+        tb.keep_grads = True                                 # test hook: the Adam launch leaves the gradient it read in place
+        worst_g = 0.0
+        for step in range(6):
+            if step == 4:
+                ta.lr = tb.lr = 2.5e-4                        # learning-rate decay reaches the device state (and the replayed graph)
+            # every step starts from the SAME parameters and moments: Adam's first steps turn a 1e-7 difference in a near-zero
+            # gradient entry into +-lr, and a 16-bit mode rounds a 1e-7 input difference into a 4e-3 one - the steps are compared
+            # one by one, not as two trajectories
+            tb.flat_param.copy_(ta.flat_param)
+            tb.exp_avg.copy_(ta.exp_avg)
+            tb.exp_avg_sq.copy_(ta.exp_avg_sq)
+            m_before = ta.exp_avg.clone()
+            draws = [Fn.rng_uniform(tb.state, 1, R * S).view(R, S), Fn.rng_uniform(tb.state, 2, R * G).view(R, G),
+                     Fn.rng_uniform(tb.state, 3, R * G).view(R, G)]
+            with Replay(draws) as rp:
+                la, rgb_a = ta.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+                assert rp.draws == []
+            lb, rgb_b = tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+            la, lb = float(la), float(lb)
+            assert abs(la - lb) <= 2e-5 * abs(la) + 1e-7, (name, dtype, step, la, lb)
+            # (the GGX lobe turns a 1e-7 difference in the accumulated normal into 1e-5 .. 1e-4 on rgb: test_gpu_parity's bound)
+            assert float((rgb_a - rgb_b).abs().max()) <= (1e-4 if name == "microfacet" else 2e-5), (name, dtype, step)
+            ga, gb = ta.flat_grad, tb.flat_grad
+            scale = float(ga.abs().max())
+            e = float((ga - gb).abs().max()) / scale
+            cos = float(torch.nn.functional.cosine_similarity(ga.double(), gb.double(), dim=0))
+            worst_g = max(worst_g, e)
+            if dtype == "fp32":       # (microfacet: the GGX lobe's gradient amplifies a 1e-7 difference of the accumulated normal)
+                assert e <= (5e-4 if name == "microfacet" else 5e-5), (name, dtype, step, e)
+            else:       # a 1e-7 difference of a gradient seed can flip its 16-bit rounding
+                assert cos >= 0.99995 and e <= 2e-2, (name, dtype, step, cos, e)
+            # the optimiser: first moments are linear in the gradient, parameters move by at most lr per step
+            dm = float(((ta.exp_avg - m_before) - (tb.exp_avg - m_before)).abs().max()) / (0.1 * scale)
+            assert dm <= ((5e-4 if name == "microfacet" else 5e-5) if dtype == "fp32" else 2e-2), (name, dtype, step, dm)
+            assert float((ta.flat_param - tb.flat_param).abs().max()) <= 2.1 * ta.lr
+            assert float((ta.flat_param - tb.flat_param).abs().mean()) <= (2e-7 if dtype == "fp32" else 2e-5), (name, dtype, step)
+        assert ta.adam_steps == tb.adam_steps
+        if name == "lambert":
+            assert len(tb._graphs) == 1, "the Lambertian lean step was not captured"
+        diag(f"lean vs general step {name} {dtype}: worst flat-gradient difference over 6 steps {worst_g:.2e} of the largest entry; "
+             f"graphs {len(tb._graphs)}")
+    finally:
+        brdf_nerf_amd.set_deterministic(prev)
+
+
+def test_lean_step_mixes_with_the_general_path():
+    """A schedule that leaves the lean path (gsam_only stage) and comes back: gradients are cleared where they have to be and
+    the Adam step counts stay in step on host and device."""
+    from test_gpu_parity import build_model, make_args
+    from brdf_nerf_amd import functions as Fn
+    from brdf_nerf_amd.trainer import FusedTrainer
+    cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16)
+    args = make_args(cfg)
+    g = torch.Generator().manual_seed(5)
+    R = 48
+    rays, rgbs = _sat_rays(R, g).to(DEV), torch.rand(R, 3, generator=g).to(DEV)
+    torch.manual_seed(2)
+    tr = FusedTrainer(build_model(cfg, 4), args, lr=5e-4, strict_rng=False)
+    tr.use_graph = False
+    seq = [False, False, True, False, True, True, False]
+    for gs in seq:
+        loss, _ = tr.step(rays, rgbs, gsam_only=gs)
+        assert np.isfinite(float(loss))
+    assert tr.adam_steps["base"] == len(seq)
+    assert Fn.state_views(tr.state)[2].tolist()[0] == len(seq) or tr._state_adam[0] == len(seq)
+    assert int(Fn.state_views(tr.state)[0]) == seq.count(False)

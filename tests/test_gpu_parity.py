@@ -131,7 +131,7 @@ def compare_render(res, g, tag, ray_tol=(1e-4, 2e-5), other_tol=(1e-3, 2e-4)):
 # ------------------------------------------------------------------------------------------------ C ABI smoke
 def test_library_loads_on_gpu():
     from brdf_nerf_amd import _lib
-    assert _lib.lib().bn_abi_version() == 3
+    assert _lib.lib().bn_abi_version() == 4
 
 
 def test_device_fault_word_stays_clear():
@@ -624,6 +624,49 @@ def test_render_rays_golden_fp32(name, mode):
             # end-to-end (two passes + resampling): 5e-3 of the largest entry; the field backward alone, with identical
             # inputs, is held to 2e-4 (test_field_backward_oracle_fp32)
             assert err <= 5e-3 * scale + 1e-9, f"{k}: err {err:.3e} scale {scale:.3e}"
+
+
+BRANCHES = {   # round 3: branches of inference() that no fixture reached before (tests/golden/make_goldens.py gen_branches)
+    "rpv_m1f1h2": (dict(funcM=1, funcF=1, funcH=2, normal="learned"), dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    "rpv_m1f1h2_multibrdf": (dict(funcM=1, funcF=1, funcH=2, normal="learned", MultiBRDF=True),
+                             dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    "rpv_m1h2": (dict(funcM=1, funcH=2, normal="learned"), dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    "shell1_nobrdf": (dict(shell_hapke=1, normal="learned"), dict(apply_brdf=False, apply_theta=False, cos_irra_on=False)),
+    "shell2_nobrdf": (dict(shell_hapke=2, normal="learned"), dict(apply_brdf=False, apply_theta=False, cos_irra_on=True)),
+    "shell3_nobrdf": (dict(shell_hapke=3, normal="learned"), dict(apply_brdf=False, apply_theta=False, cos_irra_on=True)),
+    "shell3_brdf": (dict(shell_hapke=3, normal="learned"), dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+}
+
+
+@pytest.mark.parametrize("name", list(BRANCHES))
+def test_render_rays_unpinned_branches_golden_fp32(name):
+    """funcH == 2 (rhoc := albedo; models/spsbrdfnerf.py:306,317) per ray and per sample, and shell_hapke in {1, 2, 3} with
+    apply_brdf=False (:320,348,383): render_rays against the reference's outputs, key set included."""
+    from brdf_nerf_amd import render_rays
+    g = load_golden(f"render_{name}_test")
+    kw, flags = BRANCHES[name]
+    cfg = mini(**kw)
+    model = build_model(cfg, 11)
+    with torch.no_grad(), Replay(replay_list(g)) as rp:
+        res, brdf_type = render_rays({"coarse": model}, make_args(cfg), torch.from_numpy(g["rays"]).to(DEV), None, mode="test", **flags)
+        assert rp.draws == []
+    assert brdf_type == str(g["brdf_type"])
+    assert {k[4:] for k in g if k.startswith("out/")} == set(res)
+    compare_render(res, g, f"render_{name}_test", ray_tol=(1e-4, 4e-5) if name.startswith("shell") else (1e-4, 2e-5))
+
+
+def test_render_rays_ref_sphere_golden():
+    """rows / cols -> ref_sphere (models/spsbrdfnerf.py:404-412), bit for bit, with the reference's tiling order."""
+    from brdf_nerf_amd import render_rays
+    g = load_golden("render_rpv111_nlr_refsphere_test")
+    cfg = mini(**CONFIGS["rpv111_nlr"])
+    model = build_model(cfg, 11)
+    with torch.no_grad(), Replay(replay_list(g)):
+        res, _ = render_rays({"coarse": model}, make_args(cfg), torch.from_numpy(g["rays"]).to(DEV), None, mode="test", apply_brdf=True,
+                             apply_theta=True, cos_irra_on=True, rows=torch.from_numpy(g["rows"]).to(DEV), cols=torch.from_numpy(g["cols"]).to(DEV))
+    assert {k[4:] for k in g if k.startswith("out/")} == set(res)
+    assert np.array_equal(res["ref_sphere_coarse"].cpu().numpy(), g["out/ref_sphere_coarse"])
+    compare_render(res, g, "render_refsphere_test")
 
 
 def test_render_blender_rays_golden():
@@ -1633,8 +1676,12 @@ def test_train_loop_trajectory_against_oracle(name):
     loop.table.next_batch = lambda *x, **kw: (batches.append(nb(*x, **kw)) or batches[-1])
     gen = torch.Generator().manual_seed(9)
     got, want = [], []
+    from brdf_nerf_amd import functions as Fn
     for i in range(K):
-        uz, ug, ut = torch.rand(R, S, generator=gen), torch.rand(R, G, generator=gen), torch.rand(R, G, generator=gen)
+        # the launch-lean step draws in its kernels: the same Philox streams, as arrays, for the oracle (a step that leaves the
+        # lean path would take them through torch.rand instead)
+        st = loop.trainer.state
+        uz, ug, ut = [Fn.rng_uniform(st, sid, R * n).view(R, n).cpu() for sid, n in ((1, S), (2, G), (3, G))]
         with Replay([uz, ug, ut]):
             out = loop.step()
         got.append(float(out["loss"]))
@@ -1709,17 +1756,86 @@ def test_full_size_render_and_train_step_properties(name):
     for k, v in res.items():
         if v.dtype.is_floating_point and k != "hpk_scl_coarse":
             assert bool(torch.isfinite(v).all()), k
+    # ---- the training step at full size (round 3): (1) the 16-bit flat gradient against the fp32 HIP mode on the same batch and
+    # the same in-kernel draws, per parameter matrix; (2) 24 steps on a LEARNABLE table (one consistent scene: colours and depth
+    # priors of a height field) - the loss has to go down
+    tb = _learnable_table(R, 21)
+    lb = {k: tb.data[k] for k in ("rays", "rgbs", "valid_depth", "depths", "depth_std")}
+    step_kw = dict(valid_depth=lb["valid_depth"], depths=lb["depths"], depth_std=lb["depth_std"], near_far=(0.0, 2.0), **flags)
+    grads = {}
+    t16 = torch.bfloat16 if dtype == "bf16" else torch.float16
+    lambert = name.startswith("c2_")
+    start = None
+    if not lambert:
+        # The BRDF models are compared at a TRAINED geometry: 150 Lambertian-stage steps on the learnable table first (the
+        # reference's stage 1, README.md:100-116) - at a random initialisation the analytic normals of an untrained density and
+        # the rays at grazing angles make the BRDF-stage gradient a near-cancelling sum that fp32 itself does not reproduce
+        # under a 2^-9 perturbation of the weights
+        torch.manual_seed(0)
+        m0 = load_model(args).to(DEV)
+        torch.manual_seed(5)
+        t0 = FusedTrainer(m0, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+        pre_kw = dict(step_kw, apply_brdf=False, apply_theta=False, cos_irra_on=False)
+        for _ in range(150):
+            t0.step(lb["rays"], lb["rgbs"], **pre_kw)
+        start = {k: v.detach().clone() for k, v in m0.state_dict().items()}
+        del t0, m0
+    for tag, dt, round_w in (("fp32", "fp32", False), (dtype, dtype, False), ("fp32_w16", "fp32", True)):
+        if tag == "fp32_w16" and lambert:
+            continue
+        torch.manual_seed(0)
+        m = load_model(make_args(cfg, dt)).to(DEV)
+        if start is not None:
+            m.load_state_dict(start)
+        if round_w:                                            # the referee: fp32 arithmetic on weights rounded to the 16-bit type
+            with torch.no_grad():
+                for p_ in m.parameters():
+                    p_.copy_(p_.to(t16).float())
+        torch.manual_seed(7)                                   # seeds the step state's draw key: the same draws in every run
+        t = FusedTrainer(m, make_args(cfg, dt), lr=5e-4, ds_lambda=10.0, strict_rng=False)
+        t.keep_grads = True
+        t.step(lb["rays"], lb["rgbs"], **step_kw)
+        assert bool(torch.isfinite(t.flat_grad).all()), f"{tag}: non-finite gradient"
+        grads[tag] = {k: v.clone() for k, v in t.grad_views.items()}
+        dropped = t.dropped_samples
+        del t, m
+
+    def worst_cos(a, b):
+        worst, worst_k = 1.0, ""
+        for k, g32 in grads[a].items():
+            if g32.numel() < 256 or float(g32.abs().max()) == 0.0:
+                continue
+            c = float(torch.nn.functional.cosine_similarity(g32.flatten().double(), grads[b][k].flatten().double(), dim=0))
+            if c < worst:
+                worst, worst_k = c, k
+        return worst, worst_k
+
+    worst, worst_k = worst_cos("fp32", dtype)
+    if lambert:
+        # Lambertian model: every matrix of the 16-bit gradient points where the fp32 HIP mode's does
+        diag(f"full size {name} ({dtype}): worst per-matrix gradient cosine vs the fp32 HIP mode {worst:.5f} ({worst_k}), dropped {dropped}")
+        assert worst >= 0.99, (worst, worst_k)
+    else:
+        # BRDF on a RANDOM model: the loss gradient is a near-cancelling sum over rays at grazing angles / GGX peaks and over
+        # normals of an untrained density - ill-conditioned in the WEIGHTS already.  The referee is the fp32 HIP mode evaluated on
+        # weights rounded to the 16-bit type (fp32 arithmetic throughout): the 16-bit mode must track fp32 about as well as that
+        # does - what is left when the conditioning of the problem is taken out
+        ref, ref_k = worst_cos("fp32", "fp32_w16")
+        diag(f"full size {name} ({dtype}): worst per-matrix gradient cosine vs the fp32 HIP mode {worst:.5f} ({worst_k}); the fp32 mode on "
+             f"{dtype}-rounded weights: {ref:.5f} ({ref_k}); dropped {dropped}")
+        # (measured, profiles/r03_parity_errors.txt: the referee itself scatters between -0.99 and 0.997 over these configurations -
+        # a sign flip of the roughness head's bias gradient included - i.e. the BRDF-stage gradient at this state is not
+        # reproducible to 2^-9 in the weights; where it is well conditioned, hapke + theta, the 16-bit modes reach 0.94-0.95)
+        # -> asserted where the referee says the comparison means something (it reproduces fp32 to 0.9 itself); reported otherwise
+        assert ref < 0.9 or worst >= min(0.99, ref - 0.25 * (1.0 - ref) - 0.02) or worst >= 0.9, (worst, worst_k, ref, ref_k)
+    torch.manual_seed(3)
     tr = FusedTrainer(model, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
-    losses_ = []
-    for i in range(8):
-        loss, _ = tr.step(b["rays"], b["rgbs"], valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"],
-                          near_far=(0.0, 2.0), **flags)
-        assert bool(torch.isfinite(tr.flat_grad).all()), f"step {i}: non-finite gradient"
-        assert float(tr.flat_grad.abs().max()) > 0.0, f"step {i}: all-zero gradient"
-        losses_.append(float(loss))
-    # Adam's first steps move every weight by lr whatever the gradient: the loss may spike before it settles
-    assert all(l == l for l in losses_) and losses_[-1] < max(losses_[:3]), losses_
-    diag(f"full size {name} ({dtype}): losses {losses_[0]:.4f} -> {losses_[-1]:.4f}, dropped samples {int(tr.dropped_samples)}")
+    losses_ = [float(tr.step(lb["rays"], lb["rgbs"], **step_kw)[0]) for _ in range(24)]
+    assert all(l == l for l in losses_), losses_
+    diag(f"full size {name} ({dtype}): learnable-table losses {losses_[0]:.4f} {losses_[1]:.4f} .. {losses_[-2]:.4f} {losses_[-1]:.4f}, "
+         f"dropped samples {int(tr.dropped_samples)}")
+    # (Adam's first steps move every weight by lr whatever the gradient: the first losses may spike; the last ones are below them)
+    assert max(losses_[-3:]) < min(losses_[:3]), losses_
 
 
 def _learnable_table(n_rays, seed):
@@ -1869,15 +1985,24 @@ def test_reduced_precision_heldout_psnr_tracks_fp32_rpv_analytic_normals():
     _ = statistics
 
 
-@pytest.mark.parametrize("name", ["lambert", "rpv_nan"])
-def test_two_rank_step_matches_one_rank(name):
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
+@pytest.mark.parametrize("name,lean", [("lambert", "1"), ("rpv_nan", "1"), ("lambert", "0")])
+def test_two_rank_step_matches_one_rank(name, lean):
     """ray-batch data parallelism.  Two ranks (both on cuda:0, gloo - the one-GPU box has no second device for
     RCCL) each run FusedTrainer.step on half of a batch; the all-reduced flat gradient / 2 and the parameters after Adam
-    must equal a one-rank step on the concatenated batch (tests/dist_step_worker.py)."""
+    must equal a one-rank step on the concatenated batch (tests/dist_step_worker.py).  lean = 1: the launch-lean step, whose
+    in-kernel draws are indexed by the GLOBAL ray (FusedTrainer.ray_offset); lean = 0: the general step fed with slices of the
+    whole batch's draws."""
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_step_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2", BN_DIST_CONFIG=name,
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="2", BN_DIST_CONFIG=name, BN_DIST_LEAN=lean,
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, worker], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
@@ -1902,7 +2027,7 @@ def test_rccl_initialises_and_reduces_the_flat_gradient():
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_step_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", WORLD_SIZE="1", RANK="0", BN_DIST_CONFIG="lambert",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="1", RANK="0", BN_DIST_CONFIG="lambert",
                BN_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     for line in p.stdout.splitlines():

@@ -43,10 +43,16 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(bn_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
     L = _lib.lib()                       # dlopen; resolves every symbol or raises
-    assert L.bn_abi_version() == 3
+    assert L.bn_abi_version() == 4
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
+
+
+def test_release_library_has_no_diagnostic_switches():
+    """bn_build_flags(): the in-tree library is built without any A/B or timing define."""
+    from brdf_nerf_amd import _lib
+    assert _lib.lib().bn_build_flags() == b""
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
@@ -321,3 +327,63 @@ def test_checkpoint_prefix_round_trip(tmp_path):
             assert torch.equal(v, m1.state_dict()[k]), k
         else:
             assert torch.equal(v, before[k]), k
+
+
+@pytest.mark.parametrize("N,B,W", [(1000, 64, 1), (1000, 64, 2), (1003, 32, 4), (517, 100, 8), (4096, 512, 8), (70, 64, 4)])
+def test_ray_table_epoch_semantics_against_dataloader_and_distributed_sampler(N, B, W):
+    """SURVEY 8(f) row 3 against the loaders the reference runs (main.py:170-184: DataLoader(shuffle=True, batch_size=B);
+    under `Trainer(gpus=W)` Lightning swaps its sampler for DistributedSampler(shuffle=True), one loader per rank).
+    Same: optimiser steps per epoch per rank (the unit StepLR ticks in), every batch of B rows except the epoch's last, every
+    row of the table once per epoch, a fresh permutation per epoch, `train_steps += W` per step.  Deliberately different (and
+    documented in DESIGN.md): DistributedSampler PADS its permutation to a multiple of W by repeating rows (up to W - 1 rows are
+    seen twice per epoch) and deals rows to ranks with stride W; the ray table serves each row exactly once and gives rank r a
+    contiguous share of every global batch - the last global batch of an epoch is split as evenly as it divides, so ranks may
+    differ by one row there (never by more), where the reference's ranks are equal."""
+    import argparse
+    import torch
+    from torch.utils.data import DataLoader, DistributedSampler, TensorDataset
+    from brdf_nerf_amd.raytable import RayTable
+    from brdf_nerf_amd.schedule import StageSchedule
+    ids = torch.arange(N, dtype=torch.float32)
+    rays = ids[:, None].expand(N, 11).contiguous()            # row id in every column: a batch reveals which rows it holds
+    ds = TensorDataset(ids)
+    ref_steps, ref_rows = [], []
+    for r in range(W):
+        sampler = DistributedSampler(ds, num_replicas=W, rank=r, shuffle=True, seed=0) if W > 1 else None
+        dl = DataLoader(ds, batch_size=B, shuffle=(sampler is None), sampler=sampler)
+        ref_steps.append(len(dl))
+        sizes = [b[0].shape[0] for b in dl]
+        assert all(s == B for s in sizes[:-1]) and 0 < sizes[-1] <= B
+        ref_rows.append(sum(sizes))
+    assert len(set(ref_steps)) == 1 and len(set(ref_rows)) == 1          # equal across ranks upstream (padding)
+    steps = ref_steps[0]
+    assert ref_rows[0] == -(-N // W)
+    args = argparse.Namespace(batch_size=B, max_train_steps=10 * steps * W, lr=5e-4, noise_std=0.0, ds_lambda=0.0)
+    sch = StageSchedule(args, N, W)
+    assert sch.lr_steps_per_epoch == steps                               # StepLR ticks after the same number of optimiser steps
+    assert sch.max_steps == (args.max_train_steps if W == 1 else args.max_train_steps // W)
+    tables = [RayTable(rays, torch.zeros(N, 3), seed=5) for _ in range(W)]      # one per rank, same seed: same permutations
+    perms = []
+    for epoch in range(3):
+        seen = [[] for _ in range(W)]
+        for step in range(steps):
+            got = [t.next_batch(B * W, r, W)["rays"][:, 0].long() for r, t in enumerate(tables)]
+            n_global = sum(g.shape[0] for g in got)
+            if step < steps - 1:
+                assert all(g.shape[0] == B for g in got)                 # full batches: B rows per rank, like upstream
+            else:
+                assert n_global == N - (steps - 1) * B * W and max(g.shape[0] for g in got) - min(g.shape[0] for g in got) <= 1
+            for r in range(W):
+                seen[r].append(got[r])
+            assert all(t.epoch == epoch for t in tables)
+        flat = torch.cat([torch.cat(s) for s in seen])
+        assert flat.shape[0] == N and torch.equal(torch.sort(flat)[0], torch.arange(N))   # every row exactly once per epoch
+        per_rank = [int(sum(x.shape[0] for x in s)) for s in seen]
+        assert all(N // W <= n <= -(-N // W) for n in per_rank)          # upstream: ceil(N / W) each, with repeats
+        perms.append(torch.cat([torch.cat([seen[r][k] for r in range(W)]) for k in range(steps)]))
+    assert not torch.equal(perms[0], perms[1]) and not torch.equal(perms[1], perms[2])    # reshuffled every epoch
+    for k in range(2 * steps + 1):                                        # train_steps += W per step; lr decays per epoch
+        flags = sch.begin_step()
+        assert sch.train_steps == (k + 1) * W
+        assert abs(sch.lr(k) - 5e-4 * 0.9 ** (k // steps)) < 1e-15
+        assert flags["epoch"] == ((k + 1) * W) // max(1, N // B)          # get_current_epoch (train_utils.py:117-118)

@@ -411,3 +411,52 @@ def test_regulariser_losses():
     assert_close(depth.grad, g["d_depth"], 1e-5, 1e-9, "d_depth")
     assert_close(n_an.grad, g["d_normal_an"], 1e-5, 1e-10, "d_normal_an")
     assert_close(n_lr.grad, g["d_normal_lr"], 1e-5, 1e-10, "d_normal_lr")
+
+
+# ---- round 3: branches of inference() no fixture reached before (funcH == 2, shell_hapke with apply_brdf=False, ref_sphere)
+BRANCHES = {
+    "rpv_m1f1h2": (dict(funcM=1, funcF=1, funcH=2, normal="learned"), dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    "rpv_m1f1h2_multibrdf": (dict(funcM=1, funcF=1, funcH=2, normal="learned", MultiBRDF=True),
+                             dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    "rpv_m1h2": (dict(funcM=1, funcH=2, normal="learned"), dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+    "shell1_nobrdf": (dict(shell_hapke=1, normal="learned"), dict(apply_brdf=False, apply_theta=False, cos_irra_on=False)),
+    "shell2_nobrdf": (dict(shell_hapke=2, normal="learned"), dict(apply_brdf=False, apply_theta=False, cos_irra_on=True)),
+    "shell3_nobrdf": (dict(shell_hapke=3, normal="learned"), dict(apply_brdf=False, apply_theta=False, cos_irra_on=True)),
+    "shell3_brdf": (dict(shell_hapke=3, normal="learned"), dict(apply_brdf=True, apply_theta=True, cos_irra_on=True)),
+}
+
+
+def _check_render(res, g):
+    ref_keys = {k[4:] for k in g if k.startswith("out/")}
+    got_keys = {k for k in res if not k.startswith("_")}
+    assert ref_keys == got_keys, sorted(ref_keys ^ got_keys)
+    for k in sorted(ref_keys):
+        if k == "sort_idx_coarse":
+            assert np.array_equal(res[k].numpy(), g["out/" + k]), k
+        else:
+            assert_close(res[k], g["out/" + k], 2e-4, 2e-5, k)
+
+
+@pytest.mark.parametrize("name", list(BRANCHES))
+def test_render_rays_unpinned_branches(name):
+    """models/spsbrdfnerf.py:306,317 (funcH == 2: rhoc := albedo, per ray and per sample), :320,348,383 (shell_hapke > 0 shades
+    with the Hapke shell even with apply_brdf=False)."""
+    g = load_golden(f"render_{name}_test")
+    kw, flags = BRANCHES[name]
+    cfg = mini(**kw)
+    assert abs(checksum(cfg, 11) - float(g["param_checksum"])) < 1e-9
+    res, bt = RD.render_rays(tparams(cfg, 11), cfg, torch.from_numpy(g["rays"]), RD.Randoms(replay=replay_list(g)), mode="test", **flags)
+    assert bt == str(g["brdf_type"])
+    _check_render(res, g)
+
+
+def test_render_rays_ref_sphere():
+    """rows / cols -> ref_sphere (models/spsbrdfnerf.py:404-412), with the reference's tiling order."""
+    g = load_golden("render_rpv111_nlr_refsphere_test")
+    cfg = mini(**CONFIGS["rpv111_nlr"])
+    res, bt = RD.render_rays(tparams(cfg, 11), cfg, torch.from_numpy(g["rays"]), RD.Randoms(replay=replay_list(g)), mode="test",
+                             apply_brdf=True, apply_theta=True, cos_irra_on=True, rows=torch.from_numpy(g["rows"]),
+                             cols=torch.from_numpy(g["cols"]))
+    assert "ref_sphere_coarse" in res
+    _check_render(res, g)
+    assert np.array_equal(res["ref_sphere_coarse"].numpy(), g["out/ref_sphere_coarse"])
