@@ -47,7 +47,8 @@ class FieldGrads(C.Structure):      # the same members, writable, + the gradient
 
 class Points(C.Structure):
     _fields_ = [("xyz", fptr), ("rays", fptr), ("z", fptr), ("ray_stride", C.c_int32), ("n_samples", C.c_int32),
-                ("n_points", C.c_int64), ("dirs", fptr), ("t_embed", fptr)]
+                ("n_points", C.c_int64), ("dirs", fptr), ("t_embed", fptr), ("point_offset", C.c_int64), ("total_points", C.c_int64),
+                ("z2", fptr), ("n_samples2", C.c_int32), ("seg1_points", C.c_int64)]
 
 
 class FoldDesc(C.Structure):          # bn_fold_desc

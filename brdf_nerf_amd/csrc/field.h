@@ -222,3 +222,26 @@ static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, in
   }
   s->total = off;
 }
+
+// Layout of a forward / normals call that writes points [off, off + n) of a larger set's stash: the set's layout with every
+// per-point array advanced by `off` points (off a multiple of the tile: the native tile images advance by whole tiles).
+static inline void bn_stash_layout_at(const FieldGeom &g, const bn_points *pts, int BM, size_t esz, StashLayout *s) {
+  const int64_t total = pts->total_points > 0 ? pts->total_points : pts->n_points;
+  bn_make_stash_layout(g, total, BM, esz, s);
+  const size_t off = (size_t)pts->point_offset;
+  if (off == 0) return;
+  const size_t dsz = esz == 4 ? 4 : 1, F = (size_t)g.F;
+  s->sraw += off * 4; s->nraw += off * 16; s->dpre_trunk += off * 16; s->dpre_head += off * BN_DPH * 4;
+  s->pe += off * g.KP * esz;
+  if (g.KD > 0) s->dirpe += off * g.KD * esz;
+  for (int l = 0; l < g.L; ++l) { s->Y[l] += off * F * esz; s->D[l] += off * F * dsz; s->dZ[l] += off * F * esz; }
+  s->feats += off * F * esz; s->dfeats += off * F * esz;
+  for (int p = 0; p < g.n_pass; ++p) { s->G[p] += off * F * esz; s->DG[p] += off * F * dsz; s->dG[p] += off * g.pass_N[p] * esz; }
+  if (g.ch_normal_an >= 0) {
+    s->gradx += off * 16; s->sbar += off * 4; s->sprime += off * 4; s->gbar_pe += off * g.KP * esz;
+    for (int l = 0; l < g.L; ++l) {
+      s->adj_delta[l] += off * F * esz; s->adj_a[l] += off * F * esz; s->adj_abar[l + 1] += off * F * esz; s->adj_zbar[l] += off * F * esz;
+    }
+  }
+  s->Mpad = ceil_div64(pts->n_points, BM) * BM;     // rows this call walks
+}

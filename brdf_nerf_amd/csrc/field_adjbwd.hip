@@ -72,8 +72,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       if (A.pts.xyz) {
         x[0] = A.pts.xyz[gm * 3]; x[1] = A.pts.xyz[gm * 3 + 1]; x[2] = A.pts.xyz[gm * 3 + 2];
       } else {
-        const float *rr = A.pts.rays + (gm / A.pts.n_samples) * A.pts.ray_stride;
-        const float zz = A.pts.z[gm];
+        // (a set of two sample blocks of the same rays: bn_points.seg1_points)
+        const bool second = A.pts.seg1_points > 0 && gm >= A.pts.seg1_points;
+        const int64_t gl = second ? gm - A.pts.seg1_points : gm;
+        const float *rr = A.pts.rays + (gl / (second ? A.pts.n_samples2 : A.pts.n_samples)) * A.pts.ray_stride;
+        const float zz = second ? A.pts.z2[gl] : A.pts.z[gl];
         x[0] = rr[0] + rr[3] * zz; x[1] = rr[1] + rr[4] * zz; x[2] = rr[2] + rr[5] * zz;
       }
     }

@@ -214,7 +214,10 @@ int bn_field_normals_impl(const bn_field_desc *desc, const bn_field_params *para
   a.p = *params; a.packed = packed; a.pts = *pts; a.out = out; a.grad_x = grad_x; a.stash = (const char *)stash; a.keep = keep;
   bn_make_packed_layout(a.g, &a.pl);
   const int BM = a.g.BM;
-  bn_make_stash_layout(a.g, pts->n_points, BM, bn_esize(desc->dtype), &a.sl);
+  BN_REQUIRE(pts->point_offset >= 0 && pts->point_offset % BM == 0, "field_normals: point_offset must be a multiple of %d", BM);
+  bn_stash_layout_at(a.g, pts, BM, bn_esize(desc->dtype), &a.sl);
+  a.out = out + pts->point_offset * a.g.C;
+  if (grad_x) a.grad_x = grad_x + pts->point_offset * 3;
   const int64_t tiles = ceil_div64(pts->n_points, BM);
   hipStream_t st = (hipStream_t)stream;
   BN_DISPATCH_TILE(desc->dtype, a.g, launch_adj, (a, tiles, st));

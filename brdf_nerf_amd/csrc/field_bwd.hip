@@ -398,6 +398,12 @@ extern "C" int bn_field_backward_parts(const bn_field_desc *desc, const bn_field
   a.an = desc->normal_an ? 1 : 0;
   BN_REQUIRE(pts && pts->n_points > 0 && packed && out && d_out && stash && G, "field_backward: null argument");
   BN_REQUIRE(parts > 0 && (parts & ~BN_BWD_ALL) == 0, "field_backward: parts=%d", parts);
+  BN_REQUIRE(pts->point_offset == 0 && (pts->total_points == 0 || pts->total_points == pts->n_points),
+             "field_backward: the backward runs over a whole point set (point_offset = 0)");
+  BN_REQUIRE(pts->seg1_points == 0 || (pts->rays && pts->z && pts->z2 && pts->n_samples2 > 0 && pts->seg1_points < pts->n_points &&
+                                       pts->seg1_points % pts->n_samples == 0 && (pts->n_points - pts->seg1_points) % pts->n_samples2 == 0),
+             "field_backward: bad two-block point set");
+  BN_REQUIRE(pts->seg1_points == 0 || !(desc->t_dim > 0 && G->d_t_embed), "field_backward: d_t_embed is not served for a two-block point set");
   BN_REQUIRE(parts == BN_BWD_ALL || !bn_deterministic(), "field_backward: the deterministic mode runs the whole backward in one call");
   const FieldGeom &g = a.g;
   a.d = *desc; a.p = *params; a.packed = packed; a.M = pts->n_points; a.out = out; a.d_out = d_out; a.stash = (char *)stash;

@@ -825,7 +825,13 @@ int bn_field_forward_impl(const bn_field_desc *desc, const bn_field_params *para
   a.sigma_only = sigma_only;
   bn_make_packed_layout(a.g, &a.pl);
   const int BM = a.g.BM;
-  bn_make_stash_layout(a.g, pts->n_points, BM, esize(desc->dtype), &a.sl);
+  BN_REQUIRE(pts->point_offset >= 0 && pts->point_offset % BM == 0 &&
+                 (pts->total_points == 0 || pts->point_offset + pts->n_points <= pts->total_points) &&
+                 (pts->point_offset == 0 || (pts->total_points > 0 && !sigma_only)),
+             "field_forward: point_offset=%lld total_points=%lld (offset must be a multiple of %d inside the set)",
+             (long long)pts->point_offset, (long long)pts->total_points, BM);
+  bn_stash_layout_at(a.g, pts, BM, esize(desc->dtype), &a.sl);
+  a.out = out + pts->point_offset * (sigma_only ? 1 : a.g.C);        // rows of this call in the set's output array
   const int64_t tiles = ceil_div64(pts->n_points, BM);
   hipStream_t st = (hipStream_t)stream;
   BN_DISPATCH_TILE(desc->dtype, a.g, launch_fwd, (a, tiles, st));

@@ -574,7 +574,9 @@ int bn_launch_wgrad(WgradArgs &wv, unsigned int *tk, bool bf, bool f16m, int64_t
 #endif
     // (small batches - up to 1024 rays x 64 samples per launch - run faster with one round of workgroups: 512 rays 0.232 ->
     // 0.197 ms, 1024 rays 0.367 -> 0.345, session 51)
-    int64_t n_split = (Mpad <= 65536 ? W2_BLOCKS / 2 : W2_BLOCKS) / tiles;
+    // (both passes of a 4096-ray step in one call - 524,288 points: four rounds, i.e. the points per workgroup of the tuned
+    // two-round shape; with twice the points per workgroup the launch ran 3-7 % slower than two launches, profiles/r03_ablation.txt)
+    int64_t n_split = (Mpad <= 65536 ? W2_BLOCKS / 2 : (Mpad <= 327680 ? W2_BLOCKS : 2 * W2_BLOCKS)) / tiles;
     if (n_split < 1) n_split = 1;
     int64_t mpb2 = ceil_div64(ceil_div64(Mpad, n_split), W2_BK) * W2_BK;
     if (mpb2 < 512) mpb2 = 512;

@@ -187,9 +187,12 @@ class FieldSpec:
         return names
 
 
-def make_points(xyz=None, rays=None, z=None, dirs=None, t_embed=None):
+def make_points(xyz=None, rays=None, z=None, dirs=None, t_embed=None, point_offset=0, total_points=0, z2=None):
+    """point_offset / total_points: this call's points inside a larger set that shares one output array and one stash;
+    z2 (R, G): the backward over a set of TWO sample blocks of the same rays (bn_points)."""
     pts = L.Points()
-    pts.dirs = pts.t_embed = None
+    pts.dirs = pts.t_embed = pts.z2 = None
+    pts.point_offset, pts.total_points, pts.n_samples2, pts.seg1_points = int(point_offset), int(total_points), 0, 0
     if t_embed is not None:      # per point with xyz, per ray with rays
         rows = xyz.shape[0] if xyz is not None else rays.shape[0]
         assert t_embed.shape[0] == rows and t_embed.is_contiguous() and t_embed.dtype == torch.float32
@@ -203,6 +206,10 @@ def make_points(xyz=None, rays=None, z=None, dirs=None, t_embed=None):
     else:
         pts.xyz, pts.rays, pts.z = None, rays.data_ptr(), z.data_ptr()
         pts.ray_stride, pts.n_samples, pts.n_points = rays.shape[1], z.shape[1], z.shape[0] * z.shape[1]
+        if z2 is not None:
+            assert z2.shape[0] == z.shape[0] and z2.is_contiguous() and z2.dtype == torch.float32
+            pts.z2, pts.n_samples2, pts.seg1_points = z2.data_ptr(), z2.shape[1], pts.n_points
+            pts.n_points = pts.n_points + z2.shape[0] * z2.shape[1]
     return pts
 
 
@@ -381,8 +388,9 @@ def composite_backward_raw(z, out, d_weights, d_depth, d_acc, noise=None, noise_
     return d_out
 
 
-def field_forward_raw(spec, named_params, packed, out, stash, xyz=None, rays=None, z=None):
-    pts = make_points(xyz, rays, z)
+def field_forward_raw(spec, named_params, packed, out, stash, xyz=None, rays=None, z=None, point_offset=0, total_points=0):
+    """out / stash are the whole SET's when total_points > 0 (this call fills rows [point_offset, point_offset + n_points))."""
+    pts = make_points(xyz, rays, z, point_offset=point_offset, total_points=total_points)
     ps = spec.params_struct(named_params)
     L.check(L.lib().bn_field_forward(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(out), _p(stash), _stream()),
             "bn_field_forward")
@@ -393,11 +401,12 @@ def field_forward_raw(spec, named_params, packed, out, stash, xyz=None, rays=Non
 
 
 def field_backward_raw(spec, named_params, named_grads, packed, out, d_out, stash, xyz=None, rays=None, z=None, unfold=True,
-                       zero_folded=True, parts=L.BN_BWD_ALL):
+                       zero_folded=True, parts=L.BN_BWD_ALL, z2=None):
     """unfold=False leaves the folded first-layer gradients in spec.fold_grads (they keep accumulating): a caller that
     back-propagates several batches before the optimizer step unfolds once, on the last call.  parts: bn_field_backward_parts
-    (a caller that overlaps the all-reduce of the trunk's gradient with the rest of the backward)."""
-    pts = make_points(xyz, rays, z)
+    (a caller that overlaps the all-reduce of the trunk's gradient with the rest of the backward).  z2: the points are the two
+    sample blocks [z | z2] of the same rays evaluated into one output / stash (field_forward_raw(point_offset=...))."""
+    pts = make_points(xyz, rays, z, z2=z2)
     ps, gs = spec.params_struct(named_params), spec.params_struct(named_grads, grads=True)
     L.check(L.lib().bn_field_backward_parts(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(out), _p(d_out), _p(stash),
                                             C.byref(gs), int(parts), _stream()), "bn_field_backward")

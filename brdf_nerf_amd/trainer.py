@@ -46,6 +46,7 @@ class FusedTrainer:
         # sample set composited through its sort index, one-launch Lambertian tail, fold / unfold kernels, one Adam launch for
         # all groups - and, for a step whose inputs keep their addresses, replayed from a captured HIP graph.
         self.lean = True
+        self.merge_passes = True        # one output array / stash / backward for both passes (False: two backward launch sets)
         self.overlap_allreduce = True   # world > 1: all-reduce the trunk's gradient while the rest of the backward still runs
         self.ray_offset = 0             # index of this rank's first ray in the global batch: in-kernel draws are taken per GLOBAL ray
         self.keep_grads = False         # True: the optimiser launch leaves the step's gradient in flat_grad (tests, diagnostics)
@@ -347,7 +348,7 @@ class FusedTrainer:
             sig = (spec.key(), rays.shape, rays.data_ptr(), rgbs.data_ptr(), None if valid_depth is None else valid_depth.data_ptr(),
                    None if depths is None else depths.data_ptr(), None if depth_std is None else depth_std.data_ptr(),
                    nf.data_ptr(), use_ds, tuple(active), float(self.ds_lambda), float(self.lambda_rgb), bool(self.usealldepth),
-                   L.deterministic(), int(self.ray_offset), bool(self.keep_grads))
+                   L.deterministic(), int(self.ray_offset), bool(self.keep_grads), bool(self.merge_passes))
             ent = self._graphs.get(sig)
             if ent is not None:
                 ent[0].replay()
@@ -388,9 +389,21 @@ class FusedTrainer:
         with torch.no_grad():
             packed = model.repack(spec)                                   # fold + pack: 2 launches
             z = Fn.stratified_z_rng(rays, S, st, self._buf("z", (R, S)), ray_offset=self.ray_offset)
-            out1 = self._buf("out1", (R * S, C))
-            stash1 = self._buf("stash1", (Fn.field_stash_bytes(spec, R * S),), torch.uint8)
-            Fn.field_forward_raw(spec, named, packed, out1, stash1, rays=rays, z=z)
+            # ONE output array, one stash and one gradient array for both passes: pass 2 is a second forward launch (it needs
+            # pass 1's result to place its samples) into rows [R S, R (S + G)) of the same set, and the backward - chain,
+            # weight gradients, skinny jobs - runs ONCE over all R (S + G) points (two launch sets before round 3's merge)
+            tile = 64 if spec.dtype == L.BN_F32 else 128
+            merged = self.merge_passes and (R * S) % tile == 0
+            n_all = R * (S + G)
+            if merged:
+                out_all = self._buf("out_all", (n_all, C))
+                stash_all = self._buf("stash_all", (Fn.field_stash_bytes(spec, n_all),), torch.uint8)
+                out1, out2 = out_all[:R * S], out_all[R * S:]
+                Fn.field_forward_raw(spec, named, packed, out_all, stash_all, rays=rays, z=z, point_offset=0, total_points=n_all)
+            else:
+                out1 = self._buf("out1", (R * S, C))
+                stash1 = self._buf("stash1", (Fn.field_stash_bytes(spec, R * S),), torch.uint8)
+                Fn.field_forward_raw(spec, named, packed, out1, stash1, rays=rays, z=z)
             out1v = out1.view(R, S, C)
             bufs = {"z2": self._buf("z2", (R, G)), "z_all": self._buf("z_all", (R, S + G)),
                     "idx": self._buf("idx", (R, S + G), torch.int64)}
@@ -398,11 +411,15 @@ class FusedTrainer:
             z2, z_all, idx = Fn.composite_guided(z, out1v, G, nf, args.std_range, valid_depth if has_t else None,
                                                  depths[:, 0] if has_t else None, depth_std if has_t else None, state=st, bufs=bufs,
                                                  ray_offset=self.ray_offset)
-            out2 = self._buf("out2", (R * G, C))
-            stash2 = self._buf("stash2", (Fn.field_stash_bytes(spec, R * G),), torch.uint8)
-            Fn.field_forward_raw(spec, named, packed, out2, stash2, rays=rays, z=z2)
+            if merged:
+                Fn.field_forward_raw(spec, named, packed, out_all, stash_all, rays=rays, z=z2, point_offset=R * S, total_points=n_all)
+            else:
+                out2 = self._buf("out2", (R * G, C))
+                stash2 = self._buf("stash2", (Fn.field_stash_bytes(spec, R * G),), torch.uint8)
+                Fn.field_forward_raw(spec, named, packed, out2, stash2, rays=rays, z=z2)
             out2v = out2.view(R, G, C)
-            d1o, d2o = self._buf("d1o", (R, S, C)), self._buf("d2o", (R, G, C))
+            d_all = self._buf("d_all", (n_all, C))
+            d1o, d2o = d_all[:R * S].view(R, S, C), d_all[R * S:].view(R, G, C)
         loss = None
         if lambertian:
             rgb = self._buf("rgb", (R, 3))
@@ -437,23 +454,29 @@ class FusedTrainer:
                 Fn.merged_composite_backward(z_all, idx, out1v, out2v, cg(d_weights), cg(d_depth), cg(d_acc), d1o, d2o,
                                              nonfinite=self._nonfinite if self.sanitize_grads else None)
         with torch.no_grad():
-            Fn.field_backward_raw(spec, named, self.grad_views, packed, out1, d1o.view(R * S, C), stash1, rays=rays, z=z, unfold=False)
+            def backward(parts, last):
+                """bn_field_backward over the merged set, or over the two passes one after the other; `last`: unfold afterwards."""
+                if merged:
+                    Fn.field_backward_raw(spec, named, self.grad_views, packed, out_all, d_all, stash_all, rays=rays, z=z, z2=z2,
+                                          unfold=last, zero_folded=False, parts=parts)
+                else:
+                    Fn.field_backward_raw(spec, named, self.grad_views, packed, out1, d1o.reshape(R * S, C), stash1, rays=rays, z=z,
+                                          unfold=False, parts=parts)
+                    Fn.field_backward_raw(spec, named, self.grad_views, packed, out2, d2o.reshape(R * G, C), stash2, rays=rays, z=z2,
+                                          unfold=last, zero_folded=False, parts=parts)       # (bn_fold_heads clears the folded accumulators)
             if self.world > 1 and self.overlap_allreduce and 0 < self.n_trunk < self.flat_grad.numel() and not L.deterministic():
                 # Two buckets (the reference: DDP's bucketed all-reduce overlapped with backward, main.py:720-731): the trunk's
-                # gradient is final after the second backward's trunk weight-gradient launch - its all-reduce (RCCL's own
-                # stream, ordered behind this one) runs under the head / skinny weight gradients and the unfold launch
+                # gradient is final after the trunk weight-gradient launch - its all-reduce (RCCL's own stream, ordered behind
+                # this one) runs under the head / skinny weight gradients and the unfold launch
                 import torch.distributed as dist
-                Fn.field_backward_raw(spec, named, self.grad_views, packed, out2, d2o.view(R * G, C), stash2, rays=rays, z=z2,
-                                      unfold=False, parts=L.BN_BWD_CHAIN | L.BN_BWD_WGRAD_TRUNK)
+                backward(L.BN_BWD_CHAIN | L.BN_BWD_WGRAD_TRUNK, False)
                 wa = dist.all_reduce(self.flat_grad[:self.n_trunk], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                Fn.field_backward_raw(spec, named, self.grad_views, packed, out2, d2o.view(R * G, C), stash2, rays=rays, z=z2,
-                                      zero_folded=False, parts=L.BN_BWD_WGRAD_HEADS | L.BN_BWD_SKINNY)
+                backward(L.BN_BWD_WGRAD_HEADS | L.BN_BWD_SKINNY, True)
                 wb = dist.all_reduce(self.flat_grad[self.n_trunk:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                 wa.wait()
                 wb.wait()
             else:
-                Fn.field_backward_raw(spec, named, self.grad_views, packed, out2, d2o.view(R * G, C), stash2, rays=rays, z=z2,
-                                      zero_folded=False)      # (bn_fold_heads of the next step clears the folded accumulators)
+                backward(L.BN_BWD_ALL, True)
                 if self.world > 1:
                     allreduce_sum_(self.flat_grad, self.pg)
             keep = self.keep_grads       # test hook: leave the gradient in the flat buffer

@@ -155,6 +155,16 @@ typedef struct bn_points {
   const float *t_embed;                /* desc.t_dim > 0: the per-image embedding models['t'](ts) (rendering.py:226-229) - xyz form:
                                           per point [n_points][t_dim]; rays form: per ray [n_rays][t_dim] (repeated per sample,
                                           spsbrdfnerf.py:98)                                                                       */
+  /* One output array and ONE stash for several forward calls (round 3: pass 1 and pass 2 of the fused step are evaluated by
+   * two launches - the second needs the first's result to place its samples - and back-propagated by ONE set of launches).
+   * Forward / normals: this call's points are points [point_offset, point_offset + n_points) of a set of total_points points
+   * (point_offset a multiple of the tile: 128 points in the 16-bit modes, 64 in fp32; `out` and `stash` are the SET's);
+   * total_points == 0: a set of its own.  Backward over the whole set (rays form): points [0, seg1_points) are samples
+   * z[r][0 .. n_samples) of ray r, points [seg1_points, n_points) are samples z2[r][0 .. n_samples2); seg1_points == 0: one block. */
+  int64_t point_offset, total_points;
+  const float *z2;
+  int32_t n_samples2;
+  int64_t seg1_points;
 } bn_points;
 
 /* sigma-only forward (forward(sigma_only=True), spsbrdfnerf.py:684): sigma[n_points]. */

@@ -28,8 +28,10 @@ def main():
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     variants = {}
     for tag in tags:
-        path = os.path.join(here, "brdf_nerf_amd", "libbrdfnerf_hip.so") if tag == "default" else \
-            os.path.join(here, "brdf_nerf_amd", "build", tag, "libbrdfnerf_hip.so")
+        # "<build>[:attr=value,...]": a library build (default = the in-tree one) and FusedTrainer attributes to set on its trainer
+        build, _, attrs = tag.partition(":")
+        path = os.path.join(here, "brdf_nerf_amd", "libbrdfnerf_hip.so") if build == "default" else \
+            os.path.join(here, "brdf_nerf_amd", "build", build, "libbrdfnerf_hip.so")
         h = L.load(path)
         L.use(h)
         args = bench.make_args(n_rays, 64, 64, dtype, **bench.CONFIG_FLAGS[config][0])
@@ -37,6 +39,9 @@ def main():
         model = load_model(args).to(dev)
         tr = FusedTrainer(model, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
         tr.use_graph = False              # the per-kernel events live in the library's launch sites: eager steps
+        for kv in filter(None, attrs.split(",")):
+            k, v = kv.split("=")
+            setattr(tr, k, {"True": True, "False": False}.get(v, v))
         variants[tag] = (h, args, model, tr)
     b = bench.synthetic_batch(n_rays, 1, dev)
     flags = bench.CONFIG_FLAGS[config][1]
