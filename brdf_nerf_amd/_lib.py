@@ -51,6 +51,15 @@ class Points(C.Structure):
                 ("z2", fptr), ("n_samples2", C.c_int32), ("seg1_points", C.c_int64)]
 
 
+class ShadeDesc(C.Structure):         # bn_shade_desc
+    _fields_ = [(k, C.c_int32) for k in ("kind", "C", "ch_normal", "ch_p0", "ch_p1", "ch_p2", "rhoc_is_albedo", "shell",
+                                         "cos_irradiance", "usealldepth")] + \
+               [(k, C.c_float) for k in ("hpk_scl", "f0", "rgb_padding", "lambda_rgb", "lambda_ds", "lambda_hs")]
+
+
+BN_SHADE_LAMBERT, BN_SHADE_RPV, BN_SHADE_HAPKE, BN_SHADE_MICROFACET = 0, 1, 2, 3
+
+
 class FoldDesc(C.Structure):          # bn_fold_desc
     _fields_ = [("n_heads", C.c_int32), ("F", C.c_int32), ("rows", C.c_int32), ("wf", fptr), ("bf", fptr),
                 ("w1", fptr * BN_MAX_HEADS), ("w1_ld", C.c_int64 * BN_MAX_HEADS), ("b1", fptr * BN_MAX_HEADS),
@@ -113,9 +122,12 @@ _SIGS = {
                                       fptr, C.c_int64, fptr, C.c_int64, fptr, fptr, fptr, C.c_uint32, C.c_uint32, C.c_int64, fptr, fptr,
                                       fptr, fptr, fptr, fptr]),
     "bn_merged_composite_forward": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, fptr,
-                                              fptr, fptr, fptr, fptr]),
+                                              fptr, fptr, fptr, fptr, fptr]),
     "bn_merged_composite_backward": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, fptr,
-                                               fptr, fptr, fptr, fptr, fptr]),
+                                               fptr, C.c_float, fptr, fptr, fptr, fptr, fptr]),
+    "bn_ray_shade_loss": (C.c_int, [fptr, fptr, fptr, fptr, fptr, fptr, C.c_int64, fptr, C.c_int64, fptr, fptr, C.c_int64, fptr,
+                                    C.c_int64, fptr, C.c_int64, fptr, C.c_int64, C.c_int64, fptr, fptr, fptr, C.c_int32, fptr, fptr,
+                                    fptr, fptr]),
     "bn_lambert_tail": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, C.c_int64, fptr,
                                   C.c_int64, fptr, C.c_int64, fptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, fptr, fptr,
                                   C.c_int32, fptr, fptr, fptr, fptr, fptr, fptr]),

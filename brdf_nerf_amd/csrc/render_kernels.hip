@@ -106,7 +106,6 @@ extern "C" int bn_rng_uniform(const unsigned long long *rng, uint32_t rng_stream
 // Lane i of the ray's wave owns samples [i*c, (i+1)*c), c = ceil(S/64) <= BN_MAX_C: the exclusive prefix product
 // of (1 - alpha + 1e-10) is a per-lane serial product + a 6-step wavefront shuffle scan.
 #define BN_MAX_CPL 8   // samples per lane -> S <= 512
-#define BN_MAX_CH 32   // rgb3 + sigma + beta + two normals + three 3-wide BRDF heads = 20 at most today
 
 struct CompArgs {
   const float *z, *sigma, *noise, *chan;
@@ -782,7 +781,7 @@ struct MergedArgs {
   const float *out1, *out2;
   int S1, S2, C;
   int64_t R;
-  float *alphas, *trans, *weights, *depth, *acc, *wsum;
+  float *alphas, *trans, *weights, *depth, *acc, *wsum, *var;
   // MODE 1
   const float *rgbs, *valid, *tdepth, *tweight, *tstd;
   int64_t v_stride, td_stride, tw_stride, ts_stride;
@@ -791,7 +790,8 @@ struct MergedArgs {
   float *ray_loss, *rgb, *loss_acc;
   int loss_slots;                  // the rays' loss terms are added to loss_acc[ray % loss_slots] (spread: same-address atomics serialise)
   // MODE 2
-  const float *d_weights, *d_depth, *d_acc, *d_wsum;
+  const float *d_weights, *d_depth, *d_acc, *d_wsum, *depth_in;
+  float hs_scale;
   // MODE 1, 2
   float *d_out1, *d_out2;
   unsigned long long *nonfinite;   // nullable: zero non-finite gradient elements and count them ([0] NaN, [1] Inf)
@@ -876,15 +876,18 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
       }
       if (MODE == 1 && A.acc && lane == 0) A.acc[ray * C + 3] = 0.f;
     }
+    float var = 0.f;
+    if (MODE == 1 || A.var) {
+#pragma unroll
+      for (int j = 0; j < BN_MAX_CPL; ++j) {
+        const int s = lane * cpl + j;
+        if (j < cpl && s < S) { const float dz = zv[j] - dsum; var += dz * dz * w[j]; }
+      }
+      var = wave_sum(var);
+      if (lane == 0 && A.var) A.var[ray] = var;
+    }
     if (MODE == 0) return;
     // ---- Lambertian shading + SNerfLoss + DepthLoss and their gradients (lambert_loss_kernel)
-    float var = 0.f;
-#pragma unroll
-    for (int j = 0; j < BN_MAX_CPL; ++j) {
-      const int s = lane * cpl + j;
-      if (j < cpl && s < S) { const float dz = zv[j] - dsum; var += dz * dz * w[j]; }
-    }
-    var = wave_sum(var);
     const float invn = 1.f / (3.f * (float)A.R);
     float loss = 0.f;
 #pragma unroll
@@ -918,6 +921,7 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
   }
   // ---- backward: g_s = dL/dw_s; dL/dalpha_s = g_s T_s - (1/u_s) sum_{k>s} g_k w_k   
   const int ng = MODE == 1 ? 3 : C;
+  const float hs = MODE == 2 ? A.hs_scale : 0.f, hs_depth = (MODE == 2 && A.hs_scale != 0.f) ? A.depth_in[ray] : 0.f;
   float g[BN_MAX_CPL], gw = 0.f;
 #pragma unroll
   for (int j = 0; j < BN_MAX_CPL; ++j) {
@@ -926,6 +930,7 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
     if (j < cpl && s < S) {
       float gg = dd * zv[j] + dws;
       if (MODE == 2 && A.d_weights) gg += A.d_weights[ray * S + s];
+      if (MODE == 2 && hs != 0.f) { const float dz = zv[j] - hs_depth; gg += hs * (dz * dz); }
       for (int c = 0; c < ng; ++c)
         if (c != 3) gg += dacc[c] * chan(j, c);
       g[j] = gg;
@@ -984,10 +989,10 @@ static bool merged_c4(const MergedArgs &a) {
 
 extern "C" int bn_merged_composite_forward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
                                            int32_t S2, int32_t C, int64_t R, float *alphas, float *trans, float *weights, float *depth,
-                                           float *acc, float *wsum, void *stream) {
+                                           float *acc, float *wsum, float *var, void *stream) {
   MergedArgs a = {};
   a.z = z; a.idx = sort_idx; a.out1 = out1; a.out2 = out2; a.S1 = S1; a.S2 = S2; a.C = C; a.R = R;
-  a.alphas = alphas; a.trans = trans; a.weights = weights; a.depth = depth; a.acc = acc; a.wsum = wsum;
+  a.alphas = alphas; a.trans = trans; a.weights = weights; a.depth = depth; a.acc = acc; a.wsum = wsum; a.var = var;
   if (int e = merged_check(a, "merged_composite_forward")) return e;
   BnProfScope prof_(BN_K_COMPOSITE_FWD, (hipStream_t)stream);
   if (merged_c4(a)) merged_composite_kernel<0, true><<<MERGED_GRID(R)>>>(a);
@@ -998,13 +1003,14 @@ extern "C" int bn_merged_composite_forward(const float *z, const int64_t *sort_i
 
 extern "C" int bn_merged_composite_backward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
                                             int32_t S2, int32_t C, int64_t R, const float *d_weights, const float *d_depth,
-                                            const float *d_acc, const float *d_wsum, float *d_out1, float *d_out2,
-                                            unsigned long long *nonfinite, void *stream) {
+                                            const float *d_acc, const float *d_wsum, float hs_scale, const float *depth,
+                                            float *d_out1, float *d_out2, unsigned long long *nonfinite, void *stream) {
   MergedArgs a = {};
   a.z = z; a.idx = sort_idx; a.out1 = out1; a.out2 = out2; a.S1 = S1; a.S2 = S2; a.C = C; a.R = R;
   a.d_weights = d_weights; a.d_depth = d_depth; a.d_acc = d_acc; a.d_wsum = d_wsum; a.d_out1 = d_out1; a.d_out2 = d_out2;
-  a.nonfinite = nonfinite;
+  a.nonfinite = nonfinite; a.hs_scale = hs_scale; a.depth_in = depth;
   if (int e = merged_check(a, "merged_composite_backward")) return e;
+  BN_REQUIRE(hs_scale == 0.f || depth, "merged_composite_backward: hs_scale needs the forward's depth");
   BN_REQUIRE(d_out1 && (S1 == S2 || d_out2), "merged_composite_backward: null gradient buffer");
   BnProfScope prof_(BN_K_COMPOSITE_BWD, (hipStream_t)stream);
   if (merged_c4(a)) merged_composite_kernel<2, true><<<MERGED_GRID(R)>>>(a);

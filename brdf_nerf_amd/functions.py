@@ -559,21 +559,56 @@ def merged_composite_forward(z_all, idx, out1, out2, bufs=None, want=("weights",
     S1, Cc = out1.shape[1], out1.shape[2]
     dev = z_all.device
     b = bufs if bufs is not None else {}
-    shapes = dict(alphas=(R, S2), trans=(R, S2), weights=(R, S2), depth=(R,), acc=(R, Cc), wsum=(R,))
+    shapes = dict(alphas=(R, S2), trans=(R, S2), weights=(R, S2), depth=(R,), acc=(R, Cc), wsum=(R,), var=(R,))
     o = {k: (b[k] if k in b else torch.empty(shapes[k], dtype=torch.float32, device=dev)) for k in want}
     g = lambda k: _p(o.get(k))
     L.check(L.lib().bn_merged_composite_forward(_p(z_all), _p(idx), _p(out1), _p(out2), S1, S2, Cc, R, g("alphas"), g("trans"),
-                                                g("weights"), g("depth"), g("acc"), g("wsum"), _stream()), "bn_merged_composite_forward")
+                                                g("weights"), g("depth"), g("acc"), g("wsum"), g("var"), _stream()),
+            "bn_merged_composite_forward")
     return o
 
 
-def merged_composite_backward(z_all, idx, out1, out2, d_weights, d_depth, d_acc, d_out1, d_out2, d_wsum=None, nonfinite=None):
-    """Gradient rows in the SOURCE layouts (d_out1 [R][S1][C], d_out2 [R][G][C]); channel 3 receives d sigma."""
+def merged_composite_backward(z_all, idx, out1, out2, d_weights, d_depth, d_acc, d_out1, d_out2, d_wsum=None, nonfinite=None,
+                              hs_scale=0.0, depth=None):
+    """Gradient rows in the SOURCE layouts (d_out1 [R][S1][C], d_out2 [R][G][C]); channel 3 receives d sigma.  hs_scale (with
+    the forward's depth): + hs_scale (z - depth)^2 on d loss / d w (HardSurfaceLoss, see ray_shade_loss)."""
     R, S2 = z_all.shape
     S1, Cc = out1.shape[1], out1.shape[2]
     L.check(L.lib().bn_merged_composite_backward(_p(z_all), _p(idx), _p(out1), _p(out2), S1, S2, Cc, R, _p(d_weights), _p(d_depth),
-                                                 _p(d_acc), _p(d_wsum), _p(d_out1), _p(d_out2), _p(nonfinite), _stream()),
+                                                 _p(d_acc), _p(d_wsum), float(hs_scale), _p(depth if hs_scale else None), _p(d_out1),
+                                                 _p(d_out2), _p(nonfinite), _stream()),
             "bn_merged_composite_backward")
+
+
+def ray_shade_loss(desc, acc, wsum, depth, var, rays_d, sun_d, rgbs, bufs=None, valid_depth=None, target_depth=None,
+                   target_weight=None, target_std=None, ray_loss=None, loss_acc=None):
+    """Ray-level shading + SNerfLoss + DepthLoss + HardSurfaceLoss and their gradients w.r.t. the composited sums in one
+    launch (bn_ray_shade_loss).  desc: L.ShadeDesc (rendering.shade_desc).  rays_d / sun_d: (R,3) views with unit inner
+    stride (sun_d None: ones).  -> dict rgb (R,3), d_acc (R,C), d_wsum (R,), d_depth (R,)."""
+    R, Cc = acc.shape
+    b = bufs if bufs is not None else {}
+    shapes = dict(rgb=(R, 3), d_acc=(R, Cc), d_wsum=(R,), d_depth=(R,))
+    o = {k: (b[k] if k in b else torch.empty(sh, dtype=torch.float32, device=acc.device)) for k, sh in shapes.items()}
+    use = target_depth is not None and desc.lambda_ds > 0
+    vp, vs = _strided(valid_depth if use else None)
+    tdp, tds = _strided(target_depth if use else None)
+    twp, tws = _strided(target_weight if use else None)
+    tsp, tss = _strided(target_std if use else None)
+
+    def rows3(t):
+        if t is None:
+            return None, 0
+        assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == 3
+        if t.stride(1) != 1:
+            t = t.contiguous()
+        return C.c_void_p(t.data_ptr()), t.stride(0)
+    rdp, rds = rows3(rays_d)
+    sdp, sds = rows3(sun_d)
+    L.check(L.lib().bn_ray_shade_loss(C.byref(desc), _p(acc), _p(wsum), _p(depth), _p(var), rdp, rds, sdp, sds, _p(rgbs), vp, vs, tdp, tds,
+                                      twp, tws, tsp, tss, R, _p(o["rgb"]), _p(ray_loss), _p(loss_acc),
+                                      0 if loss_acc is None else loss_acc.numel(), _p(o["d_acc"]), _p(o["d_wsum"]), _p(o["d_depth"]),
+                                      _stream()), "bn_ray_shade_loss")
+    return o
 
 
 def lambert_tail(z_all, idx, out1, out2, rgbs, rgb_padding, lambda_rgb, d_out1, d_out2, valid_depth=None, target_depth=None,

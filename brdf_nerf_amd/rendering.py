@@ -221,7 +221,8 @@ def shade(model, args, spec, out, z_vals, alphas, transparency, weights, depth, 
 def shade_ray(model, args, spec, z_vals, weights, depth, acc, rays_d, sun_d, apply_brdf, cos_irra_on):
     """The part of shade() a training loss reads when every ray has ONE BRDF and no per-sample irradiance (MultiBRDF == 0, no
     sun-visibility pass): rgb from the composited sums alone (models/spsbrdfnerf.py:259-357), without the per-sample entries
-    of the result dict.  Used by the launch-lean fused step, whose merged sample set is never materialised."""
+    of the result dict.  The torch-level statement of what bn_ray_shade_loss (shade_desc) computes in the launch-lean fused
+    step, whose merged sample set is never materialised; tests differentiate it with autograd against that kernel."""
     normal_c0 = None
     if spec.normal_an:
         normal_c0 = spec.ch_normal_an
@@ -252,6 +253,39 @@ def shade_ray(model, args, spec, z_vals, weights, depth, acc, rays_d, sun_d, app
     brdf, _ = _per_ray_brdf(model, args, kind, sun_d, -rays_d, normal_s, albedo_s, sums)
     rgb = brdf if irr_ray is None else irr_ray * brdf
     return {"rgb": rgb.clamp(0.0, 1.0)}, kind
+
+
+def shade_desc(model, args, spec, apply_brdf, cos_irra_on, lambda_rgb=1.0, lambda_ds=0.0, lambda_hs=0.0, usealldepth=False):
+    """bn_shade_desc of shade_ray() for this model / spec: which BRDF (the same selection as shade(), models/spsbrdfnerf.py:
+    277-357) and where its inputs sit among the composited channels."""
+    from . import _lib as L
+    cols = {name: c0 for (name, _, _), (c0, _) in zip(spec.heads[1:], spec.head_cols[1:])}
+    ch_n = -1
+    if spec.normal_an:
+        ch_n = spec.ch_normal_an
+    if spec.normal_lr:
+        ch_n = spec.ch_normal_lr
+    shell = int(getattr(args, "shell_hapke", 0))
+    kind, p = L.BN_SHADE_LAMBERT, (-1, -1, -1)
+    if ch_n >= 0 or cols:
+        if model.roughness and apply_brdf:
+            kind, p = L.BN_SHADE_MICROFACET, (cols["roughness_from_xyz"], -1, -1)
+        elif model.RPV and apply_brdf:
+            kind = L.BN_SHADE_RPV
+            p = (cols.get("k_from_xyz", -1), cols.get("theta_rpv_from_xyz", -1),
+                 -1 if args.funcH == 2 else cols.get("rhoc_from_xyz", -1))
+        elif (apply_brdf and args.b == True) or shell > 0:  # noqa: E712
+            kind = L.BN_SHADE_HAPKE
+            p = (cols.get("b_from_xyz", -1), cols.get("c_from_xyz", -1), cols.get("theta_from_xyz", -1))
+    if kind != L.BN_SHADE_LAMBERT and ch_n < 0:
+        raise RuntimeError("BRDF shading needs a normal field (--normal learned | analystic | analystic_learned)")
+    d = L.ShadeDesc()
+    d.kind, d.C, d.ch_normal, (d.ch_p0, d.ch_p1, d.ch_p2) = kind, spec.out_channels, ch_n, p
+    d.rhoc_is_albedo = int(kind == L.BN_SHADE_RPV and args.funcH == 2)
+    d.shell, d.cos_irradiance, d.usealldepth = shell, int(bool(cos_irra_on)), int(bool(usealldepth))
+    d.hpk_scl, d.f0 = float(getattr(args, "hpk_scl", 1.0)), float(getattr(args, "fresnel_f0", 0.04))
+    d.rgb_padding, d.lambda_rgb, d.lambda_ds, d.lambda_hs = float(model.rgb_padding), float(lambda_rgb), float(lambda_ds), float(lambda_hs)
+    return d
 
 
 def render_rays(models, args, rays, ts, mode="test", valid_depth=None, target_depths=None, target_std=None,

@@ -13,7 +13,7 @@ from . import functions as Fn
 from . import _lib as L
 from . import losses
 from .distributed import allreduce_sum_
-from .rendering import shade, shade_ray, get_z_vals, inference, sun_far
+from .rendering import shade, shade_desc, get_z_vals, inference, sun_far
 
 
 class FusedTrainer:
@@ -344,11 +344,12 @@ class FusedTrainer:
         body = lambda: self._lean_body(spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, cos_irra_on, use_ds, nf, reg,
                                        lambertian, active)
         res = None
-        if self.use_graph and self.world == 1 and lambertian:
+        if self.use_graph and self.world == 1:
             sig = (spec.key(), rays.shape, rays.data_ptr(), rgbs.data_ptr(), None if valid_depth is None else valid_depth.data_ptr(),
                    None if depths is None else depths.data_ptr(), None if depth_std is None else depth_std.data_ptr(),
                    nf.data_ptr(), use_ds, tuple(active), float(self.ds_lambda), float(self.lambda_rgb), bool(self.usealldepth),
-                   L.deterministic(), int(self.ray_offset), bool(self.keep_grads), bool(self.merge_passes))
+                   L.deterministic(), int(self.ray_offset), bool(self.keep_grads), bool(self.merge_passes), bool(apply_brdf),
+                   bool(cos_irra_on), float(reg.get("hs", 0)), bool(self.sanitize_grads))
             ent = self._graphs.get(sig)
             if ent is not None:
                 ent[0].replay()
@@ -433,26 +434,31 @@ class FusedTrainer:
                 if det:
                     loss = ray_loss.sum()
         else:
+            # BRDF / normal models: three launches - composited sums of the merged set, the ray-level shading + losses with
+            # their gradients w.r.t. those sums (bn_ray_shade_loss), and the composite backward
+            hs = float(reg.get("hs", 0))
+            desc = shade_desc(model, args, spec, apply_brdf, cos_irra_on, self.lambda_rgb, self.ds_lambda if use_ds else 0.0,
+                              hs, self.usealldepth)
+            det = L.deterministic()
+            ray_loss = self._buf("ray_loss", (R,)) if det else None
             with torch.no_grad():
                 o = Fn.merged_composite_forward(z_all, idx, out1v, out2v,
-                                                {k: self._buf("m_" + k, sh) for k, sh in (("weights", (R, S + G)), ("depth", (R,)),
-                                                                                          ("acc", (R, C)))})
-            acc_l, depth_l, weights_l = o["acc"].requires_grad_(True), o["depth"].requires_grad_(True), o["weights"].requires_grad_(True)
-            rays_d = rays[:, 3:6]
-            sun_d = rays[:, 8:11] if args.data == "sat" else torch.ones_like(rays[:, 0:3])
-            res, _ = shade_ray(model, args, spec, z_all, weights_l, depth_l, acc_l, rays_d, sun_d, apply_brdf, cos_irra_on)
-            loss = losses.snerf_loss(res["rgb"], rgbs, self.lambda_rgb)
-            if use_ds:
-                loss = loss + losses.depth_loss(z_all, depth_l, weights_l, depths[:, 0], depths[:, 1], valid_depth, depth_std,
-                                                self.ds_lambda, self.usealldepth)
-            if reg.get("hs", 0) > 0:
-                loss = loss + losses.hard_surface_loss(z_all, depth_l, weights_l, reg["hs"])
-            d_acc, d_depth, d_weights = torch.autograd.grad(loss, [acc_l, depth_l, weights_l], allow_unused=True)
-            rgb = res["rgb"]
-            with torch.no_grad():
-                cg = lambda t: None if t is None else t.contiguous()
-                Fn.merged_composite_backward(z_all, idx, out1v, out2v, cg(d_weights), cg(d_depth), cg(d_acc), d1o, d2o,
-                                             nonfinite=self._nonfinite if self.sanitize_grads else None)
+                                                {k: self._buf("m_" + k, sh) for k, sh in (("depth", (R,)), ("acc", (R, C)),
+                                                                                          ("wsum", (R,)), ("var", (R,)))},
+                                                want=("depth", "acc", "wsum", "var"))
+                sun_d = rays[:, 8:11] if args.data == "sat" else None
+                sb = {k: self._buf("s_" + k, sh) for k, sh in (("rgb", (R, 3)), ("d_acc", (R, C)), ("d_wsum", (R,)),
+                                                               ("d_depth", (R,)))}
+                g = Fn.ray_shade_loss(desc, o["acc"], o["wsum"], o["depth"], o["var"], rays[:, 3:6], sun_d, rgbs, sb,
+                                      valid_depth if use_ds else None, depths[:, 0] if use_ds else None,
+                                      depths[:, 1] if use_ds else None, depth_std if use_ds else None, ray_loss=ray_loss,
+                                      loss_acc=None if det else Fn.state_loss_partials(st))
+                rgb = g["rgb"]
+                Fn.merged_composite_backward(z_all, idx, out1v, out2v, None, g["d_depth"], g["d_acc"], d1o, d2o, d_wsum=g["d_wsum"],
+                                             nonfinite=self._nonfinite if self.sanitize_grads else None, hs_scale=hs / R if hs > 0 else 0.0,
+                                             depth=o["depth"])
+                if det:
+                    loss = ray_loss.sum()
         with torch.no_grad():
             def backward(parts, last):
                 """bn_field_backward over the merged set, or over the two passes one after the other; `last`: unfold afterwards."""

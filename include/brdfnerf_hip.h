@@ -346,11 +346,36 @@ int bn_composite_guided(const float *z, const float *sigma, int64_t sigma_stride
  * gradient elements are written as 0 and counted ([0] NaN, [1] Inf) - FusedTrainer.sanitize_grads without extra passes. */
 int bn_merged_composite_forward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
                                 int32_t S2, int32_t C, int64_t R, float *alphas, float *trans, float *weights, float *depth,
-                                float *acc, float *wsum, void *stream);
+                                float *acc, float *wsum, float *var, void *stream);
+/* hs_scale != 0 (with depth [R], the forward's result): adds hs_scale (z_s - depth)^2 to d loss / d w_s - the per-sample part
+ * of HardSurfaceLoss's gradient (metrics.py:263-290), see bn_ray_shade_loss. */
 int bn_merged_composite_backward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
                                  int32_t S2, int32_t C, int64_t R, const float *d_weights, const float *d_depth,
-                                 const float *d_acc, const float *d_wsum, float *d_out1, float *d_out2,
-                                 unsigned long long *nonfinite, void *stream);
+                                 const float *d_acc, const float *d_wsum, float hs_scale, const float *depth, float *d_out1,
+                                 float *d_out2, unsigned long long *nonfinite, void *stream);
+
+/* Ray-level shading + losses of a training step whose rays have ONE BRDF each (MultiBRDF == 0) and no per-sample
+ * irradiance, forward AND backward in one launch (one thread per ray), between bn_merged_composite_forward and
+ * bn_merged_composite_backward.  From the composited sums acc [R][C], wsum [R], depth [R] and var [R] = sum_s w (z - depth)^2:
+ *   albedo_s = acc[0:3] (1 + 2 pad) - pad wsum ;  n = l2_normalize(acc[ch_normal : +3]) ;  parameters = acc[ch_p* : ...]
+ *   rgb = clamp(irradiance * BRDF(sun_d, -rays_d, n, albedo_s, parameters), 0, 1)        (models/spsbrdfnerf.py:259-357)
+ *   loss = SNerfLoss(rgb, rgbs) + DepthLoss + HardSurfaceLoss                           (metrics.py:39-61, 82-161, 263-290)
+ * and d loss / d acc [R][C], d loss / d wsum [R], d loss / d depth [R] (the HardSurfaceLoss term's per-sample part is
+ * bn_merged_composite_backward's hs_scale = lambda_hs / R).  kind: BN_SHADE_*; channels < 0: head absent (RPV: p0 k, p1
+ * theta, p2 rhoc, or rhoc = albedo_s with rhoc_is_albedo (funcH == 2); Hapke: p0 b, p1 c, p2 theta (1 wide); microfacet: p0
+ * roughness (1 wide)).  sun_d NULL: (1,1,1).  The prior arrays carry element strides and are nullable together. */
+enum { BN_SHADE_LAMBERT = 0, BN_SHADE_RPV = 1, BN_SHADE_HAPKE = 2, BN_SHADE_MICROFACET = 3 };
+typedef struct {
+  int32_t kind, C, ch_normal, ch_p0, ch_p1, ch_p2;
+  int32_t rhoc_is_albedo, shell, cos_irradiance, usealldepth;
+  float hpk_scl, f0, rgb_padding, lambda_rgb, lambda_ds, lambda_hs;
+} bn_shade_desc;
+int bn_ray_shade_loss(const bn_shade_desc *desc, const float *acc, const float *wsum, const float *depth, const float *var,
+                      const float *rays_d, int64_t rd_stride, const float *sun_d, int64_t sd_stride, const float *rgbs,
+                      const float *valid_depth, int64_t v_stride, const float *target_depth, int64_t td_stride,
+                      const float *target_weight, int64_t tw_stride, const float *target_std, int64_t ts_stride, int64_t R,
+                      float *rgb, float *ray_loss, float *loss_acc, int32_t loss_slots, float *d_acc, float *d_wsum,
+                      float *d_depth, void *stream);
 /* Ray-level tail of a Lambertian step in ONE launch: bn_merged_composite_forward + bn_lambert_loss (shading, SNerfLoss,
  * DepthLoss; metrics.py:39-61,82-161) + bn_merged_composite_backward.  The prior arrays carry element strides.  ray_loss [R]
  * (nullable) and/or loss_acc (nullable): ray r's term is atomically added to loss_acc[r % loss_slots] - partial sums the

@@ -206,6 +206,100 @@ def test_lambert_tail_forward_against_reference_render_golden():
     assert float((rgb - t("rgb_coarse")).abs().max()) <= 2e-5
 
 
+# ------------------------------------------------------------------------------------------------ ray-level shading + losses
+_SHADE_CFGS = {
+    "rpv111_nlr": (dict(funcM=1, funcF=1, funcH=1, normal="learned"), True),
+    "rpv_m1f1h2_nan": (dict(funcM=1, funcF=1, funcH=2, normal="analystic"), True),
+    "rpv_f1_nanlr": (dict(funcF=1, normal="analystic_learned"), True),
+    "hapke_bct": (dict(b=1, c=1, theta=1, normal="learned"), True),
+    "hapke_b": (dict(b=1, normal="analystic"), True),
+    "hapke_shell3_nobrdf": (dict(shell_hapke=3, normal="learned"), False),
+    "microfacet": (dict(roughness=True, normal="analystic"), True),
+    "normal_only": (dict(normal="learned"), False),
+}
+
+
+@pytest.mark.parametrize("prior", [True, False])
+@pytest.mark.parametrize("name", list(_SHADE_CFGS))
+def test_ray_shade_loss_kernel_against_autograd_of_the_torch_statement(name, prior):
+    """bn_ray_shade_loss against rendering.shade_ray (the torch-level ray shading, held to the reference's render goldens through
+    shade() in test_gpu_parity.py) + losses.snerf_loss / depth_loss / hard_surface_loss (held to metrics.py goldens), differentiated
+    with autograd: rgb, loss, d acc, d wsum, d depth - and bn_merged_composite_backward's HardSurfaceLoss term against autograd of
+    the per-sample weights."""
+    from test_gpu_parity import build_model, make_args
+    from brdf_nerf_amd import functions as Fn, losses
+    from brdf_nerf_amd.rendering import shade_ray, shade_desc
+    kw, brdf = _SHADE_CFGS[name]
+    cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16, **kw)
+    args = make_args(cfg)
+    model = build_model(cfg, 5)
+    nr_lr, nr_an = cfg.normal in ("learned", "analystic_learned"), cfg.normal in ("analystic", "analystic_learned")
+    spec = model.spec(brdf, brdf, nr_lr, nr_an, beta=False)
+    C = spec.out_channels
+    R, S = 301, 24
+    g = torch.Generator().manual_seed(len(name) + 7 * prior)
+    rays = _sat_rays(R, g).to(DEV)
+    rays_d, sun_d = rays[:, 3:6], rays[:, 8:11]
+    # a plausible merged set: weights of a real compositing, channel rows in the heads' ranges
+    out = _field_like(R, S, C, g)
+    z = torch.sort(0.5 + torch.rand(R, S, generator=g), -1)[0].to(DEV).contiguous()
+    o = Fn.merged_composite_forward(z, None, out, None, want=("weights", "depth", "acc", "wsum", "var"))
+    if spec.normal_an or spec.normal_lr:       # composited normals roughly facing the camera, a few degenerate (zero) ones
+        c0 = spec.ch_normal_lr if spec.normal_lr else spec.ch_normal_an
+        nrm = -rays_d + 0.5 * torch.randn(R, 3, generator=g).to(DEV)
+        nrm[::37] = 0.0
+        o["acc"][:, c0:c0 + 3] = nrm * o["wsum"][:, None]
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    valid = (torch.rand(R, generator=g) < 0.6).float().to(DEV)
+    depths = torch.stack([o["depth"].cpu() + 0.1 * torch.randn(R, generator=g), torch.rand(R, generator=g)], -1).to(DEV)
+    dstd = (0.05 * torch.rand(R, generator=g)).to(DEV)
+    lam_rgb, lam_ds, lam_hs = 0.7, 10.0 if prior else 0.0, 0.3
+    cos_on = brdf or name == "normal_only"
+    # ---- torch statement
+    acc_l, depth_l, w_l = o["acc"].clone().requires_grad_(True), o["depth"].clone().requires_grad_(True), o["weights"].clone().requires_grad_(True)
+    res, _ = shade_ray(model, args, spec, z, w_l, depth_l, acc_l, rays_d, sun_d, brdf, cos_on)
+    loss = losses.snerf_loss(res["rgb"], rgbs, lam_rgb)
+    if prior:
+        loss = loss + losses.depth_loss(z, depth_l, w_l, depths[:, 0], depths[:, 1], valid, dstd, lam_ds, False)
+    loss = loss + losses.hard_surface_loss(z, depth_l, w_l, lam_hs)
+    d_acc, d_depth, d_w = torch.autograd.grad(loss, [acc_l, depth_l, w_l])
+    # ---- kernel
+    desc = shade_desc(model, args, spec, brdf, cos_on, lam_rgb, lam_ds, lam_hs, False)
+    ray_loss, lacc = torch.empty(R, device=DEV), torch.zeros(8, device=DEV)
+    k = Fn.ray_shade_loss(desc, o["acc"], o["wsum"], o["depth"], o["var"], rays_d, sun_d, rgbs, None,
+                          valid if prior else None, depths[:, 0] if prior else None, depths[:, 1] if prior else None,
+                          dstd if prior else None, ray_loss=ray_loss, loss_acc=lacc)
+    tol_rgb = 1e-4 if name == "microfacet" else 2e-6
+    assert float((k["rgb"] - res["rgb"]).abs().max()) <= tol_rgb, name
+    assert abs(float(ray_loss.sum()) - float(loss)) <= 2e-5 * abs(float(loss)), (name, float(ray_loss.sum()), float(loss))
+    assert abs(float(lacc.sum()) - float(loss)) <= 2e-5 * abs(float(loss))
+    # d loss / d w_s = (d wsum + hs (z - depth)^2) + [shading terms through acc: not part of w's own gradient here]: the torch
+    # statement reads weights in wsum (albedo padding), the depth-loss gate (no gradient) and HardSurfaceLoss
+    want_w = k["d_wsum"][:, None] + (lam_hs / R) * (z - o["depth"][:, None]) ** 2
+    assert float((want_w - d_w).abs().max()) <= 2e-5 * float(d_w.abs().max()) + 1e-12, name
+    d_acc = d_acc.clone()
+    d_acc[:, 3] = 0
+    bad_k, bad_t = ~torch.isfinite(k["d_acc"]).all(-1), ~torch.isfinite(d_acc).all(-1)
+    assert torch.equal(bad_k, bad_t), (name, bad_k.nonzero().flatten().tolist(), bad_t.nonzero().flatten().tolist())
+    # (Hapke with theta: a degenerate normal gives NaN gradients on BOTH sides, in the same rays - the step's sanitize_grads
+    # zeroes and counts them)
+    assert int(bad_k.sum()) <= R // 20
+    ok = ~bad_k
+    sc = float(d_acc[ok].abs().max())
+    err = float((k["d_acc"][ok] - d_acc[ok]).abs().max()) / sc
+    # (the chain through a degenerate normal / a GGX lobe amplifies last-bit differences of the forward)
+    assert err <= (2e-3 if name == "microfacet" else 2e-4), (name, err)
+    assert float((k["d_depth"] - d_depth).abs().max()) <= 2e-5 * float(d_depth.abs().max()) + 1e-12, name
+    # ---- the composite backward adds the per-sample HardSurfaceLoss term
+    d1a, d1b = torch.empty(R, S, C, device=DEV), torch.empty(R, S, C, device=DEV)
+    fin = {key: torch.nan_to_num(v, 0.0, 0.0, 0.0) for key, v in k.items()}
+    Fn.merged_composite_backward(z, None, out, None, None, fin["d_depth"], fin["d_acc"], d1a, None, d_wsum=fin["d_wsum"],
+                                 hs_scale=lam_hs / R, depth=o["depth"])
+    want_w = fin["d_wsum"][:, None] + (lam_hs / R) * (z - o["depth"][:, None]) ** 2
+    Fn.merged_composite_backward(z, None, out, None, want_w.contiguous(), fin["d_depth"], fin["d_acc"], d1b, None)
+    assert float((d1a - d1b).abs().max()) <= 2e-6 * float(d1b.abs().max())
+
+
 # ------------------------------------------------------------------------------------------------ fold / unfold / Adam
 @pytest.mark.parametrize("F,heads,dir_dim", [(512, 1, 0), (64, 3, 0), (192, 2, 24)])
 def test_fold_and_unfold_kernels_against_torch(F, heads, dir_dim):
@@ -307,7 +401,7 @@ def _lean_cfgs():
 @pytest.mark.parametrize("name", list(_lean_cfgs()))
 def test_lean_step_matches_general_step_on_the_same_draws(name, dtype):
     """FusedTrainer's launch-lean step (in-kernel draws, fused per-ray kernels, fold / unfold / Adam kernels; eager, then
-    replayed from a HIP graph for the Lambertian model) against the general step (ATen glue; held to the autograd path and the
+    replayed from a HIP graph) against the general step (ATen glue; held to the autograd path and the
     oracle by test_gpu_fuzz.py) fed with the Philox streams' draws as arrays: loss, rgb and parameters over five steps."""
     import brdf_nerf_amd
     from test_gpu_parity import build_model, make_args, Replay, diag
@@ -369,8 +463,7 @@ def test_lean_step_matches_general_step_on_the_same_draws(name, dtype):
             assert float((ta.flat_param - tb.flat_param).abs().max()) <= 2.1 * ta.lr
             assert float((ta.flat_param - tb.flat_param).abs().mean()) <= (2e-7 if dtype == "fp32" else 2e-5), (name, dtype, step)
         assert ta.adam_steps == tb.adam_steps
-        if name == "lambert":
-            assert len(tb._graphs) == 1, "the Lambertian lean step was not captured"
+        assert len(tb._graphs) == 1, "the lean step was not captured into a HIP graph"
         diag(f"lean vs general step {name} {dtype}: worst flat-gradient difference over 6 steps {worst_g:.2e} of the largest entry; "
              f"graphs {len(tb._graphs)}")
     finally:
