@@ -18,7 +18,7 @@ no instrumentation inside; the per-kernel HIP-event times come from a SEPARATE p
 prices the kernel with the largest share of the step, as a fraction of the dense bf16/fp16 MFMA peak both by the
 reference network's algorithmic FLOPs and by the FLOPs the build executes (the linear feats layer is folded into the
 heads); `traffic` / `mfma_busy` come from the committed rocprofv3 PMC pass of the SAME kernel sources
-(profiles/r02_pmc.json, keyed by a hash of csrc/), null when the sources have changed since.  `cpu_baseline` times the
+(profiles/r03_pmc.json, keyed by a hash of csrc/), null when the sources have changed since.  `cpu_baseline` times the
 CPU oracle (a port of the reference's PyTorch path) on a bounded sample of the same workload.
 """
 import argparse
@@ -145,22 +145,13 @@ def cpu_baseline(args, rays=1024, seconds_budget=30.0):
                 cross_timing="profiles/r02_cpu_cross_timing.txt (oracle vs the imported reference, build container)")
 
 
-def source_hash():
-    """sha256 over the kernel sources the library is built from (csrc/ + the C ABI header): the key under which a PMC pass
-    is valid for the current kernels."""
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "brdf_nerf_amd", "csrc")
-    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".cpp")))
-    for f in files + [os.path.join(ROOT, "include", "brdfnerf_hip.h"), os.path.join(ROOT, "brdf_nerf_amd", "build.py")]:   # (per-file compiler flags)
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+from brdf_nerf_amd.build import source_hash  # noqa: E402  (key of the committed PMC passes)
 
 
 def pmc_record(config, dtype):
-    """Per-kernel counters of the committed rocprofv3 PMC passes (profiles/pmc_collect.sh -> profiles/r02_pmc.json), or
+    """Per-kernel counters of the committed rocprofv3 PMC passes (profiles/pmc_collect.sh -> profiles/r03_pmc.json), or
     ({}, reason) when there is none for this workload or the kernel sources have changed since it was taken."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc.json")
     if not os.path.exists(path):
         return {}, "no PMC pass committed"
     rec = json.load(open(path))
@@ -410,6 +401,7 @@ def main():
         if name in pmc:
             k["pmc"] = pmc[name]
         kernels[name] = k
+    half_step = lambda n: kernels[n]["ms_per_launch"] * kernels[n]["launches_per_step"] / 2      # ms per M2 / 2 points
     mfma = {n: k for n, k in kernels.items() if "tflops" in k and n != "skinny_wgrad"}
     dom = max(mfma, key=lambda n: mfma[n]["ms_per_launch"] * mfma[n]["launches_per_step"])
     dpm = pmc.get(dom, {})
@@ -439,14 +431,14 @@ def main():
         # SURVEY.md section 8d kernel-level figure: the fused MLP on M = rays x samples rows (one launch of each kernel)
         "mlp_microbench": {
             "rows": M2 // 2,
-            "fwd_ms": kernels["field_fwd_full"]["ms_per_launch"],
-            "fwd_tflops": fpp[False]["field_fwd_full"] * (M2 // 2) / (kernels["field_fwd_full"]["ms_per_launch"] * 1e-3) / 1e12,
-            "fwd_bwd_ms": sum(kernels[n]["ms_per_launch"] for n in ("field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad")
-                              if n in kernels),
+            "fwd_ms": half_step("field_fwd_full"),
+            "fwd_tflops": fpp[False]["field_fwd_full"] * (M2 // 2) / (half_step("field_fwd_full") * 1e-3) / 1e12,
+            "fwd_bwd_ms": sum(half_step(n) for n in ("field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad") if n in kernels),
             "fwd_bwd_tflops": 3.0 * fpp[False]["field_fwd_full"] * (M2 // 2) /
-                              (sum(kernels[n]["ms_per_launch"] for n in ("field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad")
+                              (sum(half_step(n) for n in ("field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad")
                                    if n in kernels) * 1e-3) / 1e12,
-            "note": "fwd = full forward with activation stash; fwd_bwd = forward + backward chain + weight gradients, 3x the "
+            "note": "per M2 / 2 rows = half of a step's points (the backward kernels run once over both passes: half of their launch); "
+                    "fwd = full forward with activation stash; fwd_bwd = forward + backward chain + weight gradients, 3x the "
                     "forward's algorithmic FLOPs (dX + dW), analytic-normal kernels not included",
         } if "field_fwd_full" in kernels else None,
         "step_tflops": flops_step[False] / step_s / 1e12, "step_frac_of_peak": flops_step[False] / step_s / 1e12 / peak,

@@ -81,6 +81,7 @@ _lib = None
 
 _SIGS = {
     "bn_abi_version": (C.c_int, []),
+    "bn_source_hash": (C.c_char_p, []),
     "bn_last_error": (C.c_char_p, []),
     "bn_build_flags": (C.c_char_p, []),
     "bn_set_deterministic": (C.c_int, [C.c_int]),
@@ -176,6 +177,14 @@ def load(path, baseline=False):
         fn.restype, fn.argtypes = res, args
     if not baseline and L.bn_abi_version() != 4:
         raise LibraryMissing(f"{path}: ABI version mismatch; rebuild")
+    if not baseline and os.environ.get("BRDFNERF_ALLOW_STALE_LIB", "0") in ("", "0"):
+        # a library older than the sources beside it must not pass for them (tests, bench and profiles all run through here)
+        from .build import CSRC, source_hash
+        if os.path.isdir(CSRC):
+            have, want = L.bn_source_hash().decode(), source_hash()
+            if have != want:
+                raise LibraryMissing(f"{path} was built from other sources (library {have}, tree {want}): run "
+                                     f"python -m brdf_nerf_amd.build (BRDFNERF_ALLOW_STALE_LIB=1 to load it anyway)")
     return L
 
 

@@ -4,6 +4,7 @@
 
 Produces brdf_nerf_amd/libbrdfnerf_hip.so.  hipcc cross-compiles without a GPU.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -21,13 +22,33 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
+def source_hash():
+    """sha256 (16 hex digits) over everything the library is compiled from: csrc/, the C ABI header and this file (the per-file
+    compiler flags).  Compiled into the library (bn_source_hash); also the key of the committed PMC passes (bench.py)."""
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp")))
+    for f in files + [os.path.join(ROOT, "include", "brdfnerf_hip.h"), os.path.abspath(__file__)]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def library_hash(path=None):
+    """The source hash compiled into a built library, read from the file's bytes (no dlopen), or None."""
+    path = path or LIB
+    if not os.path.exists(path):
+        return None
+    data = open(path, "rb").read()
+    i = data.find(b"BN_SOURCE_HASH=")
+    if i < 0:
+        return None
+    return data[i + 15:i + 31].decode("ascii", "replace")
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "brdfnerf_hip.h"),
-                                                               os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    """True unless the built library carries the hash of the sources beside it (content, not mtimes: a copied tree keeps neither
+    its timestamps nor their order)."""
+    return library_hash() != source_hash()
 
 
 # extra hipcc flags per source file (basename), on top of FLAGS.  The weight-gradient kernels gain from the max-ILP machine
@@ -59,17 +80,21 @@ def build(verbose=False, force=False, defines=(), out=None, extra_flags=(), tag=
     os.makedirs(objdir, exist_ok=True)
     procs = []
     objs = []
+    sh = source_hash()
+    hdr_bytes = b"".join(open(f, "rb").read() for f in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+                         + [os.path.join(ROOT, "include", "brdfnerf_hip.h")])
+    keys = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        if os.path.exists(obj) and not force:
-            hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
-            hdr_t = max(hdr_t, os.path.getmtime(os.path.join(ROOT, "include", "brdfnerf_hip.h")),
-                        os.path.getmtime(os.path.abspath(__file__)))          # (this file holds the per-file compiler flags)
-            if os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
-                continue
+        stamp = os.path.basename(src) == "error.cpp"            # carries the source hash (so it is recompiled whenever any source changed)
         cmd = [HIPCC] + FLAGS + list(FILE_FLAGS.get(os.path.basename(src), ())) + list(extra_flags) + ["-D" + d for d in defines] + \
-            ["-x", "hip", "-c", src, "-o", obj]
+            (['-DBN_SOURCE_HASH="%s"' % sh] if stamp else []) + ["-x", "hip", "-c", src, "-o", obj]
+        # an object is reused when it was compiled from these bytes with this command line (content key, not mtimes)
+        key = hashlib.sha256(open(src, "rb").read() + hdr_bytes + " ".join(cmd).encode()).hexdigest()
+        keys.append((obj + ".key", key))
+        if os.path.exists(obj) and not force and os.path.exists(obj + ".key") and open(obj + ".key").read() == key:
+            continue
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd))
@@ -86,6 +111,8 @@ def build(verbose=False, force=False, defines=(), out=None, extra_flags=(), tag=
             print("\n".join(keep))
     if failed:
         raise RuntimeError("hipcc failed")
+    for path, key in keys:
+        open(path, "w").write(key)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out
 

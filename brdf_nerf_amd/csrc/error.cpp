@@ -20,6 +20,13 @@ void bn_set_error(const char *fmt, ...) {
 extern "C" const char *bn_last_error(void) { return g_err; }
 extern "C" int bn_abi_version(void) { return BN_ABI_VERSION; }
 
+// sha256 prefix of the sources this library was compiled from (brdf_nerf_amd/build.py source_hash(), passed as -DBN_SOURCE_HASH):
+// the loader refuses a library that is older than the tree beside it, build() recompiles on a mismatch whatever the mtimes say.
+#ifndef BN_SOURCE_HASH
+#define BN_SOURCE_HASH "unknown"
+#endif
+extern "C" const char *bn_source_hash(void) { return "BN_SOURCE_HASH=" BN_SOURCE_HASH + 15; }
+
 // Every -D switch a source file of the library reacts to (variant builds pass the same defines to every file).
 extern "C" const char *bn_build_flags(void) {
   return ""

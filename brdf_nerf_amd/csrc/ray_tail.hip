@@ -9,6 +9,7 @@
 // (SNerfLoss, lambda_sc = 0), metrics.py:82-161 (DepthLoss), metrics.py:263-290 (HardSurfaceLoss) and their autograd graphs.
 #include "common.h"
 #include "brdfnerf_hip.h"
+#include "prof.h"
 // (no FMA contraction, like brdf.hip: the degenerate-geometry branches must round like the reference's separate ATen ops)
 #pragma clang fp contract(off)
 #include "brdf_eval.h"
@@ -27,13 +28,6 @@ struct ShadeArgs {
   int loss_slots;
   float *d_acc, *d_wsum, *d_depth;
 };
-
-template <int N> __device__ __forceinline__ Dual<N> zero_dual() {
-  Dual<N> z; z.v = 0.f;
-#pragma unroll
-  for (int i = 0; i < N; ++i) z.d[i] = 0.f;
-  return z;
-}
 
 // KIND: BN_SHADE_LAMBERT / RPV / HAPKE / MICROFACET.  Dual slots: composited normal 0-2, composited albedo 3-5, then the
 // BRDF parameters (RPV: k 6-8, theta 9-11, rhoc 12-14; Hapke: b 6-8, c 9-11, theta 12; microfacet: roughness 6).
@@ -195,6 +189,7 @@ extern "C" int bn_ray_shade_loss(const bn_shade_desc *desc, const float *acc, co
   a.d_depth = d_depth;
   const dim3 grid((unsigned)ceil_div64(R, 64));
   hipStream_t st = (hipStream_t)stream;
+  BnProfScope prof_(BN_K_BRDF, st);
   switch (q.kind) {
     case BN_SHADE_LAMBERT: ray_shade_loss_kernel<BN_SHADE_LAMBERT><<<grid, 64, 0, st>>>(a); break;
     case BN_SHADE_RPV: ray_shade_loss_kernel<BN_SHADE_RPV><<<grid, 64, 0, st>>>(a); break;

@@ -60,6 +60,10 @@ class FusedTrainer:
         # device (bn_count_nonfinite, no host round trip); read it with dropped_grad_elems()
         self._nonfinite = torch.zeros(2, dtype=torch.int64, device=self.flat_param.device)
 
+    def seed_draws(self, seed):
+        """Key of the in-kernel draws of the launch-lean step (default: torch.initial_seed() at construction)."""
+        self.state[0] = int(seed) & 0x7FFFFFFFFFFFFFFF
+
     # ------------------------------------------------------------------ flat parameter / gradient storage
     def _flatten(self):
         """One flat fp32 buffer, in Adam GROUPS: [base | BRDF heads | theta head].  torch.optim.Adam (the reference's

@@ -59,6 +59,8 @@ const char *bn_last_error(void);
  * build).  Timing builds under profiles/ change instruction streams or drop work; the test-suite asserts that the library
  * it validates reports none. */
 const char *bn_build_flags(void);
+/* First 16 hex digits of the sha256 over the sources the library was compiled from (csrc/, this header, the build recipe). */
+const char *bn_source_hash(void);
 /* Run-to-run reproducible parameter gradients (the reference trains with Lightning's deterministic=True, main.py:726).
  * The weight-gradient kernels of bn_field_backward split the points over workgroups that add fp32 partial sums with
  * atomics; on = 1 makes the workgroups of one output tile add in a fixed order (a turn counter per tile): bitwise

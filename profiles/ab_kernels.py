@@ -47,6 +47,7 @@ def main():
     flags = bench.CONFIG_FLAGS[config][1]
     z = torch.sort(torch.rand(n_rays, 128, device=dev) * 2, -1)[0]
     times = {tag: {} for tag in tags}
+    counts = {tag: {} for tag in tags}       # launches per step (field_fwd_sigma: the separate sigma-only inference forward, 1 per call)
     for rnd in range(rounds + 1):                       # round 0 = warm-up
         for tag in tags:
             h, args, model, tr = variants[tag]
@@ -66,6 +67,7 @@ def main():
                 continue
             for k, (ms, n) in prof.items():
                 times[tag].setdefault(k, []).append(ms / n)
+                counts[tag][k] = n / (4 if k == "field_fwd_sigma" else 3)
     # whole steps, graph replay where the trainer captures one: wall time of 30 steps per variant, alternating
     import time
     step_ms = {tag: [] for tag in tags}
@@ -86,8 +88,8 @@ def main():
             if rnd:
                 step_ms[tag].append((time.perf_counter() - t0) / 30 * 1e3)
     keys = ["pack", "field_fwd_sigma", "field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad", "field_adjoint", "field_adjoint_bwd",
-            "composite_fwd", "composite_bwd", "guided_samples", "stratified_z", "adam"]
-    print(f"config {config} dtype {dtype} rays {n_rays}: ms per launch, median (min) over {rounds} alternating rounds")
+            "composite_fwd", "composite_bwd", "brdf", "guided_samples", "stratified_z", "adam"]
+    print(f"config {config} dtype {dtype} rays {n_rays}: launches per step x ms per launch, median (min) over {rounds} alternating rounds")
     print(f"{'kernel':>18} " + " ".join(f"{t[:26]:>26}" for t in tags))
     for k in keys:
         if not any(k in times[t] for t in tags):
@@ -95,7 +97,7 @@ def main():
         row = []
         for t in tags:
             v = times[t].get(k)
-            row.append(f"{statistics.median(v):.4f} ({min(v):.4f})" if v else "-")
+            row.append(f"{counts[t][k]:g} x {statistics.median(v):.4f} ({min(v):.4f})" if v else "-")
         print(f"{k:>18} " + " ".join(f"{c:>26}" for c in row))
     print(f"{'step (wall, ms)':>18} " + " ".join(f"{statistics.median(step_ms[t]):.4f} ({min(step_ms[t]):.4f})".rjust(26) for t in tags))
 

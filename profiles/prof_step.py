@@ -15,7 +15,8 @@ over, flags, _ = bench.CONFIG_FLAGS[config]
 args = bench.make_args(4096, 64, 64, dtype, **over)
 torch.manual_seed(0)
 model = load_model(args).to(dev)
-tr = FusedTrainer(model, args, lr=args.lr, ds_lambda=args.ds_lambda)
+tr = FusedTrainer(model, args, lr=args.lr, ds_lambda=args.ds_lambda, strict_rng=False)     # the launch-lean step, as bench.py runs it
+tr.use_graph = False      # eager launches: one profiler record per kernel launch
 b = bench.synthetic_batch(4096, 1, dev)
 for i in range(steps):
     tr.step(b["rays"], b["rgbs"], valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"], near_far=(0.0, 2.0), **flags)

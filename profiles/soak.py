@@ -47,7 +47,8 @@ def main():
         _lib.check(_lib.lib().bn_device_faults(C.byref(faults), None), "bn_device_faults")
         per = [(b_ - a_) / 100 * 1e3 for a_, b_ in zip(marks[:-1], marks[1:])]
         print(f"{config} {dtype}: {n} steps, final loss {float(loss):.5f}, faults {faults.value}, dropped {tr.dropped_grad_elems()}, reserved "
-              f"{mem0 / 2**30:.2f} -> {torch.cuda.memory_reserved() / 2**30:.2f} GiB, ms/step per 100-step window min {min(per):.3f} max {max(per):.3f}", flush=True)
+              f"{mem0 / 2**30:.2f} -> {torch.cuda.memory_reserved() / 2**30:.2f} GiB, ms/step per 100-step window min {min(per):.3f} max {max(per):.3f} "
+              f"(window {per.index(max(per)) + 1} of {len(per)}; the first four: {' '.join(f'{x:.3f}' for x in per[:4])}; graphs {len(tr._graphs)})", flush=True)
         assert faults.value == 0 and torch.cuda.memory_reserved() <= mem0 * 1.05
         del tr, model
         torch.cuda.empty_cache()

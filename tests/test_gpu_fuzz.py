@@ -69,7 +69,6 @@ def test_random_field_configuration_against_oracle(seed):
     t_ref = torch.randn(B, cfg.t_dim, generator=g).requires_grad_(True) if cfg.beta else None
     ref = OF.field_forward(p, cfg, xyz, dirs=dirs, t_embed=t_ref, **flags)
     coef = torch.randn(ref.shape, generator=g)
-    (ref * coef).sum().backward()
     t_gpu = t_ref.detach().to(DEV).requires_grad_(True) if cfg.beta else None
     out = model(xyz.to(DEV), input_dir=None if dirs is None else dirs.to(DEV), input_t=t_gpu, **flags)
     tag = (f"fuzz {seed}: F={cfg.feat} L={cfg.layers} siren={int(cfg.siren)} pe={int(cfg.mapping)} normal={cfg.normal} "
@@ -84,13 +83,20 @@ def test_random_field_configuration_against_oracle(seed):
         other = torch.ones(out.shape[1], dtype=torch.bool)
         other[c0:c0 + 3] = False
         assert float(dif[:, other].max()) <= 2e-4 * float(ref.detach().abs().max()) + 2e-5, tag
-        assert int((dif[:, c0:c0 + 3].amax(-1) > 2e-4).sum()) <= max(1, B // 50), f"{tag}: analytic normals off at too many points"
+        at_kink = dif[:, c0:c0 + 3].amax(-1) > 2e-4
+        assert int(at_kink.sum()) <= max(1, B // 50), f"{tag}: analytic normals off at too many points"
+        # ONE point on the other side of a ReLU moves a bias gradient by several percent (seed 847 of a 15 x hunt: 4.4 %, the fp32
+        # oracle itself landing on either side depending on the host's BLAS threading): those points - the two evaluations took
+        # different branches there, both legitimate - are left out of the backward comparison on BOTH sides, everything else is
+        # held to the ordinary analytic-normal tolerance
+        coef[at_kink] = 0.0
+        if int(at_kink.sum()):
+            diag(f"{tag}: {int(at_kink.sum())} point(s) at a ReLU kink left out of the backward comparison")
     else:
         assert err <= 2e-4 * float(ref.detach().abs().max()) + 2e-5, tag
+    (ref * coef).sum().backward()
     (out * coef.to(DEV)).sum().backward()
-    # (kink: ONE point on the other side of a ReLU moves a bias gradient by several percent - seed 847 of a 15 x hunt: 4.4 %, with the
-    # fp32 oracle itself landing on either side depending on the host's BLAS threading; gross faults are of order 1)
-    tol = (1e-1 if kink else 1e-3) if nr_an else 2e-4
+    tol = 1e-3 if nr_an else 2e-4
     if cfg.beta:
         scale = float(t_ref.grad.abs().max())
         assert float((t_gpu.grad.cpu() - t_ref.grad).abs().max()) <= tol * scale + 1e-7, tag + " d_t_embed"
@@ -118,6 +124,7 @@ def test_random_field_configuration_against_oracle(seed):
             e_hip, e_ref = float((got.cpu().double() - t64).abs().max()), float((want.double() - t64).abs().max())
             assert e_hip <= 3 * e_ref + tol * float(t64.abs().max()) + 1e-7, \
                 f"{tag} {k}: err vs fp64 {e_hip:.3e} (the fp32 oracle's own: {e_ref:.3e}) scale {scale:.3e}"
+            diag(f"{tag} {k}: fp64 referee used (HIP {e_hip:.2e}, fp32 oracle {e_ref:.2e}, scale {scale:.2e})")
             continue
         assert e <= tol * scale + 1e-7, f"{tag} {k}: err {e:.3e} scale {scale:.3e}"
 

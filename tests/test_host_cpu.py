@@ -55,6 +55,22 @@ def test_release_library_has_no_diagnostic_switches():
     assert _lib.lib().bn_build_flags() == b""
 
 
+def test_library_carries_the_hash_of_the_sources_beside_it(tmp_path, monkeypatch):
+    """build() decides by content, not mtimes - the library holds the sha256 prefix of the sources it was
+    compiled from; the loader refuses a library built from other sources."""
+    from brdf_nerf_amd import _lib, build
+    want = build.source_hash()
+    assert _lib.lib().bn_source_hash().decode() == want
+    assert build.library_hash() == want and not build.needs_build()
+    # another tree state: the same library is stale, and the loader says so
+    monkeypatch.setattr(build, "source_hash", lambda: "0123456789abcdef")
+    assert build.needs_build()
+    with pytest.raises(_lib.LibraryMissing, match="other sources"):
+        _lib.load(_lib.LIB_PATH)
+    monkeypatch.setenv("BRDFNERF_ALLOW_STALE_LIB", "1")
+    _lib.load(_lib.LIB_PATH)
+
+
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     from brdf_nerf_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
