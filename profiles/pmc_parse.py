@@ -10,15 +10,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 # field_fwd_kernel<T, MT, NT, WAVES = 8, KEEP, DIR>: KEEP (the stash-writing training forward) follows the 8
-NAMES = [("field_fwd_kernel", "Li8ELb1", "field_fwd_full"), ("field_fwd_kernel", "Li8ELb0", "field_fwd_sigma"), ("field_bwd_kernel", "", "field_bwd_chain"),
-         ("wgrad256_kernel", "", "wgrad"), ("skinny_wgrad_kernel", "", "skinny_wgrad"), ("field_adjoint_kernel", "", "field_adjoint"),
-         ("field_adjbwd_kernel", "", "field_adjoint_bwd"), ("composite_kernel", "Lb0", "composite_fwd"), ("composite_kernel", "Lb1", "composite_bwd"),
-         ("guided_kernel", "", "guided_samples"), ("adam_kernel", "", "adam")]
+NAMES = [("field_fwd_kernel", ("Li8ELb1", "8, true"), "field_fwd_full"), ("field_fwd_kernel", ("Li8ELb0", "8, false"), "field_fwd_sigma"),
+         ("field_bwd_kernel", (), "field_bwd_chain"), ("wgrad256_kernel", (), "wgrad"), ("skinny_wgrad_kernel", (), "skinny_wgrad"),
+         ("field_adjoint_kernel", (), "field_adjoint"), ("field_adjbwd_kernel", (), "field_adjoint_bwd"),
+         # round 3: the merged-set compositing kernel (MODE 0 forward, 1 Lambertian tail, 2 backward), pass-1 compositing fused with the
+         # guided resampling, the ray-level shading + loss kernel, multi-group Adam
+         ("merged_composite_kernel", ("ILi0E", "<0,"), "composite_fwd"), ("merged_composite_kernel", ("ILi1E", "<1,", "ILi2E", "<2,"), "composite_bwd"),
+         ("composite_guided_kernel", (), "guided_samples"), ("ray_shade_loss_kernel", (), "brdf"), ("adam_multi_kernel", (), "adam"),
+         ("composite_kernel", ("Lb0", "<false"), "composite_fwd"), ("composite_kernel", ("Lb1", "<true"), "composite_bwd"),
+         ("guided_kernel", (), "guided_samples"), ("adam_kernel", (), "adam")]
 
 
 def classify(kernel_name):
-    for sub, tag, out in NAMES:
-        if sub in kernel_name and (not tag or tag in kernel_name or tag.replace("Li8E", "8, ").replace("Lb1", "true").replace("Lb0", "false") in kernel_name):
+    for sub, tags, out in NAMES:
+        if sub in kernel_name and (not tags or any(t in kernel_name for t in tags)):
             return out
     return None
 
