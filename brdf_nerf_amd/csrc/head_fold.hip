@@ -4,7 +4,7 @@
 //   unfold:  dW1_h[:, :F] += M_h Wf^T + s_h bf^T    db1_h += s_h    dWf += sum_h W1_h^T M_h    dbf += sum_h W1_h^T s_h
 // with M_h = dL/dW'_h, s_h = dL/db'_h accumulated by the weight-gradient kernels.  feats_from_xyz is linear and feeds only
 // the heads' first (linear) layers (models/spsbrdfnerf.py:694-755): W1 (Wf y + bf) + b1 = (W1 Wf) y + (W1 bf + b1).
-// Exact fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32 = a k-ordered fmaf chain): one workgroup per 32x32 output tile, the
+// Exact fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32 = an fmaf chain over a fixed permutation of k): one workgroup per 32x32 output tile, the
 // contraction split over its four waves, partial tiles summed through LDS.  The operands (<= 1 MB each) sit in L2.
 #include "common.h"
 
@@ -14,20 +14,38 @@ struct FoldArgs {
   int tiles_dw1, tiles_dwf;
 };
 
-// acc (32x32, this wave's share of k in [k0, k1)) += sum_k A(m0 + i, k) B(k, n0 + j);  element strides (sam, sak), (sbk, sbn)
+// acc (32x32, this wave's share of k in [k0, k1), both multiples of 8) += sum_k A(m0 + i, k) B(k, n0 + j);  element strides (sam, sak),
+// (sbk, sbn).  Lane (r, h) feeds the contraction indices k + 4 h + {0..3} of every group of 8 - the same permutation on both
+// operands, so an operand that is contiguous along k (sak == 1 / sbk == 1: rows of M, W1, Wf^T) is read with ONE 16-byte load per
+// lane and four MFMA steps instead of four strided 4-byte loads.
+__device__ __forceinline__ f32x4 k4_load(const float *p, int64_t sk, bool vec) {
+  if (vec) return *(const f32x4 *)p;
+  return f32x4{p[0], p[sk], p[2 * sk], p[3 * sk]};
+}
 __device__ __forceinline__ void tile_mac(f32x16 &acc, const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn,
                                          int k0, int k1, int lane) {
   const int r = lane & 31, h = lane >> 5;
-  const float *a = A + r * sam + h * sak, *b = B + h * sbk + r * sbn;
+  const bool a4 = sak == 1 && (sam & 3) == 0 && ((uintptr_t)A & 15) == 0;
+  const bool b4 = sbk == 1 && (sbn & 3) == 0 && ((uintptr_t)B & 15) == 0;
+  const float *a = A + r * sam + 4 * h * sak, *b = B + r * sbn + 4 * h * sbk;
   int k = k0;
-  for (; k + 16 <= k1; k += 16) {
-    float av[8], bv[8];
+  for (; k + 32 <= k1; k += 32) {
+    f32x4 av[4], bv[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { av[q] = a[(int64_t)(k + 2 * q) * sak]; bv[q] = b[(int64_t)(k + 2 * q) * sbk]; }
+    for (int u = 0; u < 4; ++u) {
+      av[u] = k4_load(a + (int64_t)(k + 8 * u) * sak, sak, a4);
+      bv[u] = k4_load(b + (int64_t)(k + 8 * u) * sbk, sbk, b4);
+    }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q], bv[u][q], acc, 0, 0, 0);
   }
-  for (; k + 2 <= k1; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(int64_t)k * sak], b[(int64_t)k * sbk], acc, 0, 0, 0);
+  for (; k + 8 <= k1; k += 8) {
+    const f32x4 av = k4_load(a + (int64_t)k * sak, sak, a4), bv = k4_load(b + (int64_t)k * sbk, sbk, b4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+  }
 }
 // sum the four waves' partial tiles; the result lands in wave 0's accumulator
 __device__ __forceinline__ void tile_reduce(f32x16 &acc, float *red, int wave, int lane) {

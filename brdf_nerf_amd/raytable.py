@@ -31,6 +31,7 @@ class RayTable:
         self.perm = None
         self.cursor = 0
         self.epoch = 0
+        self.last_offset = 0
 
     def __len__(self):
         return self.n
@@ -39,19 +40,30 @@ class RayTable:
         self.perm = torch.randperm(self.n, device=self.device, generator=self.gen)
         self.cursor = 0
 
-    def next_batch(self, batch_size, rank=0, world=1):
+    def next_batch(self, batch_size, rank=0, world=1, out=None):
         """The next `batch_size` rows of the epoch's permutation (the last batch of an epoch is short, like
-        DataLoader(drop_last=False)); rank r of `world` gets rows shard_bounds(len, r, world) of that global batch."""
+        DataLoader(drop_last=False)); rank r of `world` gets rows shard_bounds(len, r, world) of that global batch
+        (`last_offset` = index of its first row in the global batch).  out: a dict of staging buffers from staging() - the rows
+        are gathered INTO them, so successive batches live at the same addresses (the fused step then replays its HIP graph)."""
         if self.perm is None or self.cursor >= self.n:
             if self.perm is not None:
                 self.epoch += 1
             self._reshuffle()
         idx = self.perm[self.cursor:self.cursor + batch_size]
         self.cursor += batch_size
+        self.last_offset = 0
         if world > 1:
             lo, hi = shard_bounds(idx.shape[0], rank, world)
             idx = idx[lo:hi]
-        return {k: v.index_select(0, idx) for k, v in self.data.items()}
+            self.last_offset = lo
+        if out is None:
+            return {k: v.index_select(0, idx) for k, v in self.data.items()}
+        n = idx.shape[0]
+        return {k: torch.index_select(v, 0, idx, out=out[k][:n]) for k, v in self.data.items()}
+
+    def staging(self, rows):
+        """Buffers for next_batch(out=...): one per table column, `rows` rows each."""
+        return {k: torch.empty((rows,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device) for k, v in self.data.items()}
 
     def state_dict(self):
         return {"gen": self.gen.get_state(), "perm": self.perm, "cursor": self.cursor, "epoch": self.epoch}

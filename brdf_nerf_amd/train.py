@@ -24,6 +24,7 @@ class TrainLoop:
         """near_far: the (near, far) pair the guided-sampling clamp uses (rendering.py:133 reads row 0 of the batch;
         satellite batches share one pair per image) - pass it to keep the step free of device->host reads."""
         self.args, self.table, self.near_far = args, table, near_far
+        self._staging = None
         # trusted_ckpts: --in_ckpts points at a checkpoint written by the reference (Lightning pickles callback objects
         # beside the weights; torch's safe loader refuses those unless the caller vouches for the file)
         self.rank, self.world = world_info()
@@ -69,12 +70,15 @@ class TrainLoop:
         # --beta: for the first two epochs the reference scores with SNerfLoss(lambda_sc) - lambda_rgb = 1 - and only then with
         # SNerfLoss(lambda_rgb=args.lambda_rgb) (main.py:82-86, 237-238: 'beta_coarse' in results and epoch < 2)
         tr.lambda_rgb = 1.0 if (getattr(a, "beta", False) and flags["epoch"] < 2) else self._lambda_rgb
-        b = self.table.next_batch(a.batch_size * self.world, self.rank, self.world)
+        # batches are gathered into the same staging buffers every step: unchanged addresses let the fused step replay its HIP graph
+        if self._staging is None:
+            self._staging = self.table.staging(a.batch_size)      # a rank's share of a global batch: at most batch_size rows
+        b = self.table.next_batch(a.batch_size * self.world, self.rank, self.world, out=self._staging)
+        tr.ray_offset = self.table.last_offset        # in-kernel draws are taken per GLOBAL ray: the same whatever the sharding
         has_depth = "depths" in b
         depths = b.get("depths")
         if has_depth and getattr(a, "ds_noweights", False):
-            depths = depths.clone()
-            depths[:, 1] = 1.0
+            depths[:, 1] = 1.0                        # (the staging copy, not the table)
         reg = dict(tr.reg)
         if not flags["nr_reg_on"]:
             reg["nr_an"] = reg["nr_lr"] = 0.0

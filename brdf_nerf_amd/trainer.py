@@ -50,6 +50,8 @@ class FusedTrainer:
         self.overlap_allreduce = True   # world > 1: all-reduce the trunk's gradient while the rest of the backward still runs
         self.ray_offset = 0             # index of this rank's first ray in the global batch: in-kernel draws are taken per GLOBAL ray
         self.keep_grads = False         # True: the optimiser launch leaves the step's gradient in flat_grad (tests, diagnostics)
+        self.seed_hook = None           # callable(name, tensor): sees / may overwrite "z2" (guided depths) and "d_all" (the gradient rows the
+                                        # field backward starts from) of a launch-lean step (tests; such steps are not captured)
         self.use_graph = True
         self.graph_after = 3            # eager steps with an unchanged signature before the step is captured
         self._graphs, self._sig_seen, self._nf_dev = {}, {}, {}
@@ -348,7 +350,7 @@ class FusedTrainer:
         body = lambda: self._lean_body(spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, cos_irra_on, use_ds, nf, reg,
                                        lambertian, active)
         res = None
-        if self.use_graph and self.world == 1:
+        if self.use_graph and self.world == 1 and self.seed_hook is None:
             sig = (spec.key(), rays.shape, rays.data_ptr(), rgbs.data_ptr(), None if valid_depth is None else valid_depth.data_ptr(),
                    None if depths is None else depths.data_ptr(), None if depth_std is None else depth_std.data_ptr(),
                    nf.data_ptr(), use_ds, tuple(active), float(self.ds_lambda), float(self.lambda_rgb), bool(self.usealldepth),
@@ -416,6 +418,8 @@ class FusedTrainer:
             z2, z_all, idx = Fn.composite_guided(z, out1v, G, nf, args.std_range, valid_depth if has_t else None,
                                                  depths[:, 0] if has_t else None, depth_std if has_t else None, state=st, bufs=bufs,
                                                  ray_offset=self.ray_offset)
+            if self.seed_hook is not None:   # (and the guided depths pass 2 is evaluated at)
+                self.seed_hook("z2", z2)
             if merged:
                 Fn.field_forward_raw(spec, named, packed, out_all, stash_all, rays=rays, z=z2, point_offset=R * S, total_points=n_all)
             else:
@@ -463,6 +467,8 @@ class FusedTrainer:
                                              depth=o["depth"])
                 if det:
                     loss = ray_loss.sum()
+        if self.seed_hook is not None:       # test hook: sees (and may overwrite) the gradient rows [R (S + G)][C] the field backward starts from
+            self.seed_hook("d_all", d_all)
         with torch.no_grad():
             def backward(parts, last):
                 """bn_field_backward over the merged set, or over the two passes one after the other; `last`: unfold afterwards."""

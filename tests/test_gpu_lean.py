@@ -300,6 +300,66 @@ def test_ray_shade_loss_kernel_against_autograd_of_the_torch_statement(name, pri
     assert float((d1a - d1b).abs().max()) <= 2e-6 * float(d1b.abs().max())
 
 
+_REF_SHADE = {   # golden -> (model flags, step flags): the reference's own per-sample outputs of its render fixtures
+    "render_rpv111_nlr_train": (dict(funcM=1, funcF=1, funcH=1, normal="learned"), True, True),
+    "render_rpv111_nan_train": (dict(funcM=1, funcF=1, funcH=1, normal="analystic"), True, True),
+    "render_hapke_bct_train": (dict(b=1, c=1, theta=1, normal="learned"), True, True),
+    "render_hapke_bc_train": (dict(b=1, c=1, normal="analystic"), True, True),
+    "render_microfacet_train": (dict(roughness=True, normal="learned"), True, True),
+    "render_rpv_m1f1h2_test": (dict(funcM=1, funcF=1, funcH=2, normal="learned"), True, True),
+    "render_rpv_m1h2_test": (dict(funcM=1, funcH=2, normal="learned"), True, True),
+    "render_shell1_nobrdf_test": (dict(shell_hapke=1, normal="learned"), False, False),
+    "render_shell2_nobrdf_test": (dict(shell_hapke=2, normal="learned"), False, True),
+    "render_shell3_nobrdf_test": (dict(shell_hapke=3, normal="learned"), False, True),
+    "render_shell3_brdf_test": (dict(shell_hapke=3, normal="learned"), True, True),
+}
+_HEAD_KEYS = {"k_from_xyz": "rpv_k", "theta_rpv_from_xyz": "rpv_theta", "rhoc_from_xyz": "rpv_rhoc", "b_from_xyz": "hpk_b",
+              "c_from_xyz": "hpk_c", "theta_from_xyz": "hpk_theta", "roughness_from_xyz": "roughness"}
+
+
+@pytest.mark.parametrize("name", list(_REF_SHADE))
+def test_ray_shade_loss_on_the_references_per_sample_outputs(name):
+    """the new glue kernel against the reference's render goldens.  The fixtures hold the REFERENCE's
+    per-sample field outputs on the merged S+G set (albedo, sigmas, normals, BRDF parameters, z_vals; produced by rendering.py:
+    168-291 + models/spsbrdfnerf.py:198-357): composited by bn_merged_composite_forward and shaded by bn_ray_shade_loss they must
+    give the reference's rgb_coarse (and, for the training fixtures, its loss = mean((rgb - target)^2) + 0.01 mean(depth))."""
+    from test_gpu_parity import build_model, make_args, load_golden, mini
+    from brdf_nerf_amd import functions as Fn
+    from brdf_nerf_amd.rendering import shade_desc
+    kw, brdf, cos_on = _REF_SHADE[name]
+    g = load_golden(name)
+    cfg = mini(**kw)
+    args = make_args(cfg)
+    model = build_model(cfg, 11)
+    spec = model.spec(brdf, brdf, cfg.normal in ("learned", "analystic_learned"), cfg.normal in ("analystic", "analystic_learned"),
+                      beta=False)
+    t = lambda k: torch.from_numpy(g["out/" + k + "_coarse"]).to(DEV)
+    z = t("z_vals").contiguous()
+    R, S = z.shape
+    out = torch.zeros(R, S, spec.out_channels, device=DEV)
+    out[..., :3], out[..., 3] = t("albedo"), t("sigmas").reshape(R, S)
+    if spec.normal_an:
+        out[..., spec.ch_normal_an:spec.ch_normal_an + 3] = t("normal_an")
+    if spec.normal_lr:
+        out[..., spec.ch_normal_lr:spec.ch_normal_lr + 3] = t("normal_lr")
+    for (hname, _, _), (c0, wdt) in zip(spec.heads[1:], spec.head_cols[1:]):
+        out[..., c0:c0 + wdt] = t(_HEAD_KEYS[hname]).reshape(R, S, wdt)
+    o = Fn.merged_composite_forward(z, None, out, None, want=("weights", "depth", "acc", "wsum", "var"))
+    assert float((o["weights"] - t("weights")).abs().max()) <= 1e-5 and float((o["depth"] - t("depth")).abs().max()) <= 2e-5
+    rays = torch.from_numpy(g["rays"]).to(DEV)
+    rgbs = torch.from_numpy(g["tgt/rgbs"]).to(DEV) if "tgt/rgbs" in g else torch.zeros(R, 3, device=DEV)
+    desc = shade_desc(model, args, spec, brdf, cos_on, 1.0, 0.0, 0.0, False)
+    ray_loss = torch.empty(R, device=DEV)
+    k = Fn.ray_shade_loss(desc, o["acc"], o["wsum"], o["depth"], o["var"], rays[:, 3:6], rays[:, 8:11], rgbs, ray_loss=ray_loss)
+    # (same ray-level bounds as test_render_rays_golden_fp32: the GGX lobe and Hapke's opposition terms amplify 1e-7)
+    tol = 1e-4 if "microfacet" in name else (4e-5 if ("hapke" in name or "shell" in name) else 2e-5)
+    err = float((k["rgb"] - t("rgb")).abs().max())
+    assert err <= tol, (name, err)
+    if "loss" in g and "tgt/rgbs" in g:
+        loss = float(ray_loss.sum()) + 0.01 * float(o["depth"].mean())
+        assert abs(loss - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])) + 1e-7, (name, loss, float(g["loss"]))
+
+
 # ------------------------------------------------------------------------------------------------ fold / unfold / Adam
 @pytest.mark.parametrize("F,heads,dir_dim", [(512, 1, 0), (64, 3, 0), (192, 2, 24)])
 def test_fold_and_unfold_kernels_against_torch(F, heads, dir_dim):
@@ -453,13 +513,17 @@ def test_lean_step_matches_general_step_on_the_same_draws(name, dtype):
             e = float((ga - gb).abs().max()) / scale
             cos = float(torch.nn.functional.cosine_similarity(ga.double(), gb.double(), dim=0))
             worst_g = max(worst_g, e)
-            if dtype == "fp32":       # (microfacet: the GGX lobe's gradient amplifies a 1e-7 difference of the accumulated normal)
-                assert e <= (5e-4 if name == "microfacet" else 5e-5), (name, dtype, step, e)
+            # (analytic normals - rpv111_nan, microfacet: the two ray-level evaluations differ by fp32 rounding (1e-7) in the composited
+            # normal, which the normalisation of a small density gradient and the GGX lobe amplify; measured 2e-5 .. 1.7e-4 depending
+            # on the last bits of the folded weights, learned normals 3e-6)
+            sensitive = name in ("microfacet", "rpv111_nan")
+            if dtype == "fp32":
+                assert e <= (5e-4 if sensitive else 5e-5), (name, dtype, step, e)
             else:       # a 1e-7 difference of a gradient seed can flip its 16-bit rounding
                 assert cos >= 0.99995 and e <= 2e-2, (name, dtype, step, cos, e)
             # the optimiser: first moments are linear in the gradient, parameters move by at most lr per step
             dm = float(((ta.exp_avg - m_before) - (tb.exp_avg - m_before)).abs().max()) / (0.1 * scale)
-            assert dm <= ((5e-4 if name == "microfacet" else 5e-5) if dtype == "fp32" else 2e-2), (name, dtype, step, dm)
+            assert dm <= ((5e-4 if sensitive else 5e-5) if dtype == "fp32" else 2e-2), (name, dtype, step, dm)
             assert float((ta.flat_param - tb.flat_param).abs().max()) <= 2.1 * ta.lr
             assert float((ta.flat_param - tb.flat_param).abs().mean()) <= (2e-7 if dtype == "fp32" else 2e-5), (name, dtype, step)
         assert ta.adam_steps == tb.adam_steps

@@ -1780,8 +1780,9 @@ def test_full_size_render_and_train_step_properties(name):
             t0.step(lb["rays"], lb["rgbs"], **pre_kw)
         start = {k: v.detach().clone() for k, v in m0.state_dict().items()}
         del t0, m0
-    for tag, dt, round_w in (("fp32", "fp32", False), (dtype, dtype, False), ("fp32_w16", "fp32", True)):
-        if tag == "fp32_w16" and lambert:
+    seeds = {}
+    for tag, dt, round_w in (("fp32", "fp32", False), (dtype, dtype, False), ("fp32_w16", "fp32", True), (dtype + "_seeded", dtype, False)):
+        if lambert and tag not in ("fp32", dtype):
             continue
         torch.manual_seed(0)
         m = load_model(make_args(cfg, dt)).to(DEV)
@@ -1794,6 +1795,10 @@ def test_full_size_render_and_train_step_properties(name):
         torch.manual_seed(7)                                   # seeds the step state's draw key: the same draws in every run
         t = FusedTrainer(m, make_args(cfg, dt), lr=5e-4, ds_lambda=10.0, strict_rng=False)
         t.keep_grads = True
+        if tag == "fp32":                                      # keep the guided depths and the gradient rows the fp32 field backward starts from ...
+            t.seed_hook = lambda k_, d: seeds.update({k_: d.clone()})
+        if tag.endswith("_seeded"):                            # ... and run the 16-bit field kernels at the SAME points from the SAME rows
+            t.seed_hook = lambda k_, d: d.copy_(seeds[k_])
         t.step(lb["rays"], lb["rgbs"], **step_kw)
         assert bool(torch.isfinite(t.flat_grad).all()), f"{tag}: non-finite gradient"
         grads[tag] = {k: v.clone() for k, v in t.grad_views.items()}
@@ -1826,8 +1831,14 @@ def test_full_size_render_and_train_step_properties(name):
         # (measured, profiles/r03_parity_errors.txt: the referee itself scatters between -0.99 and 0.997 over these configurations -
         # a sign flip of the roughness head's bias gradient included - i.e. the BRDF-stage gradient at this state is not
         # reproducible to 2^-9 in the weights; where it is well conditioned, hapke + theta, the 16-bit modes reach 0.94-0.95)
-        # -> asserted where the referee says the comparison means something (it reproduces fp32 to 0.9 itself); reported otherwise
-        assert ref < 0.9 or worst >= min(0.99, ref - 0.25 * (1.0 - ref) - 0.02) or worst >= 0.9, (worst, worst_k, ref, ref_k)
+        # -> the end-to-end cosines are REPORTED.  ASSERTED is what the 16-bit kernels are responsible for: every mode runs the
+        # ray-level shading and losses in fp32, and the ill-conditioning sits there (the BRDF Jacobian amplifies the 1e-3 difference
+        # of the composited sums) - so the 16-bit field backward (chain, analytic-normal double backward, weight gradients, at full
+        # width and batch) is started from the SAME per-sample gradient rows as the fp32 mode's and must reproduce its gradient
+        seeded, seeded_k = worst_cos("fp32", dtype + "_seeded")
+        diag(f"full size {name} ({dtype}): worst per-matrix gradient cosine of the {dtype} field backward started from the fp32 mode's "
+             f"gradient rows {seeded:.5f} ({seeded_k})")
+        assert seeded >= 0.99, (seeded, seeded_k)
     torch.manual_seed(3)
     tr = FusedTrainer(model, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
     losses_ = [float(tr.step(lb["rays"], lb["rgbs"], **step_kw)[0]) for _ in range(24)]

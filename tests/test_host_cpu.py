@@ -403,3 +403,25 @@ def test_ray_table_epoch_semantics_against_dataloader_and_distributed_sampler(N,
         assert sch.train_steps == (k + 1) * W
         assert abs(sch.lr(k) - 5e-4 * 0.9 ** (k // steps)) < 1e-15
         assert flags["epoch"] == ((k + 1) * W) // max(1, N // B)          # get_current_epoch (train_utils.py:117-118)
+
+
+def test_ray_table_staging_buffers_keep_their_addresses():
+    """next_batch(out=staging): the same rows as without, gathered into the same buffers every batch (what lets TrainLoop's fused
+    step replay a HIP graph), short last batch included; last_offset = the rank's first row in the global batch."""
+    from brdf_nerf_amd.raytable import synthetic_table
+    a, b = synthetic_table(1000, seed=3), synthetic_table(1000, seed=3)
+    st = b.staging(96)
+    ptr = {k: v.data_ptr() for k, v in st.items()}
+    for i in range(12):
+        x, y = a.next_batch(96), b.next_batch(96, out=st)
+        assert set(x) == set(y)
+        for k in x:
+            assert torch.equal(x[k], y[k]) and y[k].data_ptr() == ptr[k], (i, k)
+    assert b.epoch == 1 and y["rays"].shape[0] == 96
+    c = synthetic_table(1000, seed=3)
+    parts, offs = [], []
+    for r in range(3):
+        c.load_state_dict(a.state_dict())
+        parts.append(c.next_batch(100, rank=r, world=3, out=c.staging(34))["rgbs"].clone())
+        offs.append(c.last_offset)
+    assert offs == [0, 34, 67] and torch.equal(torch.cat(parts), a.next_batch(100)["rgbs"])
