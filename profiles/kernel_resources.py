@@ -48,7 +48,7 @@ def main():
     names = demangle([r["name"] for r in rows])
     print(f"{'VGPR':>5} {'AGPR':>5} {'scratch':>8} {'occ':>4} {'LDS':>7}  kernel")
     for r, n in zip(rows, names):
-        n = re.sub(r"\(.*$", "", n)
+        n = re.sub(r"\(.*$", "", n.replace("(anonymous namespace)::", ""))
         if filt and not any(f in n for f in filt):
             continue
         print(f"{r.get('VGPRs', 0):>5} {r.get('AGPRs', 0):>5} {r.get('ScratchSize', 0):>8} {r.get('Occupancy', 0):>4} {r.get('LDS Size', 0):>7}  {n}")
