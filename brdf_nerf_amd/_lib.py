@@ -128,7 +128,7 @@ _SIGS = {
                                                fptr, C.c_float, fptr, fptr, fptr, fptr, fptr]),
     "bn_ray_shade_loss": (C.c_int, [fptr, fptr, fptr, fptr, fptr, fptr, C.c_int64, fptr, C.c_int64, fptr, fptr, C.c_int64, fptr,
                                     C.c_int64, fptr, C.c_int64, fptr, C.c_int64, C.c_int64, fptr, fptr, fptr, C.c_int32, fptr, fptr,
-                                    fptr, fptr]),
+                                    fptr, fptr, fptr]),
     "bn_lambert_tail": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, C.c_int64, fptr,
                                   C.c_int64, fptr, C.c_int64, fptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, fptr, fptr,
                                   C.c_int32, fptr, fptr, fptr, fptr, fptr, fptr]),

@@ -79,6 +79,10 @@ __device__ __forceinline__ void bwd_dpre(const BwdArgs &A, int64_t gm, float (&d
   }
 }
 
+__global__ void clear_words_kernel(unsigned int *p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
+}
+
 // fp16 loss scaling: amax[which] = max over the launch of the finite |seed gradients| (float bits; non-negative floats order
 // like their bit patterns).  which = 0: the primal chain's seeds (bwd_dpre); which = 1: the analytic-normal double
 // backward's seeds gbar_PE = J_PE(x) gbar, bounded by 2^(pe_freqs-1) |gbar| (field_adjbwd.hip).
@@ -422,7 +426,11 @@ extern "C" int bn_field_backward_parts(const bn_field_desc *desc, const bn_field
   const unsigned amax_grid = (unsigned)(ceil_div64(pts->n_points, 256) < 1024 ? ceil_div64(pts->n_points, 256) : 1024);
   if (parts & BN_BWD_CHAIN) {
   if (f16m) {
-    if (hipMemsetAsync(amax, 0, 16, st) != hipSuccess) { bn_set_error("field_backward: memset failed"); return BN_ELAUNCH; }
+    // (a kernel, not hipMemsetAsync: inside a captured HIP graph the memset became a memset NODE, and replays of such graphs
+    // were seen to run the atomicMax kernels below against a stale / late-cleared word once in a few hundred steps - fp16 steps
+    // with analytic normals ended with non-finite parameters, profiles/r03_ablation.txt; kernel nodes are ordered like launches)
+    clear_words_kernel<<<1, 64, 0, st>>>((unsigned int *)amax, 4);
+    BN_LAUNCH_CHECK("clear amax");
     if (a.an) {
       grad_amax_kernel<1><<<amax_grid, 256, 0, st>>>(a, amax);
       BN_LAUNCH_CHECK("grad_amax<1>");

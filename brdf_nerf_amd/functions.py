@@ -581,10 +581,11 @@ def merged_composite_backward(z_all, idx, out1, out2, d_weights, d_depth, d_acc,
 
 
 def ray_shade_loss(desc, acc, wsum, depth, var, rays_d, sun_d, rgbs, bufs=None, valid_depth=None, target_depth=None,
-                   target_weight=None, target_std=None, ray_loss=None, loss_acc=None):
+                   target_weight=None, target_std=None, ray_loss=None, loss_acc=None, nonfinite=None):
     """Ray-level shading + SNerfLoss + DepthLoss + HardSurfaceLoss and their gradients w.r.t. the composited sums in one
     launch (bn_ray_shade_loss).  desc: L.ShadeDesc (rendering.shade_desc).  rays_d / sun_d: (R,3) views with unit inner
-    stride (sun_d None: ones).  -> dict rgb (R,3), d_acc (R,C), d_wsum (R,), d_depth (R,)."""
+    stride (sun_d None: ones).  nonfinite (int64[2]): rays with a non-finite loss term are left out of the step and counted.
+    -> dict rgb (R,3), d_acc (R,C), d_wsum (R,), d_depth (R,)."""
     R, Cc = acc.shape
     b = bufs if bufs is not None else {}
     shapes = dict(rgb=(R, 3), d_acc=(R, Cc), d_wsum=(R,), d_depth=(R,))
@@ -607,7 +608,7 @@ def ray_shade_loss(desc, acc, wsum, depth, var, rays_d, sun_d, rgbs, bufs=None, 
     L.check(L.lib().bn_ray_shade_loss(C.byref(desc), _p(acc), _p(wsum), _p(depth), _p(var), rdp, rds, sdp, sds, _p(rgbs), vp, vs, tdp, tds,
                                       twp, tws, tsp, tss, R, _p(o["rgb"]), _p(ray_loss), _p(loss_acc),
                                       0 if loss_acc is None else loss_acc.numel(), _p(o["d_acc"]), _p(o["d_wsum"]), _p(o["d_depth"]),
-                                      _stream()), "bn_ray_shade_loss")
+                                      _p(nonfinite), _stream()), "bn_ray_shade_loss")
     return o
 
 

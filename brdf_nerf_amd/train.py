@@ -128,8 +128,8 @@ class TrainLoop:
 
     # ------------------------------------------------------------------ checkpoints
     def save(self, ckpts_dir, logs_dir=None):
-        self.check_device_faults()
         """`<ckpts_dir>/epoch=<e>.ckpt` in the reference's layout + resume state; `opts.json` in logs_dir (opt.py)."""
+        self.check_device_faults()
         os.makedirs(ckpts_dir, exist_ok=True)
         tr = self.trainer
         sd = {f"nerf_coarse.{k}": v.detach().clone() for k, v in self.model.state_dict().items()}

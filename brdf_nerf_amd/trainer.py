@@ -460,7 +460,8 @@ class FusedTrainer:
                 g = Fn.ray_shade_loss(desc, o["acc"], o["wsum"], o["depth"], o["var"], rays[:, 3:6], sun_d, rgbs, sb,
                                       valid_depth if use_ds else None, depths[:, 0] if use_ds else None,
                                       depths[:, 1] if use_ds else None, depth_std if use_ds else None, ray_loss=ray_loss,
-                                      loss_acc=None if det else Fn.state_loss_partials(st))
+                                      loss_acc=None if det else Fn.state_loss_partials(st),
+                                      nonfinite=self._nonfinite if self.sanitize_grads else None)
                 rgb = g["rgb"]
                 Fn.merged_composite_backward(z_all, idx, out1v, out2v, None, g["d_depth"], g["d_acc"], d1o, d2o, d_wsum=g["d_wsum"],
                                              nonfinite=self._nonfinite if self.sanitize_grads else None, hs_scale=hs / R if hs > 0 else 0.0,

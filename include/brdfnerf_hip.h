@@ -365,7 +365,9 @@ int bn_merged_composite_backward(const float *z, const int64_t *sort_idx, const 
  * and d loss / d acc [R][C], d loss / d wsum [R], d loss / d depth [R] (the HardSurfaceLoss term's per-sample part is
  * bn_merged_composite_backward's hs_scale = lambda_hs / R).  kind: BN_SHADE_*; channels < 0: head absent (RPV: p0 k, p1
  * theta, p2 rhoc, or rhoc = albedo_s with rhoc_is_albedo (funcH == 2); Hapke: p0 b, p1 c, p2 theta (1 wide); microfacet: p0
- * roughness (1 wide)).  sun_d NULL: (1,1,1).  The prior arrays carry element strides and are nullable together. */
+ * roughness (1 wide)).  sun_d NULL: (1,1,1).  The prior arrays carry element strides and are nullable together.  nonfinite
+ * (nullable, [0] NaN [1] Inf counters): a ray whose loss term is not finite is left out (loss 0, gradients 0) and counted -
+ * without it the NaN reaches the loss and the gradients as it does upstream. */
 enum { BN_SHADE_LAMBERT = 0, BN_SHADE_RPV = 1, BN_SHADE_HAPKE = 2, BN_SHADE_MICROFACET = 3 };
 typedef struct {
   int32_t kind, C, ch_normal, ch_p0, ch_p1, ch_p2;
@@ -377,7 +379,7 @@ int bn_ray_shade_loss(const bn_shade_desc *desc, const float *acc, const float *
                       const float *valid_depth, int64_t v_stride, const float *target_depth, int64_t td_stride,
                       const float *target_weight, int64_t tw_stride, const float *target_std, int64_t ts_stride, int64_t R,
                       float *rgb, float *ray_loss, float *loss_acc, int32_t loss_slots, float *d_acc, float *d_wsum,
-                      float *d_depth, void *stream);
+                      float *d_depth, unsigned long long *nonfinite, void *stream);
 /* Ray-level tail of a Lambertian step in ONE launch: bn_merged_composite_forward + bn_lambert_loss (shading, SNerfLoss,
  * DepthLoss; metrics.py:39-61,82-161) + bn_merged_composite_backward.  The prior arrays carry element strides.  ray_loss [R]
  * (nullable) and/or loss_acc (nullable): ray r's term is atomically added to loss_acc[r % loss_slots] - partial sums the

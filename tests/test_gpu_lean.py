@@ -300,6 +300,43 @@ def test_ray_shade_loss_kernel_against_autograd_of_the_torch_statement(name, pri
     assert float((d1a - d1b).abs().max()) <= 2e-6 * float(d1b.abs().max())
 
 
+def test_ray_shade_loss_leaves_non_finite_rays_out_when_asked():
+    """A ray whose shaded value is NaN (here: NaN composited sums) poisons loss and gradients as upstream - unless the caller
+    passes the non-finite counters (FusedTrainer.sanitize_grads): then the ray contributes nothing and is counted."""
+    from test_gpu_parity import build_model, make_args
+    from brdf_nerf_amd import functions as Fn
+    from brdf_nerf_amd.rendering import shade_desc
+    cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16, b=1, c=1, theta=1, normal="learned")
+    args, model = make_args(cfg), build_model(cfg, 5)
+    spec = model.spec(True, True, True, False, beta=False)
+    R, S, C = 130, 16, spec.out_channels
+    g = torch.Generator().manual_seed(0)
+    rays = _sat_rays(R, g).to(DEV)
+    z = torch.sort(0.5 + torch.rand(R, S, generator=g), -1)[0].to(DEV).contiguous()
+    o = Fn.merged_composite_forward(z, None, _field_like(R, S, C, g), None, want=("weights", "depth", "acc", "wsum", "var"))
+    o["acc"][:, spec.ch_normal_lr:spec.ch_normal_lr + 3] = -rays[:, 3:6] * o["wsum"][:, None]
+    clean = o["acc"].clone()
+    bad = [3, 64, 129]
+    o["acc"][bad, 0] = float("nan")
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    desc = shade_desc(model, args, spec, True, True, 1.0, 0.0, 0.0, False)
+    ray_loss = torch.empty(R, device=DEV)
+    k0 = Fn.ray_shade_loss(desc, o["acc"], o["wsum"], o["depth"], o["var"], rays[:, 3:6], rays[:, 8:11], rgbs, ray_loss=ray_loss)
+    assert not bool(torch.isfinite(ray_loss.sum())) and not bool(torch.isfinite(k0["d_acc"][bad]).all())
+    cnt = torch.zeros(2, dtype=torch.int64, device=DEV)
+    ray_loss2 = torch.empty(R, device=DEV)
+    k1 = Fn.ray_shade_loss(desc, o["acc"], o["wsum"], o["depth"], o["var"], rays[:, 3:6], rays[:, 8:11], rgbs, ray_loss=ray_loss2,
+                           nonfinite=cnt)
+    assert cnt.tolist() == [3, 0]
+    assert bool(torch.isfinite(ray_loss2).all()) and float(ray_loss2[bad].abs().max()) == 0.0
+    assert float(k1["d_acc"][bad].abs().max()) == 0.0 and float(k1["d_wsum"][bad].abs().max()) == 0.0
+    ref = torch.empty(R, device=DEV)
+    k2 = Fn.ray_shade_loss(desc, clean, o["wsum"], o["depth"], o["var"], rays[:, 3:6], rays[:, 8:11], rgbs, ray_loss=ref)
+    ok = torch.ones(R, dtype=torch.bool, device=DEV)
+    ok[bad] = False
+    assert torch.equal(ray_loss2[ok], ref[ok]) and torch.equal(k1["d_acc"][ok], k2["d_acc"][ok])
+
+
 _REF_SHADE = {   # golden -> (model flags, step flags): the reference's own per-sample outputs of its render fixtures
     "render_rpv111_nlr_train": (dict(funcM=1, funcF=1, funcH=1, normal="learned"), True, True),
     "render_rpv111_nan_train": (dict(funcM=1, funcF=1, funcH=1, normal="analystic"), True, True),
