@@ -6,15 +6,20 @@ One "step" = one full training step on a batch of R rays per GPU:
   + SNerfLoss + DepthLoss (ds_lambda=10, README stage 1) + backward + [RCCL grad all-reduce] + Adam.
 Workload at N=1: BASELINE config 2 - Lambertian pretrain, 4096 rays x 64 samples (+64 guided), F=512, 8 Siren layers,
 PE(10), bf16 MFMA, synthetic satellite-shaped rays, random-init weights (seed 0).
-N>1: one process per GPU, gradients all-reduced over RCCL; `--scaling weak` (default) keeps 4096 rays per GPU,
-`--scaling strong` splits ONE 4096-ray batch N ways (north_star's "4096-ray/64-sample batches at 8 GPUs").
+The step is FusedTrainer's launch-lean one (own in-kernel draws, as brdf_nerf_amd.train.TrainLoop runs it): 12 kernel launches,
+no host synchronisation, replayed from a captured HIP graph at N = 1 once its inputs have kept their addresses for 3 steps.
+N>1: one process per GPU, gradients all-reduced over RCCL in two buckets overlapped with the rest of the backward; `value` is the
+weak-scaling rate (`--scaling weak`, default: 4096 rays per GPU) and the line carries a `strong` sub-record - ONE 4096-ray batch
+split N ways (north_star's "4096-ray/64-sample batches at 8 GPUs") next to the same shard timed on one rank alone, both in this
+invocation (`speedup_vs_n1_ms`); `--scaling strong` makes the strong shape the headline instead.
 
     python bench.py --gpus N --steps K --warmup W        # N > 1: this process spawns the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  Timing protocol: W warm-up steps, then untimed "settling" steps until the chip has been
-under this load for >= 1.5 s (DVFS settles over seconds), then EXACTLY K steps between barrier + synchronize pairs with
-no instrumentation inside; the per-kernel HIP-event times come from a SEPARATE pass after the timed one.  `roofline`
+Prints ONE JSON line (rank 0).  Timing protocol: W warm-up steps, two steady steps for an estimate, then untimed "settling"
+steps until the chip has run STEADY-STATE steps for >= 1.5 s (DVFS settles over seconds), then EXACTLY K steps between barrier +
+synchronize pairs with no instrumentation inside, then `sustained` (200 more steps, outside `value`); the per-kernel HIP-event
+times and `launches_per_step` come from a SEPARATE eager pass after the timed one.  `roofline`
 prices the kernel with the largest share of the step, as a fraction of the dense bf16/fp16 MFMA peak both by the
 reference network's algorithmic FLOPs and by the FLOPs the build executes (the linear feats layer is folded into the
 heads); `traffic` / `mfma_busy` come from the committed rocprofv3 PMC pass of the SAME kernel sources

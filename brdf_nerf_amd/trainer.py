@@ -54,7 +54,7 @@ class FusedTrainer:
                                         # field backward starts from) of a launch-lean step (tests; such steps are not captured)
         self.use_graph = True
         self.graph_after = 3            # eager steps with an unchanged signature before the step is captured
-        self._graphs, self._sig_seen, self._nf_dev = {}, {}, {}
+        self._graphs, self._sig_seen, self._nf_dev, self._no_graph = {}, {}, {}, set()
         self.state = Fn.new_step_state(self.flat_param.device, torch.initial_seed(), lr)
         self._rng_step, self._state_lr, self._grads_clean = 0, float(lr), True
         self._state_adam = [0, 0, 0, 0]
@@ -363,16 +363,24 @@ class FusedTrainer:
             else:
                 n = self._sig_seen.get(sig, 0) + 1
                 self._sig_seen[sig] = n
-                if n > self.graph_after and len(self._graphs) < 16:
+                if n > self.graph_after and len(self._graphs) < 16 and sig not in self._no_graph:
                     # keep the inputs alive with the graph: their addresses are baked into it
                     keep = (rays, rgbs, valid_depth, depths, depth_std, nf)
                     g = torch.cuda.CUDAGraph()
                     torch.cuda.synchronize()
-                    with torch.cuda.graph(g):
-                        out = body()
-                    self._graphs[sig] = (g, out, keep)
-                    g.replay()            # the capture itself does not execute: this is the step
-                    res = out
+                    try:
+                        with torch.cuda.graph(g):
+                            out = body()
+                    except Exception as e:      # a runtime that cannot capture this step: it stays eager (the capture launched nothing)
+                        import warnings
+                        warnings.warn(f"brdf_nerf_amd: HIP graph capture of the training step failed ({type(e).__name__}: {e}); "
+                                      f"this step signature runs eagerly")
+                        self._no_graph.add(sig)
+                        torch.cuda.synchronize()
+                    else:
+                        self._graphs[sig] = (g, out, keep)
+                        g.replay()            # the capture itself does not execute: this is the step
+                        res = out
         if res is None:
             res = body()
         self._grads_clean = not self.keep_grads

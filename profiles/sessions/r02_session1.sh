@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 GPU session 1 (gpurun -- bash profiles/r02_session1.sh): full GPU suite (with the parity error table), clock probe, MFMA-shape ablation, bench
+# round-2 GPU session 1 (gpurun -- bash profiles/sessions/r02_session1.sh): full GPU suite (with the parity error table), clock probe, MFMA-shape ablation, bench
 export BN_DIAG=$PWD/gpurun_out/r02_parity_errors.txt
 rm -f $BN_DIAG
 timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/t1.log 2>&1

@@ -6,4 +6,4 @@ timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "full_s
 echo "pytest rc=$?"; grep -n "^E  \|^FAILED\|passed\|failed" gpurun_out/r3t14.log | grep -v "where\|+  " | cut -c1-250 | head -30
 grep -h "started from" $BN_DIAG | cut -c1-250
 unset BN_DIAG
-bash profiles/r03_session13b.sh
+bash profiles/sessions/r03_session13b.sh
