@@ -1602,6 +1602,8 @@ def test_train_loop_with_beta_keeps_the_embedding(tmp_path):
     beta0 = {k: v.detach().clone() for k, v in loop.model.state_dict().items() if k.startswith("beta_from_xyz.")}
     losses_ = [float(loop.step()["loss"]) for _ in range(6)]
     assert losses_[-1] < losses_[0]
+    # batches are gathered into fixed staging buffers: the production loop replays captured steps, not only bench.py
+    assert len(loop.trainer._graphs) >= 1, "TrainLoop's steps were not captured into a HIP graph"
     assert torch.equal(loop.embedding_t.weight, emb0)
     assert all(torch.equal(loop.model.state_dict()[k], v) for k, v in beta0.items())
     path = loop.save(str(tmp_path / "ckpts"))
@@ -1815,10 +1817,12 @@ def test_full_size_render_and_train_step_properties(name):
         dropped = t.dropped_samples
         del t, m
 
-    def worst_cos(a, b):
+    def worst_cos(a, b, matrices_only=False):
         worst, worst_k = 1.0, ""
         for k, g32 in grads[a].items():
             if g32.numel() < 256 or float(g32.abs().max()) == 0.0:
+                continue
+            if matrices_only and (g32.dim() < 2 or g32.numel() < 4096):
                 continue
             c = float(torch.nn.functional.cosine_similarity(g32.flatten().double(), grads[b][k].flatten().double(), dim=0))
             if c < worst:
@@ -1845,9 +1849,15 @@ def test_full_size_render_and_train_step_properties(name):
         # ray-level shading and losses in fp32, and the ill-conditioning sits there (the BRDF Jacobian amplifies the 1e-3 difference
         # of the composited sums) - so the 16-bit field backward (chain, analytic-normal double backward, weight gradients, at full
         # width and batch) is started from the SAME per-sample gradient rows as the fp32 mode's and must reproduce its gradient
-        seeded, seeded_k = worst_cos("fp32", dtype + "_seeded")
-        diag(f"full size {name} ({dtype}): worst per-matrix gradient cosine of the {dtype} field backward started from the fp32 mode's "
-             f"gradient rows {seeded:.5f} ({seeded_k})")
+        # (weight MATRICES: a bias vector's gradient is a signed sum over all points of the batch that nearly cancels - its cosine
+        # scatters between 0.98 and 0.9999 from run to run in either 16-bit mode and says little; it is reported with the rest)
+        seeded, seeded_k = worst_cos("fp32", dtype + "_seeded", matrices_only=True)
+        seeded_all, seeded_all_k = worst_cos("fp32", dtype + "_seeded")
+        flat = lambda tag_: torch.cat([v.flatten().double() for v in grads[tag_].values()])
+        whole = float(torch.nn.functional.cosine_similarity(flat("fp32"), flat(dtype + "_seeded"), dim=0))
+        diag(f"full size {name} ({dtype}): {dtype} field backward started from the fp32 mode's gradient rows - worst weight-matrix gradient "
+             f"cosine {seeded:.5f} ({seeded_k}), worst of all parameters {seeded_all:.5f} ({seeded_all_k}), whole flat gradient {whole:.6f}")
+        assert whole >= 0.995, whole
         # (bf16 through the analytic-normal double backward: 8 significant bits over two chained passes, and the first layer's
         # gradient carries the w0^2 = 900 hand-over of that chain - measured 0.980 .. 0.999 for fc_net.0.weight between runs whose
         # 150 bf16 pretraining steps ended in different states (fp32 atomics); every other combination 0.997 .. 0.9997)
