@@ -41,7 +41,7 @@ def main():
         tr.use_graph = False              # the per-kernel events live in the library's launch sites: eager steps
         for kv in filter(None, attrs.split(",")):
             k, v = kv.split("=")
-            setattr(tr, k, {"True": True, "False": False}.get(v, v))
+            setattr(tr, k, {"True": True, "False": False}.get(v, int(v) if v.lstrip("-").isdigit() else v))
         variants[tag] = (h, args, model, tr)
     b = bench.synthetic_batch(n_rays, 1, dev)
     flags = bench.CONFIG_FLAGS[config][1]
