@@ -82,8 +82,13 @@ def main():
     scale = float(want.abs().max())
     err = float((got - want).abs().max())
     perr = float((tr2.flat_param - tr1.flat_param).abs().max())
-    ok = scale > 0 and err <= 2e-5 * scale and perr <= 1e-6
-    print(f"RESULT rank {rank} {name}: grad err {err:.3e} of {scale:.3e}, param err after Adam {perr:.3e} -> {'ok' if ok else 'FAIL'}", flush=True)
+    pmean = float((tr2.flat_param - tr1.flat_param).abs().mean())
+    # (the first Adam step moves every parameter by lr g / (|g| + eps): where |g| is of the order of eps = 1e-8, a 1e-8 difference
+    # of the summed gradient - the order two ranks add their halves in - changes the step by a fraction of lr; everywhere else
+    # the parameters agree to rounding: bounded by lr in the maximum, held to 1e-7 in the mean)
+    ok = scale > 0 and err <= 2e-5 * scale and perr <= 1.05 * tr1.lr and pmean <= 1e-7
+    print(f"RESULT rank {rank} {name}: grad err {err:.3e} of {scale:.3e}, param err after Adam max {perr:.3e} mean {pmean:.3e} -> "
+          f"{'ok' if ok else 'FAIL'}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
