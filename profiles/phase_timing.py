@@ -20,7 +20,7 @@ def build_timing(defines=(), tag=""):
     for src in TIMED:
         obj = os.path.join(objdir, f"{src}.timing{tag}.o")
         objs.append(obj)
-        procs.append(subprocess.Popen([B.HIPCC] + B.FLAGS + ["-DBN_PHASE_TIMING"] + ["-D" + d for d in defines] +
+        procs.append(subprocess.Popen([B.HIPCC] + B.FLAGS + list(B.FILE_FLAGS.get(src, ())) + ["-DBN_PHASE_TIMING"] + ["-D" + d for d in defines] +
                                       ["-x", "hip", "-c", os.path.join(B.CSRC, src), "-o", obj]))
     assert all(p.wait() == 0 for p in procs)
     lib = os.path.join(objdir, f"libbn_timing{tag}.so")
