@@ -60,6 +60,11 @@ class ShadeDesc(C.Structure):         # bn_shade_desc
 BN_SHADE_LAMBERT, BN_SHADE_RPV, BN_SHADE_HAPKE, BN_SHADE_MICROFACET = 0, 1, 2, 3
 
 
+class NormalReg(C.Structure):         # bn_normal_reg
+    _fields_ = [("rays_d", fptr), ("rd_stride", C.c_int64), ("ch_an", C.c_int32), ("ch_lr", C.c_int32),
+                ("lambda_an", C.c_float), ("lambda_lr", C.c_float)]
+
+
 class FoldDesc(C.Structure):          # bn_fold_desc
     _fields_ = [("n_heads", C.c_int32), ("F", C.c_int32), ("rows", C.c_int32), ("wf", fptr), ("bf", fptr),
                 ("w1", fptr * BN_MAX_HEADS), ("w1_ld", C.c_int64 * BN_MAX_HEADS), ("b1", fptr * BN_MAX_HEADS),
@@ -123,12 +128,12 @@ _SIGS = {
                                       fptr, C.c_int64, fptr, C.c_int64, fptr, fptr, fptr, C.c_uint32, C.c_uint32, C.c_int64, fptr, fptr,
                                       fptr, fptr, fptr, fptr]),
     "bn_merged_composite_forward": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, fptr,
-                                              fptr, fptr, fptr, fptr, fptr]),
+                                              fptr, fptr, fptr, fptr, fptr, fptr, fptr]),
     "bn_merged_composite_backward": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, fptr,
-                                               fptr, C.c_float, fptr, fptr, fptr, fptr, fptr]),
+                                               fptr, C.c_float, fptr, fptr, fptr, fptr, fptr, fptr]),
     "bn_ray_shade_loss": (C.c_int, [fptr, fptr, fptr, fptr, fptr, fptr, C.c_int64, fptr, C.c_int64, fptr, fptr, C.c_int64, fptr,
                                     C.c_int64, fptr, C.c_int64, fptr, C.c_int64, C.c_int64, fptr, fptr, fptr, C.c_int32, fptr, fptr,
-                                    fptr, fptr, fptr]),
+                                    fptr, fptr, fptr, fptr]),
     "bn_lambert_tail": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, C.c_int64, fptr,
                                   C.c_int64, fptr, C.c_int64, fptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, fptr, fptr,
                                   C.c_int32, fptr, fptr, fptr, fptr, fptr, fptr]),

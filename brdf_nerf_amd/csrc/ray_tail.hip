@@ -27,6 +27,7 @@ struct ShadeArgs {
   float *rgb, *ray_loss, *loss_acc;
   int loss_slots;
   float *d_acc, *d_wsum, *d_depth;
+  const float *extra_loss;              // nullable: per-ray loss terms computed elsewhere (NormalRegLoss of the compositing kernel)
   unsigned long long *nonfinite;        // nullable: a ray whose loss term is not finite contributes nothing (loss 0, gradients 0) and is counted
 };
 
@@ -125,6 +126,7 @@ template <int KIND> __global__ __launch_bounds__(64) void ray_shade_loss_kernel(
   // do not cover) makes the reference's loss NaN and its whole gradient with it.  With `nonfinite` (FusedTrainer.sanitize_grads)
   // such a ray is left out of the step - loss term 0, gradients 0 - and counted, like the non-finite gradient elements the
   // composite backward drops.
+  if (A.extra_loss) loss += A.extra_loss[ray];
   const bool drop = A.nonfinite && !(fabsf(loss) <= 3.0e38f);
   if (drop) { atomicAdd(A.nonfinite + (isnan(loss) ? 0 : 1), 1ull); loss = 0.f; }
   if (A.ray_loss) A.ray_loss[ray] = loss;
@@ -171,7 +173,7 @@ extern "C" int bn_ray_shade_loss(const bn_shade_desc *desc, const float *acc, co
                                  const float *valid_depth, int64_t v_stride, const float *target_depth, int64_t td_stride,
                                  const float *target_weight, int64_t tw_stride, const float *target_std, int64_t ts_stride, int64_t R,
                                  float *rgb, float *ray_loss, float *loss_acc, int32_t loss_slots, float *d_acc, float *d_wsum,
-                                 float *d_depth, unsigned long long *nonfinite, void *stream) {
+                                 float *d_depth, unsigned long long *nonfinite, const float *extra_loss, void *stream) {
   BN_REQUIRE(desc && acc && wsum && depth && rgbs && d_acc && d_wsum && d_depth && R > 0, "ray_shade_loss: null argument");
   const bn_shade_desc &q = *desc;
   BN_REQUIRE(q.C >= 4 && q.C <= BN_MAX_CH, "ray_shade_loss: C=%d unsupported", q.C);
@@ -194,7 +196,7 @@ extern "C" int bn_ray_shade_loss(const bn_shade_desc *desc, const float *acc, co
   a.sd_stride = sd_stride; a.rgbs = rgbs; a.valid = valid_depth; a.tdepth = target_depth; a.tweight = target_weight; a.tstd = target_std;
   a.v_stride = v_stride; a.td_stride = td_stride; a.tw_stride = tw_stride; a.ts_stride = ts_stride; a.R = R; a.rgb = rgb;
   a.ray_loss = ray_loss; a.loss_acc = loss_acc; a.loss_slots = loss_slots > 0 ? loss_slots : 1; a.d_acc = d_acc; a.d_wsum = d_wsum;
-  a.d_depth = d_depth; a.nonfinite = nonfinite;
+  a.d_depth = d_depth; a.nonfinite = nonfinite; a.extra_loss = extra_loss;
   const dim3 grid((unsigned)ceil_div64(R, 64));
   hipStream_t st = (hipStream_t)stream;
   BnProfScope prof_(BN_K_BRDF, st);

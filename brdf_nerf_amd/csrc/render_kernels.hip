@@ -792,6 +792,9 @@ struct MergedArgs {
   // MODE 2
   const float *d_weights, *d_depth, *d_acc, *d_wsum, *depth_in;
   float hs_scale;
+  // MODE 0, 2: NormalRegLoss (metrics.py:179-216) on the per-sample normals: lambda * sum_s w_s min(0, n_s . view)^2, view = -rays_d
+  bn_normal_reg nreg;              // rays_d == nullptr: off
+  float *reg_out;                  // MODE 0: the ray's regulariser term (both normal fields, lambdas applied)
   // MODE 1, 2
   float *d_out1, *d_out2;
   unsigned long long *nonfinite;   // nullable: zero non-finite gradient elements and count them ([0] NaN, [1] Inf)
@@ -876,6 +879,30 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
       }
       if (MODE == 1 && A.acc && lane == 0) A.acc[ray * C + 3] = 0.f;
     }
+    if (MODE == 0 && A.nreg.rays_d && A.reg_out) {
+      const float *rd = A.nreg.rays_d + ray * A.nreg.rd_stride;
+      const float vx = -rd[0], vy = -rd[1], vz = -rd[2];
+      float reg = 0.f;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int c0 = f == 0 ? A.nreg.ch_an : A.nreg.ch_lr;
+        const float lam = f == 0 ? A.nreg.lambda_an : A.nreg.lambda_lr;
+        if (c0 < 0 || !(lam > 0.f)) continue;
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < BN_MAX_CPL; ++j) {
+          const int s = lane * cpl + j;
+          if (j < cpl && s < S) {
+            const float *row = rowp(roff[j]);
+            const float nv = fminf(row[c0] * vx + row[c0 + 1] * vy + row[c0 + 2] * vz, 0.f);
+            part += w[j] * nv * nv;
+          }
+        }
+        reg += lam * part;
+      }
+      reg = wave_sum(reg);
+      if (lane == 0) A.reg_out[ray] = reg;
+    }
     float var = 0.f;
     if (MODE == 1 || A.var) {
 #pragma unroll
@@ -922,6 +949,9 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
   // ---- backward: g_s = dL/dw_s; dL/dalpha_s = g_s T_s - (1/u_s) sum_{k>s} g_k w_k   
   const int ng = MODE == 1 ? 3 : C;
   const float hs = MODE == 2 ? A.hs_scale : 0.f, hs_depth = (MODE == 2 && A.hs_scale != 0.f) ? A.depth_in[ray] : 0.f;
+  const bool nreg_on = MODE == 2 && A.nreg.rays_d != nullptr;
+  float nvx = 0.f, nvy = 0.f, nvz = 0.f;
+  if (nreg_on) { const float *rd = A.nreg.rays_d + ray * A.nreg.rd_stride; nvx = -rd[0]; nvy = -rd[1]; nvz = -rd[2]; }
   float g[BN_MAX_CPL], gw = 0.f;
 #pragma unroll
   for (int j = 0; j < BN_MAX_CPL; ++j) {
@@ -931,6 +961,16 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
       float gg = dd * zv[j] + dws;
       if (MODE == 2 && A.d_weights) gg += A.d_weights[ray * S + s];
       if (MODE == 2 && hs != 0.f) { const float dz = zv[j] - hs_depth; gg += hs * (dz * dz); }
+      if (MODE == 2 && nreg_on) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const int c0 = f == 0 ? A.nreg.ch_an : A.nreg.ch_lr;
+          const float lam = f == 0 ? A.nreg.lambda_an : A.nreg.lambda_lr;
+          if (c0 < 0 || !(lam > 0.f)) continue;
+          const float nv = fminf(chan(j, c0) * nvx + chan(j, c0 + 1) * nvy + chan(j, c0 + 2) * nvz, 0.f);
+          gg += lam * nv * nv;
+        }
+      }
       for (int c = 0; c < ng; ++c)
         if (c != 3) gg += dacc[c] * chan(j, c);
       g[j] = gg;
@@ -957,8 +997,24 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
         }
         *(f32x4 *)drow = o;
       } else {
+        float nr_g[2] = {0.f, 0.f};        // 2 lambda w_s min(0, n_s . view): times view[c - c0] on the normal's channels
+        if (nreg_on) {
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const int c0 = f == 0 ? A.nreg.ch_an : A.nreg.ch_lr;
+            const float lam = f == 0 ? A.nreg.lambda_an : A.nreg.lambda_lr;
+            if (c0 < 0 || !(lam > 0.f)) continue;
+            const float nv = fminf(chan(j, c0) * nvx + chan(j, c0 + 1) * nvy + chan(j, c0 + 2) * nvz, 0.f);
+            nr_g[f] = 2.f * lam * w[j] * nv;
+          }
+        }
         for (int c = 0; c < C; ++c) {
           float v = c == 3 ? dalpha * dad[j] : (c < ng ? w[j] * dacc[c] : 0.f);
+          if (nreg_on) {
+            const int ca = c - A.nreg.ch_an, cl = c - A.nreg.ch_lr;
+            if (A.nreg.ch_an >= 0 && ca >= 0 && ca < 3) v += nr_g[0] * (ca == 0 ? nvx : ca == 1 ? nvy : nvz);
+            if (A.nreg.ch_lr >= 0 && cl >= 0 && cl < 3) v += nr_g[1] * (cl == 0 ? nvx : cl == 1 ? nvy : nvz);
+          }
           if (A.nonfinite) {
             if (isnan(v)) { ++n_nan; v = 0.f; }
             else if (isinf(v)) { ++n_inf; v = 0.f; }
@@ -989,10 +1045,16 @@ static bool merged_c4(const MergedArgs &a) {
 
 extern "C" int bn_merged_composite_forward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
                                            int32_t S2, int32_t C, int64_t R, float *alphas, float *trans, float *weights, float *depth,
-                                           float *acc, float *wsum, float *var, void *stream) {
+                                           float *acc, float *wsum, float *var, const bn_normal_reg *nreg, float *reg_out,
+                                           void *stream) {
   MergedArgs a = {};
   a.z = z; a.idx = sort_idx; a.out1 = out1; a.out2 = out2; a.S1 = S1; a.S2 = S2; a.C = C; a.R = R;
   a.alphas = alphas; a.trans = trans; a.weights = weights; a.depth = depth; a.acc = acc; a.wsum = wsum; a.var = var;
+  if (nreg && nreg->rays_d) {
+    BN_REQUIRE(reg_out && (nreg->ch_an < 0 || (nreg->ch_an >= 4 && nreg->ch_an + 3 <= C)) && (nreg->ch_lr < 0 || (nreg->ch_lr >= 4 && nreg->ch_lr + 3 <= C)),
+               "merged_composite_forward: bad normal-regulariser channels (%d, %d)", nreg->ch_an, nreg->ch_lr);
+    a.nreg = *nreg; a.reg_out = reg_out;
+  }
   if (int e = merged_check(a, "merged_composite_forward")) return e;
   BnProfScope prof_(BN_K_COMPOSITE_FWD, (hipStream_t)stream);
   if (merged_c4(a)) merged_composite_kernel<0, true><<<MERGED_GRID(R)>>>(a);
@@ -1004,11 +1066,17 @@ extern "C" int bn_merged_composite_forward(const float *z, const int64_t *sort_i
 extern "C" int bn_merged_composite_backward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
                                             int32_t S2, int32_t C, int64_t R, const float *d_weights, const float *d_depth,
                                             const float *d_acc, const float *d_wsum, float hs_scale, const float *depth,
-                                            float *d_out1, float *d_out2, unsigned long long *nonfinite, void *stream) {
+                                            const bn_normal_reg *nreg, float *d_out1, float *d_out2, unsigned long long *nonfinite,
+                                            void *stream) {
   MergedArgs a = {};
   a.z = z; a.idx = sort_idx; a.out1 = out1; a.out2 = out2; a.S1 = S1; a.S2 = S2; a.C = C; a.R = R;
   a.d_weights = d_weights; a.d_depth = d_depth; a.d_acc = d_acc; a.d_wsum = d_wsum; a.d_out1 = d_out1; a.d_out2 = d_out2;
   a.nonfinite = nonfinite; a.hs_scale = hs_scale; a.depth_in = depth;
+  if (nreg && nreg->rays_d) {
+    BN_REQUIRE((nreg->ch_an < 0 || (nreg->ch_an >= 4 && nreg->ch_an + 3 <= C)) && (nreg->ch_lr < 0 || (nreg->ch_lr >= 4 && nreg->ch_lr + 3 <= C)),
+               "merged_composite_backward: bad normal-regulariser channels (%d, %d)", nreg->ch_an, nreg->ch_lr);
+    a.nreg = *nreg;
+  }
   if (int e = merged_check(a, "merged_composite_backward")) return e;
   BN_REQUIRE(hs_scale == 0.f || depth, "merged_composite_backward: hs_scale needs the forward's depth");
   BN_REQUIRE(d_out1 && (S1 == S2 || d_out2), "merged_composite_backward: null gradient buffer");

@@ -552,36 +552,56 @@ def composite_guided(z, out1, G, near_far, d_range, use_target=None, target_dept
     return (z2, z_all, idx, w1, d1) if want_pass1 else (z2, z_all, idx)
 
 
-def merged_composite_forward(z_all, idx, out1, out2, bufs=None, want=("weights", "depth", "acc")):
+def normal_reg(rays_d, ch_an, ch_lr, lambda_an, lambda_lr):
+    """bn_normal_reg: NormalRegLoss (metrics.py:179-216) inside the merged-set compositing; rays_d (R,3) view with unit inner
+    stride.  None when no field is regularised."""
+    on_an, on_lr = ch_an >= 0 and lambda_an > 0, ch_lr >= 0 and lambda_lr > 0
+    if not (on_an or on_lr):
+        return None
+    assert rays_d.is_cuda and rays_d.dtype == torch.float32 and rays_d.dim() == 2 and rays_d.stride(1) == 1
+    nr = L.NormalReg()
+    nr.rays_d, nr.rd_stride = rays_d.data_ptr(), rays_d.stride(0)
+    nr.ch_an, nr.ch_lr = (ch_an if on_an else -1), (ch_lr if on_lr else -1)
+    nr.lambda_an, nr.lambda_lr = float(lambda_an), float(lambda_lr)
+    nr._keep = rays_d
+    return nr
+
+
+def merged_composite_forward(z_all, idx, out1, out2, bufs=None, want=("weights", "depth", "acc"), nreg=None):
     """Compositing of the depth-sorted union of out1 [R][S1][C] and out2 [R][G][C] read through sort_idx (no cat / gather).
-    -> dict with the requested entries of alphas, trans, weights, depth, acc, wsum."""
+    -> dict with the requested entries of alphas, trans, weights, depth, acc, wsum, var (+ reg: the rays' NormalRegLoss terms,
+    with nreg = normal_reg(...))."""
     R, S2 = z_all.shape
     S1, Cc = out1.shape[1], out1.shape[2]
     dev = z_all.device
     b = bufs if bufs is not None else {}
-    shapes = dict(alphas=(R, S2), trans=(R, S2), weights=(R, S2), depth=(R,), acc=(R, Cc), wsum=(R,), var=(R,))
+    shapes = dict(alphas=(R, S2), trans=(R, S2), weights=(R, S2), depth=(R,), acc=(R, Cc), wsum=(R,), var=(R,), reg=(R,))
+    want = tuple(want) + (("reg",) if (nreg is not None and "reg" not in want) else ())
     o = {k: (b[k] if k in b else torch.empty(shapes[k], dtype=torch.float32, device=dev)) for k in want}
     g = lambda k: _p(o.get(k))
     L.check(L.lib().bn_merged_composite_forward(_p(z_all), _p(idx), _p(out1), _p(out2), S1, S2, Cc, R, g("alphas"), g("trans"),
-                                                g("weights"), g("depth"), g("acc"), g("wsum"), g("var"), _stream()),
+                                                g("weights"), g("depth"), g("acc"), g("wsum"), g("var"),
+                                                None if nreg is None else C.byref(nreg), g("reg") if nreg is not None else None,
+                                                _stream()),
             "bn_merged_composite_forward")
     return o
 
 
 def merged_composite_backward(z_all, idx, out1, out2, d_weights, d_depth, d_acc, d_out1, d_out2, d_wsum=None, nonfinite=None,
-                              hs_scale=0.0, depth=None):
+                              hs_scale=0.0, depth=None, nreg=None):
     """Gradient rows in the SOURCE layouts (d_out1 [R][S1][C], d_out2 [R][G][C]); channel 3 receives d sigma.  hs_scale (with
     the forward's depth): + hs_scale (z - depth)^2 on d loss / d w (HardSurfaceLoss, see ray_shade_loss)."""
     R, S2 = z_all.shape
     S1, Cc = out1.shape[1], out1.shape[2]
     L.check(L.lib().bn_merged_composite_backward(_p(z_all), _p(idx), _p(out1), _p(out2), S1, S2, Cc, R, _p(d_weights), _p(d_depth),
-                                                 _p(d_acc), _p(d_wsum), float(hs_scale), _p(depth if hs_scale else None), _p(d_out1),
-                                                 _p(d_out2), _p(nonfinite), _stream()),
+                                                 _p(d_acc), _p(d_wsum), float(hs_scale), _p(depth if hs_scale else None),
+                                                 None if nreg is None else C.byref(nreg), _p(d_out1), _p(d_out2), _p(nonfinite),
+                                                 _stream()),
             "bn_merged_composite_backward")
 
 
 def ray_shade_loss(desc, acc, wsum, depth, var, rays_d, sun_d, rgbs, bufs=None, valid_depth=None, target_depth=None,
-                   target_weight=None, target_std=None, ray_loss=None, loss_acc=None, nonfinite=None):
+                   target_weight=None, target_std=None, ray_loss=None, loss_acc=None, nonfinite=None, extra_loss=None):
     """Ray-level shading + SNerfLoss + DepthLoss + HardSurfaceLoss and their gradients w.r.t. the composited sums in one
     launch (bn_ray_shade_loss).  desc: L.ShadeDesc (rendering.shade_desc).  rays_d / sun_d: (R,3) views with unit inner
     stride (sun_d None: ones).  nonfinite (int64[2]): rays with a non-finite loss term are left out of the step and counted.
@@ -608,7 +628,7 @@ def ray_shade_loss(desc, acc, wsum, depth, var, rays_d, sun_d, rgbs, bufs=None, 
     L.check(L.lib().bn_ray_shade_loss(C.byref(desc), _p(acc), _p(wsum), _p(depth), _p(var), rdp, rds, sdp, sds, _p(rgbs), vp, vs, tdp, tds,
                                       twp, tws, tsp, tss, R, _p(o["rgb"]), _p(ray_loss), _p(loss_acc),
                                       0 if loss_acc is None else loss_acc.numel(), _p(o["d_acc"]), _p(o["d_wsum"]), _p(o["d_depth"]),
-                                      _p(nonfinite), _stream()), "bn_ray_shade_loss")
+                                      _p(nonfinite), _p(extra_loss), _stream()), "bn_ray_shade_loss")
     return o
 
 

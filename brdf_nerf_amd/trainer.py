@@ -144,9 +144,8 @@ class FusedTrainer:
         dev = rays.device
         spec = model.spec(apply_brdf, apply_theta, self.nr_lr, self.nr_an, beta=False)   # (field.py spec(): the loss never reads beta)
         reg0 = self.reg if regularisers else {}
-        # (a loss that reads per-sample channels of the merged set - MultiBRDF, the normal regularisers - keeps the general path)
-        per_sample0 = (bool(model.MultiBRDF) and apply_brdf) or any(reg0.get(k, 0) > 0 for k in ("nr_an", "nr_lr")) or \
-            abs(reg0.get("nr_spv", 0)) > 1e-5
+        # (a loss that reads per-sample channels of the merged set beyond NormalRegLoss - MultiBRDF, NormalLoss - keeps the general path)
+        per_sample0 = (bool(model.MultiBRDF) and apply_brdf) or abs(reg0.get("nr_spv", 0)) > 1e-5
         if (self.lean and not self.strict_rng and args.noise_std == 0 and not gsam_only and self.reuse_coarse and not per_sample0
                 and not (getattr(model, "sun_v", "none") == "analystic" and apply_brdf)
                 and rays.dtype == torch.float32 and rays.is_contiguous() and rays.shape[1] >= 8 and S + G <= 512):
@@ -355,7 +354,8 @@ class FusedTrainer:
                    None if depths is None else depths.data_ptr(), None if depth_std is None else depth_std.data_ptr(),
                    nf.data_ptr(), use_ds, tuple(active), float(self.ds_lambda), float(self.lambda_rgb), bool(self.usealldepth),
                    L.deterministic(), int(self.ray_offset), bool(self.keep_grads), bool(self.merge_passes), bool(apply_brdf),
-                   bool(cos_irra_on), float(reg.get("hs", 0)), bool(self.sanitize_grads))
+                   bool(cos_irra_on), float(reg.get("hs", 0)), bool(self.sanitize_grads), float(reg.get("nr_an", 0)),
+                   float(reg.get("nr_lr", 0)))
             ent = self._graphs.get(sig)
             if ent is not None:
                 ent[0].replay()
@@ -457,11 +457,14 @@ class FusedTrainer:
                               hs, self.usealldepth)
             det = L.deterministic()
             ray_loss = self._buf("ray_loss", (R,)) if det else None
+            # NormalRegLoss on the per-sample normals (metrics.py:179-216): its value and gradient come from the compositing kernels
+            nreg = Fn.normal_reg(rays[:, 3:6], spec.ch_normal_an if spec.normal_an else -1, spec.ch_normal_lr if spec.normal_lr else -1,
+                                 float(reg.get("nr_an", 0)), float(reg.get("nr_lr", 0)))
             with torch.no_grad():
                 o = Fn.merged_composite_forward(z_all, idx, out1v, out2v,
                                                 {k: self._buf("m_" + k, sh) for k, sh in (("depth", (R,)), ("acc", (R, C)),
-                                                                                          ("wsum", (R,)), ("var", (R,)))},
-                                                want=("depth", "acc", "wsum", "var"))
+                                                                                          ("wsum", (R,)), ("var", (R,)), ("reg", (R,)))},
+                                                want=("depth", "acc", "wsum", "var"), nreg=nreg)
                 sun_d = rays[:, 8:11] if args.data == "sat" else None
                 sb = {k: self._buf("s_" + k, sh) for k, sh in (("rgb", (R, 3)), ("d_acc", (R, C)), ("d_wsum", (R,)),
                                                                ("d_depth", (R,)))}
@@ -469,11 +472,11 @@ class FusedTrainer:
                                       valid_depth if use_ds else None, depths[:, 0] if use_ds else None,
                                       depths[:, 1] if use_ds else None, depth_std if use_ds else None, ray_loss=ray_loss,
                                       loss_acc=None if det else Fn.state_loss_partials(st),
-                                      nonfinite=self._nonfinite if self.sanitize_grads else None)
+                                      nonfinite=self._nonfinite if self.sanitize_grads else None, extra_loss=o.get("reg"))
                 rgb = g["rgb"]
                 Fn.merged_composite_backward(z_all, idx, out1v, out2v, None, g["d_depth"], g["d_acc"], d1o, d2o, d_wsum=g["d_wsum"],
                                              nonfinite=self._nonfinite if self.sanitize_grads else None, hs_scale=hs / R if hs > 0 else 0.0,
-                                             depth=o["depth"])
+                                             depth=o["depth"], nreg=nreg)
                 if det:
                     loss = ray_loss.sum()
         if self.seed_hook is not None:       # test hook: sees (and may overwrite) the gradient rows [R (S + G)][C] the field backward starts from

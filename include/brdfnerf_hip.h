@@ -346,15 +346,26 @@ int bn_composite_guided(const float *z, const float *sigma, int64_t sigma_stride
  * sum_s w.  Backward: from d_weights [R][S2], d_depth [R], d_acc [R][C] (d_acc[:, 3] ignored), d_wsum [R] (all nullable)
  * to the gradient rows d_out1 / d_out2 in the SOURCE layouts (channel 3 = d sigma).  nonfinite (nullable): NaN / Inf
  * gradient elements are written as 0 and counted ([0] NaN, [1] Inf) - FusedTrainer.sanitize_grads without extra passes. */
+/* NormalRegLoss (metrics.py:179-216) inside the merged-set compositing: lambda_an sum_s w_s min(0, n_an,s . view)^2 + the same
+ * for the learned normals, view = -rays_d [R] rows with element stride rd_stride; channel < 0 or lambda <= 0: that field is off.
+ * The forward writes the ray's term to reg_out [R] (an extra loss term for bn_ray_shade_loss), the backward adds its gradient
+ * w.r.t. the weights and the per-sample normal channels.  NULL (or rays_d == NULL): off. */
+typedef struct {
+  const float *rays_d;
+  int64_t rd_stride;
+  int32_t ch_an, ch_lr;
+  float lambda_an, lambda_lr;
+} bn_normal_reg;
 int bn_merged_composite_forward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
                                 int32_t S2, int32_t C, int64_t R, float *alphas, float *trans, float *weights, float *depth,
-                                float *acc, float *wsum, float *var, void *stream);
+                                float *acc, float *wsum, float *var, const bn_normal_reg *nreg, float *reg_out, void *stream);
 /* hs_scale != 0 (with depth [R], the forward's result): adds hs_scale (z_s - depth)^2 to d loss / d w_s - the per-sample part
  * of HardSurfaceLoss's gradient (metrics.py:263-290), see bn_ray_shade_loss. */
 int bn_merged_composite_backward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
                                  int32_t S2, int32_t C, int64_t R, const float *d_weights, const float *d_depth,
-                                 const float *d_acc, const float *d_wsum, float hs_scale, const float *depth, float *d_out1,
-                                 float *d_out2, unsigned long long *nonfinite, void *stream);
+                                 const float *d_acc, const float *d_wsum, float hs_scale, const float *depth,
+                                 const bn_normal_reg *nreg, float *d_out1, float *d_out2, unsigned long long *nonfinite,
+                                 void *stream);
 
 /* Ray-level shading + losses of a training step whose rays have ONE BRDF each (MultiBRDF == 0) and no per-sample
  * irradiance, forward AND backward in one launch (one thread per ray), between bn_merged_composite_forward and
@@ -367,7 +378,8 @@ int bn_merged_composite_backward(const float *z, const int64_t *sort_idx, const 
  * theta, p2 rhoc, or rhoc = albedo_s with rhoc_is_albedo (funcH == 2); Hapke: p0 b, p1 c, p2 theta (1 wide); microfacet: p0
  * roughness (1 wide)).  sun_d NULL: (1,1,1).  The prior arrays carry element strides and are nullable together.  nonfinite
  * (nullable, [0] NaN [1] Inf counters): a ray whose loss term is not finite is left out (loss 0, gradients 0) and counted -
- * without it the NaN reaches the loss and the gradients as it does upstream. */
+ * without it the NaN reaches the loss and the gradients as it does upstream.  extra_loss [R] (nullable): per-ray terms computed
+ * elsewhere that belong to the step's loss (bn_merged_composite_forward's reg_out), added to the ray's term. */
 enum { BN_SHADE_LAMBERT = 0, BN_SHADE_RPV = 1, BN_SHADE_HAPKE = 2, BN_SHADE_MICROFACET = 3 };
 typedef struct {
   int32_t kind, C, ch_normal, ch_p0, ch_p1, ch_p2;
@@ -379,7 +391,7 @@ int bn_ray_shade_loss(const bn_shade_desc *desc, const float *acc, const float *
                       const float *valid_depth, int64_t v_stride, const float *target_depth, int64_t td_stride,
                       const float *target_weight, int64_t tw_stride, const float *target_std, int64_t ts_stride, int64_t R,
                       float *rgb, float *ray_loss, float *loss_acc, int32_t loss_slots, float *d_acc, float *d_wsum,
-                      float *d_depth, unsigned long long *nonfinite, void *stream);
+                      float *d_depth, unsigned long long *nonfinite, const float *extra_loss, void *stream);
 /* Ray-level tail of a Lambertian step in ONE launch: bn_merged_composite_forward + bn_lambert_loss (shading, SNerfLoss,
  * DepthLoss; metrics.py:39-61,82-161) + bn_merged_composite_backward.  The prior arrays carry element strides.  ray_loss [R]
  * (nullable) and/or loss_acc (nullable): ray r's term is atomically added to loss_acc[r % loss_slots] - partial sums the

@@ -711,7 +711,7 @@ def test_random_lean_step_against_general_step(seed):
     kernel, fold / unfold / multi-group Adam kernels; the third step replayed from its HIP graph) on random configurations
     against the general step (held to the autograd path by test_random_fused_step_against_autograd_path) fed with the Philox
     streams' draws as arrays: loss, rgb and the flat gradient, three steps resynchronised one by one.  Random width / depth /
-    Siren or ReLU / heads / normals / funcH / shell_hapke, depth priors, hard-surface lambda, ragged ray and sample counts."""
+    Siren or ReLU / heads / normals / funcH / shell_hapke, depth priors, hard-surface and normal-regulariser lambdas, ragged ray and sample counts."""
     import brdf_nerf_amd
     from test_gpu_parity import build_model, make_args, Replay, diag
     from brdf_nerf_amd import functions as Fn
@@ -729,6 +729,7 @@ def test_random_lean_step_against_general_step(seed):
     R = int(rng.integers(8, 120))
     flags = dict(apply_brdf=brdf and bool(rng.random() < 0.85), apply_theta=bool(rng.random() < 0.7), cos_irra_on=bool(rng.random() < 0.6))
     hs = float(rng.choice([0.0, 0.3]))
+    lam = dict(hs_lambda=hs, nr_reg_an_lambda=float(rng.choice([0.0, 0.2])), nr_reg_lr_lambda=float(rng.choice([0.0, 0.1])))
     g = torch.Generator().manual_seed(seed)
     rays = _sat_rays(R, g).to(DEV)
     rgbs = torch.rand(R, 3, generator=g).to(DEV)
@@ -739,12 +740,12 @@ def test_random_lean_step_against_general_step(seed):
                      depth_std=(0.03 * torch.rand(R, generator=g)).to(DEV))
     tag = (f"fuzz-lean {seed}: F={cfg.feat} L={cfg.layers} siren={int(cfg.siren)} pe={int(cfg.mapping)} normal={cfg.normal} viewdir={cfg.input_viewdir} "
            f"heads={cfg.brdf_head_names(flags['apply_brdf'], flags['apply_theta'])} funcH={cfg.funcH} shell={cfg.shell_hapke} R={R} S={S} G={G} "
-           f"prior={bool(prior)} hs={hs} {flags}")
+           f"prior={bool(prior)} {lam} {flags}")
     prev = brdf_nerf_amd.set_deterministic(True)
     try:
         torch.manual_seed(11)
-        ta = FusedTrainer(build_model(cfg, 70 + seed), args, lr=5e-4, ds_lambda=10.0, hs_lambda=hs, strict_rng=False)
-        tb = FusedTrainer(build_model(cfg, 70 + seed), args, lr=5e-4, ds_lambda=10.0, hs_lambda=hs, strict_rng=False)
+        ta = FusedTrainer(build_model(cfg, 70 + seed), args, lr=5e-4, ds_lambda=10.0, strict_rng=False, **lam)
+        tb = FusedTrainer(build_model(cfg, 70 + seed), args, lr=5e-4, ds_lambda=10.0, strict_rng=False, **lam)
         ta.lean = False
         tb.graph_after = 1
         tb.keep_grads = True

@@ -206,6 +206,41 @@ def test_lambert_tail_forward_against_reference_render_golden():
     assert float((rgb - t("rgb_coarse")).abs().max()) <= 2e-5
 
 
+def test_merged_composite_normal_regulariser_against_autograd():
+    """NormalRegLoss (metrics.py:179-216; losses.normal_reg_loss is held to the reference's regulariser golden) inside the
+    merged-set compositing: the forward's per-ray terms and the backward's gradient rows against torch autograd through
+    bn_composite_forward on the gathered set."""
+    from brdf_nerf_amd import functions as Fn, losses
+    g = torch.Generator().manual_seed(4)
+    R, S, G, C = 37, 16, 8, 13
+    out1, out2 = _field_like(R, S, C, g), _field_like(R, G, C, g)
+    for o_ in (out1, out2):
+        o_[..., 4:10] = torch.randn(o_[..., 4:10].shape, generator=g).to(DEV)          # two normal fields, both signs of n . view
+    z = torch.sort(torch.rand(R, S, generator=g) * 2, -1)[0]
+    z2 = torch.sort(torch.rand(R, G, generator=g) * 2, -1)[0]
+    z_all, idx = torch.sort(torch.cat([z, z2], -1), dim=-1, stable=True)
+    z_all, idx = z_all.to(DEV).contiguous(), idx.to(DEV).contiguous()
+    rays = _sat_rays(R, g).to(DEV)
+    lam_an, lam_lr = 0.2, 0.1
+    nreg = Fn.normal_reg(rays[:, 3:6], 4, 7, lam_an, lam_lr)
+    o = Fn.merged_composite_forward(z_all, idx, out1, out2, want=("weights", "depth", "acc"), nreg=nreg)
+    merged = _merged_reference(z_all, idx, out1, out2).requires_grad_(True)
+    _, _, w, _, _ = Fn.composite(z_all, merged, None, 0.0)
+    view = -rays[:, 3:6]
+    per_ray = lam_an * (w * torch.clamp_max((merged[..., 4:7] * view[:, None, :]).sum(-1), 0.0) ** 2).sum(-1) + \
+        lam_lr * (w * torch.clamp_max((merged[..., 7:10] * view[:, None, :]).sum(-1), 0.0) ** 2).sum(-1)
+    total = losses.normal_reg_loss(merged[..., 4:7], w, view, lam_an)[0] + losses.normal_reg_loss(merged[..., 7:10], w, view, lam_lr)[0]
+    assert abs(float(per_ray.sum()) - float(total)) <= 1e-5 * abs(float(total))
+    assert float((o["reg"] - per_ray.detach()).abs().max()) <= 2e-6 * float(per_ray.abs().max())
+    (ref,) = torch.autograd.grad(total, merged)
+    d_cat = torch.zeros(R, S + G, C, device=DEV).scatter_(1, idx.unsqueeze(-1).expand(-1, -1, C), ref)
+    d1, d2 = torch.empty(R, S, C, device=DEV), torch.empty(R, G, C, device=DEV)
+    zero_acc = torch.zeros(R, C, device=DEV)
+    Fn.merged_composite_backward(z_all, idx, out1, out2, None, None, zero_acc, d1, d2, nreg=nreg)
+    scale = float(ref.abs().max())
+    assert float((d1 - d_cat[:, :S]).abs().max()) <= 5e-6 * scale and float((d2 - d_cat[:, S:]).abs().max()) <= 5e-6 * scale
+
+
 # ------------------------------------------------------------------------------------------------ ray-level shading + losses
 _SHADE_CFGS = {
     "rpv111_nlr": (dict(funcM=1, funcF=1, funcH=1, normal="learned"), True),
@@ -519,8 +554,10 @@ def test_lean_step_matches_general_step_on_the_same_draws(name, dtype):
     try:
         torch.manual_seed(11)
         ma, mb = build_model(cfg, 21, dtype), build_model(cfg, 21, dtype)
-        ta = FusedTrainer(ma, args, lr=5e-4, ds_lambda=10.0, hs_lambda=0.1 if brdf else 0.0, strict_rng=False)
-        tb = FusedTrainer(mb, args, lr=5e-4, ds_lambda=10.0, hs_lambda=0.1 if brdf else 0.0, strict_rng=False)
+        # (hard-surface and normal regularisers on for the models with normals: both are part of the lean step)
+        lam = dict(hs_lambda=0.1, nr_reg_an_lambda=0.2, nr_reg_lr_lambda=0.1) if brdf else {}
+        ta = FusedTrainer(ma, args, lr=5e-4, ds_lambda=10.0, strict_rng=False, **lam)
+        tb = FusedTrainer(mb, args, lr=5e-4, ds_lambda=10.0, strict_rng=False, **lam)
         ta.lean = False
         tb.graph_after = 2
         tb.keep_grads = True                                 # test hook: the Adam launch leaves the gradient it read in place
