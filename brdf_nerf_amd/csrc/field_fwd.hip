@@ -22,9 +22,6 @@ struct FwdArgs {
 // w0/(2 pi) (bn_pack_field), so `z` already is the argument of v_sin_f32/v_cos_f32 in revolutions: one transcendental
 // per output, no range-reduction multiplies.  The parity mode keeps z = W x + b and the accurate sincos.
 #define BN_INV_2PI 0.15915494309189535f
-#ifndef BN_EPI_FENCE
-#define BN_EPI_FENCE
-#endif
 
 // sticky fault word of the forward kernels (lost LDS hand-over in the barrier-free trunk, field_kernels.h pp_wait)
 __device__ unsigned int g_fwd_fault;
@@ -164,7 +161,6 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
           }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            BN_EPI_FENCE
             float y[8], dd[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
