@@ -90,6 +90,7 @@ _SIGS = {
     "bn_last_error": (C.c_char_p, []),
     "bn_build_flags": (C.c_char_p, []),
     "bn_set_deterministic": (C.c_int, [C.c_int]),
+    "bn_get_deterministic": (C.c_int, []),
     "bn_field_packed_bytes": (C.c_size_t, [C.POINTER(FieldDesc)]),
     "bn_pack_field": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(FieldParams), fptr, fptr]),
     "bn_field_stash_bytes": (C.c_size_t, [C.POINTER(FieldDesc), C.c_int64]),
@@ -136,7 +137,7 @@ _SIGS = {
                                     fptr, fptr, fptr, fptr]),
     "bn_lambert_tail": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, C.c_int64, fptr,
                                   C.c_int64, fptr, C.c_int64, fptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, fptr, fptr,
-                                  C.c_int32, fptr, fptr, fptr, fptr, fptr, fptr]),
+                                  C.c_int32, fptr, fptr, fptr, fptr, fptr, fptr, fptr]),
     "bn_fold_heads": (C.c_int, [fptr, fptr]),
     "bn_unfold_heads": (C.c_int, [fptr, fptr]),
     "bn_adam_multi": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, fptr, fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float,
@@ -180,7 +181,7 @@ def load(path, baseline=False):
             continue
         fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if not baseline and L.bn_abi_version() != 4:
+    if not baseline and L.bn_abi_version() != 5:
         raise LibraryMissing(f"{path}: ABI version mismatch; rebuild")
     if not baseline and os.environ.get("BRDFNERF_ALLOW_STALE_LIB", "0") in ("", "0"):
         # a library older than the sources beside it must not pass for them (tests, bench and profiles all run through here)
@@ -210,12 +211,14 @@ def set_deterministic(on=True):
 
 
 def deterministic():
-    """Current setting of the deterministic mode (read back through the library)."""
+    """Current setting of the deterministic mode (bn_get_deterministic: a read, nothing is toggled)."""
     L = lib()
-    prev = L.bn_set_deterministic(0)
-    if prev:
-        L.bn_set_deterministic(1)
-    return bool(prev)
+    if not hasattr(L, "bn_get_deterministic"):      # an earlier commit's library loaded by a measurement harness (load(baseline=True))
+        prev = L.bn_set_deterministic(0)
+        if prev:
+            L.bn_set_deterministic(1)
+        return bool(prev)
+    return bool(L.bn_get_deterministic())
 
 
 def use(handle):

@@ -78,6 +78,7 @@ extern "C" const char *bn_build_flags(void) {
 static std::atomic<int> g_deterministic{0};
 int bn_deterministic() { return g_deterministic.load(std::memory_order_relaxed); }
 extern "C" int bn_set_deterministic(int on) { return g_deterministic.exchange(on ? 1 : 0); }
+extern "C" int bn_get_deterministic(void) { return g_deterministic.load(std::memory_order_relaxed); }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of a kernel: remember what has been set for
 // (device, kernel) so that a second device in the same process gets its own call and concurrent callers do not race.

@@ -80,7 +80,7 @@ __device__ __forceinline__ void bwd_dpre(const BwdArgs &A, int64_t gm, float (&d
 }
 
 __global__ void clear_words_kernel(unsigned int *p, int n) {
-  if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
 }
 
 // fp16 loss scaling: amax[which] = max over the launch of the finite |seed gradients| (float bits; non-negative floats order
@@ -517,7 +517,10 @@ extern "C" int bn_field_backward_parts(const bn_field_desc *desc, const bn_field
   const bool det = bn_deterministic() != 0;
   unsigned int *tickets = det ? (unsigned int *)(S + sl.tickets) : nullptr;
   unsigned int tk_used = 0;
-  if (det) BN_HIP_CHECK(hipMemsetAsync(tickets, 0, BN_DET_TICKETS * sizeof(unsigned int), st), "field_backward: ticket memset");
+  if (det) {   // a kernel node, not a memset node: the deterministic step is captured and replayed too (see the amax clear above)
+    clear_words_kernel<<<BN_DET_TICKETS / 256, 256, 0, st>>>(tickets, BN_DET_TICKETS);
+    BN_LAUNCH_CHECK("clear tickets");
+  }
   auto launch_wgrad = [&](WgradArgs &wv, unsigned int *tk) -> int { return bn_launch_wgrad(wv, tk, bf, f16m, sl.Mpad, st); };
   if (!det) {
     if (w.n_jobs > 0)

@@ -61,6 +61,31 @@ static __device__ unsigned long long bn_phase_clk[BN_PH_N + 1];
 #define BN_CLK_END
 #endif
 
+// Per-wave event timeline, compiled only into the diagnostic library built by profiles/simd_timeline.py (-DBN_TIMELINE):
+// every wave of the first BN_TL_BLOCKS workgroups stamps s_memtime at the phase boundaries of the trunk into an LDS log
+// (a region the trunk does not use) and dumps it to a buffer nothing else reads; word 0 of a wave's log is its HW_ID
+// (which SIMD it sits on).  No output depends on the stamps; the product build executes none of this.
+#ifdef BN_TIMELINE
+#define BN_TL_BLOCKS 8
+#define BN_TL_EVENTS 112
+static __device__ unsigned long long bn_tl_buf[BN_TL_BLOCKS][8][BN_TL_EVENTS];
+#define BN_TL_DEFINE_READER(NAME)                                                                              \
+  extern "C" int NAME(unsigned long long *out) {                                                               \
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bn_tl_buf), sizeof(unsigned long long) * BN_TL_BLOCKS * 8 * BN_TL_EVENTS) == hipSuccess ? 0 : -1; \
+  }
+// log = LDS pointer to this wave's BN_TL_EVENTS slots; event code in the top byte
+#define BN_TL_DECL(LDSBASE) unsigned long long *tl_log_ = (unsigned long long *)(LDSBASE) + (threadIdx.x >> 6) * BN_TL_EVENTS; int tl_n_ = 1; \
+  if ((threadIdx.x & 63) == 0) tl_log_[0] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+#define BN_TL(ev) { if ((threadIdx.x & 63) == 0 && tl_n_ < BN_TL_EVENTS) tl_log_[tl_n_] = ((unsigned long long)(ev) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull); ++tl_n_; }
+#define BN_TL_DUMP { if (blockIdx.x < BN_TL_BLOCKS && (threadIdx.x & 63) == 0) { const int w_ = threadIdx.x >> 6; const int n_ = tl_n_ < BN_TL_EVENTS ? tl_n_ : BN_TL_EVENTS; \
+    for (int i_ = 0; i_ < BN_TL_EVENTS; ++i_) bn_tl_buf[blockIdx.x][w_][i_] = i_ < n_ ? tl_log_[i_] : 0ull; } }
+#else
+#define BN_TL_DEFINE_READER(NAME)
+#define BN_TL_DECL(LDSBASE)
+#define BN_TL(ev)
+#define BN_TL_DUMP
+#endif
+
 // Stash traffic is streaming (written once here, read once by a later kernel) and several times larger than the
 // packed weights every workgroup re-reads from L2: non-temporal stores / loads keep it from evicting the weights.
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -77,6 +102,22 @@ template <typename V> __device__ __forceinline__ V stash_load(const V *p) {
 #else
   return __builtin_nontemporal_load(p);
 #endif
+}
+
+// The same stores as buffer instructions: `base` wave-uniform (kernel arguments and blockIdx only), the lane's part in one
+// VGPR (voff), everything else in a scalar offset - no 64-bit vector address arithmetic per store (16 stores of a layer's
+// epilogue otherwise pin 32 address registers).
+__device__ __forceinline__ auto stash_rsrc(const void *base) { return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000); }
+template <typename R, typename V> __device__ __forceinline__ void stash_store_buf(R rsrc, int voff, int soff, const V &v) {
+  static_assert(sizeof(V) == 16, "one 16-byte piece per lane");
+#ifndef BN_STASH_AUX      // A/B switch (results unchanged): cache policy of the stash stores: 0 plain, 2 nt, 16 sc1 (write-through), 18 sc1 nt
+#ifdef BN_NO_NT_STASH
+#define BN_STASH_AUX 0
+#else
+#define BN_STASH_AUX 2
+#endif
+#endif
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff, soff, BN_STASH_AUX);
 }
 
 // Instantiate-and-call FN<T, MT, NT, WAVES> ARGS for the tile configuration in geometry G (returns from the caller).
@@ -179,6 +220,11 @@ template <> struct FwdDepth<bf16, true> { static constexpr int value = BN_FWD_DE
 template <> struct FwdDepth<f16, true> { static constexpr int value = BN_FWD_DEPTH_TRAIN; };
 template <typename T> struct BwdDepth { static constexpr int value = Elem<T>::kFastMath ? BN_BWD_DEPTH : 4; };
 
+// LDS (B) fragments: ONE register set (`Bc = Bn` after the MFMAs; hipcc coalesces the two and issues the reads of k-step s + 1
+// behind the last MFMA of k-step s that uses the registers).  Two named sets with the reads pinned AHEAD of the MFMAs
+// (-DBN_GEMM_B2, round 4) measured slower wherever tried: the GEMM alone in a kernel 42 vs 35 cycles per MFMA with one wave
+// per SIMD and 78 vs 56 with two (profiles/r04_probe_gemm_rate.txt), the training forward +1 %, the backward chain +5 %
+// (profiles/r04_ablation.txt).
 template <typename T, int MT, int NTW, int DEPTH, typename Side>
 __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, int ks0, int nks, const T *bsrc,
                                            int ldb, int lane, Side &side) {
@@ -189,18 +235,61 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
   const T *wl = wp + (size_t)lane * 8;
   const T *bl = bsrc + (size_t)r * ldb + 8 * h;
   const int kend = ks0 + nks;
-  frag A[DEPTH][NTW], Bc[MT];
+  frag A[DEPTH][NTW];
+  // (BN_PROBE_NO_A / BN_PROBE_NO_B: profiles/probe_gemm_rate.py only - the loop without its weight / LDS fragment traffic)
   auto loadA = [&](frag(&a)[NTW], int ks) {
     ks = ks < kend ? ks : kend - 1;
     {
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) a[nt] = gld_frag<T>(wl + ((size_t)nt * KS + ks) * 512);
+      for (int nt = 0; nt < NTW; ++nt) {
+#ifdef BN_PROBE_NO_A
+        if (ks >= ks0 + DEPTH) { asm volatile("" : "+v"(a[nt])); continue; }
+#endif
+        a[nt] = gld_frag<T>(wl + ((size_t)nt * KS + ks) * 512);
+      }
     }
   };
   auto loadB = [&](frag(&B)[MT], int ks) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) B[mt] = lds_frag<T>(bl + (size_t)mt * 32 * ldb + ks * 16);
+    for (int mt = 0; mt < MT; ++mt) {
+#ifdef BN_PROBE_NO_B
+      if (ks != ks0) { asm volatile("" : "+v"(B[mt])); continue; }
+#endif
+      B[mt] = lds_frag<T>(bl + (size_t)mt * 32 * ldb + ks * 16);
+    }
   };
+#ifdef BN_GEMM_B2
+  frag B[2][MT];
+  auto step = [&](frag(&a)[NTW], frag(&bc)[MT], frag(&bn)[MT], int ks) {   // consumes bc (fragments of k-step ks), fills bn with those of ks+1
+    loadB(bn, ks + 1 < kend ? ks + 1 : ks0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], a[nt], bc[mt]);
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) loadA(A[d], ks0 + d);
+  loadB(B[0], ks0);
+  __builtin_amdgcn_sched_barrier(0);
+  int ks = ks0;
+  for (; ks + DEPTH <= kend; ks += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      step(A[d], B[d & 1], B[(d + 1) & 1], ks + d);
+      loadA(A[d], ks + d + DEPTH);
+      side.at(d & 1);   // constant after unrolling
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (ks + d < kend) {
+      step(A[d], B[d & 1], B[(d + 1) & 1], ks + d);
+      side.at(d & 1);
+    }
+#else
+  frag Bc[MT];
   auto step = [&](frag(&a)[NTW], int ks) {   // consumes Bc (fragments of k-step ks), leaves those of ks+1 in Bc
     frag Bn[MT];
     loadB(Bn, ks + 1 < kend ? ks + 1 : ks0);
@@ -231,7 +320,65 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
       step(A[d], ks + d);
       side.at(d & 1);
     }
+#endif
 }
+// ---- The same GEMM fed by a CONTINUOUS weight stream (round 4).  The ring of DEPTH weight-fragment slots `A` belongs to the
+// caller and is never drained: while segment s runs its last DEPTH k-steps, the slots are re-filled with the FIRST k-steps of
+// the segment that follows (another k-range of the same matrix, the next layer's matrix, ...), which depend on nothing the
+// kernel computes.  What that buys (profiles/r04_probe_gemm_rate.txt): (a) no pipeline fill per segment - a chain kernel
+// starts 2-3 GEMM segments per layer, each of which exposed an L2 round trip; (b) a wave's loads retire in issue order behind
+// its own stores (vmcnt): the first weight loads of a GEMM used to be issued right after the epilogue's burst of stash
+// stores and waited for every one of them (the GEMM alone 35 / 56 cycles per MFMA at one / two waves per SIMD, 45 / 78 with a
+// layer's 24 stores per wave in front of it); now they are issued BEFORE the epilogue, and the loads behind the stores are
+// not needed for another DEPTH k-steps.  Segments are whole multiples of DEPTH k-steps (slot indices stay compile-time).
+template <typename T, int NTW, int DEPTH>
+__device__ __forceinline__ void wstream_start(typename Elem<T>::frag (&A)[DEPTH][NTW], const T *__restrict__ wp, int KS, int k0, int lane) {
+  const T *wl = wp + (size_t)lane * 8;
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) A[d][nt] = gld_frag<T>(wl + ((size_t)nt * KS + k0 + d) * 512);
+}
+// k-steps [k0, k0 + nks) of the packed matrix wp (n-tiles KS k-steps apart); the stream continues at k-step k0n of matrix wpn
+// (n-tiles KSn apart).  The last segment of a stream passes its own matrix and k0n = k0 + nks - DEPTH (a harmless re-read).
+template <typename T, int MT, int NTW, int DEPTH>
+__device__ __forceinline__ void gemm_stream(f32x16 (&acc)[NTW][MT], typename Elem<T>::frag (&A)[DEPTH][NTW], const T *__restrict__ wp, int KS,
+                                            int k0, int nks, const T *__restrict__ wpn, int KSn, int k0n, const T *bsrc, int ldb, int lane) {
+  typedef typename Elem<T>::frag frag;
+  const int r = lane & 31, h = lane >> 5;
+  const T *wl = wp + (size_t)lane * 8, *wln = wpn + (size_t)lane * 8;
+  const T *bl = bsrc + (size_t)r * ldb + 8 * h;
+  const int kend = k0 + nks;
+  frag Bc[MT];
+  auto loadB = [&](frag(&B)[MT], int ks) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) B[mt] = lds_frag<T>(bl + (size_t)mt * 32 * ldb + ks * 16);
+  };
+  loadB(Bc, k0);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int ks = k0; ks < kend; ks += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      frag Bn[MT];
+      loadB(Bn, ks + d + 1 < kend ? ks + d + 1 : k0);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], A[d][nt], Bc[mt]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) Bc[mt] = Bn[mt];
+      // re-fill the slot: DEPTH k-steps ahead in this segment, or the head of the next one
+      const int kk = ks + d + DEPTH;
+      const bool cur = kk < kend;
+      const T *pw = cur ? wl : wln;
+      const int K2 = cur ? KS : KSn, ki = cur ? kk : k0n + (kk - kend);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) A[d][nt] = gld_frag<T>(pw + ((size_t)nt * K2 + ki) * 512);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 template <typename T, int MT, int NTW, int DEPTH, typename Side>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb,
                                          int lane, Side &side) {

@@ -920,10 +920,10 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float x = a3[c] * (1.f + 2.f * A.pad) - A.pad * ws;
-      const float y = fminf(fmaxf(x, 0.f), 1.f);
+      const float y = isnan(x) ? x : fminf(fmaxf(x, 0.f), 1.f);     // a NaN colour stays a NaN (fminf / fmaxf alone would return 0)
       const float e = y - A.rgbs[ray * 3 + c];
       loss += A.lambda_rgb * e * e * invn;
-      const float dy = (x >= 0.f && x <= 1.f) ? A.lambda_rgb * 2.f * e * invn : 0.f;
+      const float dy = (x >= 0.f && x <= 1.f) ? A.lambda_rgb * 2.f * e * invn : (isnan(x) ? x : 0.f);
       dacc[c] = dy * (1.f + 2.f * A.pad);
       dws -= dy * A.pad;
       if (lane == 0 && A.rgb) A.rgb[ray * 3 + c] = y;
@@ -936,6 +936,13 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
         loss += k * tw * (dsum - td) * (dsum - td);
         dd = k * 2.f * tw * (dsum - td);
       }
+    }
+    // a ray whose loss term is not finite: with `nonfinite` (FusedTrainer.sanitize_grads) it is left out of the step - loss term 0,
+    // gradients 0 - and counted, as bn_ray_shade_loss does; without it the NaN reaches the loss and the gradients as upstream
+    if (A.nonfinite && !(fabsf(loss) <= 3.0e38f)) {
+      if (lane == 0) atomicAdd(A.nonfinite + (isnan(loss) ? 0 : 1), 1ull);
+      loss = 0.f; dd = 0.f; dws = 0.f;
+      dacc[0] = dacc[1] = dacc[2] = 0.f;
     }
     if (lane == 0) {
       if (A.ray_loss) A.ray_loss[ray] = loss;
@@ -1092,13 +1099,14 @@ extern "C" int bn_lambert_tail(const float *z, const int64_t *sort_idx, const fl
                                const float *target_depth, int64_t td_stride, const float *target_weight, int64_t tw_stride,
                                const float *target_std, int64_t ts_stride, float rgb_padding, float lambda_rgb, float lambda_ds,
                                int32_t usealldepth, float *ray_loss, float *loss_acc, int32_t loss_slots, float *rgb,
-                               float *weights, float *depth, float *d_out1, float *d_out2, void *stream) {
+                               float *weights, float *depth, float *d_out1, float *d_out2, unsigned long long *nonfinite, void *stream) {
   MergedArgs a = {};
   a.z = z; a.idx = sort_idx; a.out1 = out1; a.out2 = out2; a.S1 = S1; a.S2 = S2; a.C = C; a.R = R;
   a.rgbs = rgbs; a.valid = valid_depth; a.tdepth = target_depth; a.tweight = target_weight; a.tstd = target_std;
   a.v_stride = v_stride; a.td_stride = td_stride; a.tw_stride = tw_stride; a.ts_stride = ts_stride;
   a.pad = rgb_padding; a.lambda_rgb = lambda_rgb; a.lambda_ds = lambda_ds; a.usealldepth = usealldepth;
   a.ray_loss = ray_loss; a.loss_acc = loss_acc; a.loss_slots = loss_slots > 0 ? loss_slots : 1; a.rgb = rgb; a.weights = weights; a.depth = depth; a.d_out1 = d_out1; a.d_out2 = d_out2;
+  a.nonfinite = nonfinite;
   if (int e = merged_check(a, "lambert_tail")) return e;
   BN_REQUIRE(rgbs && d_out1 && (S1 == S2 || d_out2), "lambert_tail: null argument");
   BN_REQUIRE(!target_depth || (valid_depth && target_weight && target_std), "lambert_tail: incomplete depth prior");

@@ -634,9 +634,10 @@ def ray_shade_loss(desc, acc, wsum, depth, var, rays_d, sun_d, rgbs, bufs=None, 
 
 def lambert_tail(z_all, idx, out1, out2, rgbs, rgb_padding, lambda_rgb, d_out1, d_out2, valid_depth=None, target_depth=None,
                  target_weight=None, target_std=None, lambda_ds=0.0, usealldepth=False, ray_loss=None, loss_acc=None, rgb=None,
-                 weights=None, depth=None):
+                 weights=None, depth=None, nonfinite=None):
     """Ray-level tail of a Lambertian step in one launch (bn_lambert_tail): merged compositing + shading + SNerfLoss +
-    DepthLoss + the backward of all of it, gradient rows written to d_out1 / d_out2."""
+    DepthLoss + the backward of all of it, gradient rows written to d_out1 / d_out2.  nonfinite ([2] int64 counters): rays with a
+    non-finite loss term are left out and counted, non-finite gradient elements zeroed and counted."""
     R, S2 = z_all.shape
     S1, Cc = out1.shape[1], out1.shape[2]
     use = target_depth is not None and lambda_ds > 0
@@ -648,7 +649,7 @@ def lambert_tail(z_all, idx, out1, out2, rgbs, rgb_padding, lambda_rgb, d_out1, 
                                     tsp, tss, float(rgb_padding), float(lambda_rgb), float(lambda_ds if use else 0.0),
                                     int(bool(usealldepth)), _p(ray_loss), _p(loss_acc), 0 if loss_acc is None else loss_acc.numel(),
                                     _p(rgb), _p(weights), _p(depth),
-                                    _p(d_out1), _p(d_out2), _stream()), "bn_lambert_tail")
+                                    _p(d_out1), _p(d_out2), _p(nonfinite), _stream()), "bn_lambert_tail")
 
 
 def adam_multi(param, grad, exp_avg, exp_avg_sq, groups, active, state, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,

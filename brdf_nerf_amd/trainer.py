@@ -446,7 +446,8 @@ class FusedTrainer:
                 Fn.lambert_tail(z_all, idx, out1v, out2v, rgbs, model.rgb_padding, self.lambda_rgb, d1o, d2o,
                                 valid_depth if use_ds else None, depths[:, 0] if use_ds else None, depths[:, 1] if use_ds else None,
                                 depth_std if use_ds else None, self.ds_lambda if use_ds else 0.0, self.usealldepth,
-                                ray_loss=ray_loss, loss_acc=None if det else Fn.state_loss_partials(st), rgb=rgb)
+                                ray_loss=ray_loss, loss_acc=None if det else Fn.state_loss_partials(st), rgb=rgb,
+                                nonfinite=self._nonfinite if self.sanitize_grads else None)
                 if det:
                     loss = ray_loss.sum()
         else:

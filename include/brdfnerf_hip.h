@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BN_ABI_VERSION 4
+#define BN_ABI_VERSION 5
 #define BN_MAX_LAYERS 12
 #define BN_MAX_HEADS 6 /* rgb (+ beta) + up to 3 BRDF heads evaluated together, two per pass */
 
@@ -67,6 +67,8 @@ const char *bn_source_hash(void);
  * identical gradients for identical inputs, for 13-16 % of a training step (profiles/r02_ablation.txt).  Process-wide; returns
  * the old value. */
 int bn_set_deterministic(int on);
+/* The current setting (read-only: callers that only want to know must not toggle a process-wide switch to find out). */
+int bn_get_deterministic(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Field MLP (SpSBRDFNeRF.forward, models/spsbrdfnerf.py:662-757; calc_features :636-646;
@@ -396,13 +398,15 @@ int bn_ray_shade_loss(const bn_shade_desc *desc, const float *acc, const float *
  * DepthLoss; metrics.py:39-61,82-161) + bn_merged_composite_backward.  The prior arrays carry element strides.  ray_loss [R]
  * (nullable) and/or loss_acc (nullable): ray r's term is atomically added to loss_acc[r % loss_slots] - partial sums the
  * caller adds up (4096 atomics on ONE word serialise to ~50 us; the step state's 64 partials are folded into its loss ring
- * by bn_adam_multi). */
+ * by bn_adam_multi).  nonfinite (nullable, [0] NaN [1] Inf counters), as in bn_ray_shade_loss / bn_merged_composite_backward:
+ * a ray whose loss term is not finite is left out (loss 0, gradients 0) and counted, non-finite gradient elements are zeroed
+ * and counted; without it a NaN colour stays a NaN in rgb, in the loss and in the gradients, as it does upstream. */
 int bn_lambert_tail(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1, int32_t S2,
                     int32_t C, int64_t R, const float *rgbs, const float *valid_depth, int64_t v_stride,
                     const float *target_depth, int64_t td_stride, const float *target_weight, int64_t tw_stride,
                     const float *target_std, int64_t ts_stride, float rgb_padding, float lambda_rgb, float lambda_ds,
                     int32_t usealldepth, float *ray_loss, float *loss_acc, int32_t loss_slots, float *rgb,
-                    float *weights, float *depth, float *d_out1, float *d_out2, void *stream);
+                    float *weights, float *depth, float *d_out1, float *d_out2, unsigned long long *nonfinite, void *stream);
 
 /* Folding of the linear feats layer into the heads' first layers (bn_field_desc.fold_feats) and the chain rule back, as
  * two launches of exact-fp32 MFMA tiles:

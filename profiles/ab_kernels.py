@@ -32,7 +32,7 @@ def main():
         build, _, attrs = tag.partition(":")
         path = os.path.join(here, "brdf_nerf_amd", "libbrdfnerf_hip.so") if build == "default" else \
             os.path.join(here, "brdf_nerf_amd", "build", build, "libbrdfnerf_hip.so")
-        h = L.load(path)
+        h = L.load(path, baseline=build.startswith("r0"))     # "r0N...": an earlier round's library (profiles/build_baseline.py)
         L.use(h)
         args = bench.make_args(n_rays, 64, 64, dtype, **bench.CONFIG_FLAGS[config][0])
         torch.manual_seed(0)
