@@ -42,6 +42,15 @@ extern "C" const char *bn_build_flags(void) {
 #ifdef BN_CLOCK_STAMP_WGRAD
          "BN_CLOCK_STAMP_WGRAD "
 #endif
+#ifdef BN_TIMELINE
+         "BN_TIMELINE "
+#endif
+#ifdef BN_GEMM_PRIO
+         "BN_GEMM_PRIO "
+#endif
+#ifdef BN_STASH_AUX
+         "BN_STASH_AUX "
+#endif
 #ifdef BN_NO_NT_STASH
          "BN_NO_NT_STASH "
 #endif

@@ -307,25 +307,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
   const int n_on = F / (32 * NT) < WAVES ? F / (32 * NT) : WAVES;   // waves that own output columns
   // stash copies ride inside the GEMMs when the shape fits (NT == 2 means F = 512: always, decided at compile time)
   const bool ride = NT == 2 ? true : tile_copy_exact(F, n_on, WAVES);
-  // Two-group anti-phase (F = 512: NT == 2, all eight waves own columns; 16-bit modes).  Waves 0-3 (group 0) own output
+  // Two-group ping-pong (F = 512: NT == 2, all eight waves own columns; 16-bit modes).  Waves 0-3 (group 0) own output
   // columns 0-255, waves 4-7 (group 1) columns 256-511; each SIMD hosts one wave of either group.  There is no
-  // workgroup barrier inside the trunk.  Every wave multiplies over input-column half 0, then half 1.  Group 1 runs a
-  // WHOLE GEMM behind group 0: while one wave of a SIMD multiplies, its partner is in its (VALU + store) epilogue, so
-  // the matrix pipe serves one wave at a time and always has one to serve (round 4; rounds 1-3 lagged group 1 by half
-  // a GEMM, which put both waves of a SIMD into their GEMMs together and into their epilogues together: a layer cost
-  // 2 epilogues + 1 GEMM, now 1 + 1).  The in-place update of the LDS tile allows that lag because the epilogue is
-  // split into two passes over the accumulators that the groups run in OPPOSITE order:
-  //   pass S: sin -> 16-bit pack -> LDS tile (next layer's operand) + Y stash;   pass C: cos -> 8-bit D stash (no LDS)
-  //   group 0: C, then S - it rewrites columns 0-255 LATE, after group 1 (whose GEMM of the same layer has just started
-  //            and reads half 0 FIRST) is done with them;
-  //   group 1: S, then C - it rewrites columns 256-511 EARLY (group 0 read them last, in the second half of a GEMM that
-  //            is long finished), in time for the second half of group 0's next GEMM, which has just started.
-  // Counters in LDS (they only grow, 4 per layer each):  WR[g] waves of group g past pass S of layer l;
+  // workgroup barrier inside the trunk.  Every wave multiplies over input-column half 0, then half 1; group 1 is
+  // held one half-GEMM behind group 0, so group 0's (VALU) epilogue runs under group 1's second half-GEMM and group
+  // 1's epilogue under group 0's first half-GEMM of the next layer.
+  // Counters in LDS (they only grow, 4 per layer each):  WR[g] waves of group g past epilogue l;
   // RD[h][g] waves of group g done reading column half h in layer l.
-  //   phase 1 (half 0) needs WR[0] (and, for group 1, RD[1][0]: group 0 is through its GEMM - the enforced lag);
-  //   phase 2 needs WR[1]; pass S of group g rewrites half g: needs RD[g][0] and RD[g][1].
-  // Every wait is for an event that precedes it in one global order (layer, then group 0 GEMM < group 1 half 0 <
-  // group 0 pass S < group 1 half 1 < group 1 pass S): no cycle, and all spins are bounded (pp_wait).
+  //   phase 1 (half 0) needs WR[0] (and, for group 1, RD[0][0]: the enforced lag); phase 2 needs WR[1];
+  //   the epilogue of group g rewrites half g: needs RD[g][0] and RD[g][1].
+  // Round 4 (profiles/r04_simd_timeline*.txt, r04_ab_fwd_*.txt): a wave raises its priority while it multiplies - its MFMAs
+  // then win the SIMD's issue arbitration against the partner's epilogue (forward -3 %); the biases START the accumulators
+  // (staged per wave in LDS) instead of being added by the epilogue, and the stash stores are buffer instructions with scalar
+  // offsets (-3 %, sigma-only -6 %).  Measured and NOT adopted: group 1 a WHOLE GEMM behind with the epilogue split into a
+  // pass S (sin, LDS tile, Y stash) and a pass C (cos, D stash) run in opposite order by the two groups, which makes the
+  // in-place update legal at that lag - one wave of a SIMD in its GEMM 69 % of the trunk instead of 63 %, but a wave alone
+  // multiplies at 61-72 cycles per MFMA inside this kernel (35 in a kernel of its own, profiles/r04_probe_gemm_rate.txt):
+  // forward +5 % without the priority, equal with it.
 #ifndef BN_NO_PINGPONG
   constexpr bool PING = NT == 2 && WAVES == 8 && FAST;   // bf16 throughput mode only: the fp32 parity mode keeps k in order
 #else
@@ -377,11 +375,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
           NoSide none;
           BN_PH(1)
           pp_wait(WR + 0, 4 * l, &g_fwd_fault);                       // half 0 of Y_{l-1} is written
-#ifdef BN_PP_FULL_LAG
-          if (grp == 1) pp_wait(RD + 2, 4 * l, &g_fwd_fault);         // A/B switch: group 0 is through its whole GEMM of this layer
-#else
           if (grp == 1) pp_wait(RD + 0, 4 * l, &g_fwd_fault);         // group 0 is done with its phase 1 of this layer: the lag
-#endif
           BN_PH(12)
           BN_TL(1)
           __builtin_amdgcn_s_setprio(BN_GEMM_PRIO);
@@ -434,136 +428,41 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
         typedef typename Elem<T>::frag frag;
         constexpr int ACTK = decltype(act_tag)::value;
         const float dsc = ACTK == BN_ACT_SIN ? w0 : 1.f;
-        auto wait_rd = [&]() {   // all eight waves have read this group's columns of Y_{l-1}
-          if (l > 0) {
-            pp_wait(RD + 2 * grp + 0, 4 * l, &g_fwd_fault);
-            pp_wait(RD + 2 * grp + 1, 4 * l, &g_fwd_fault);
-          }
-        };
-        // pass C: derivative stash (8-bit), no LDS traffic.  A fence per piece: all 128 accumulators are live here, and hipcc
-        // otherwise hoists dozens of transcendentals ahead of their packs and spills the accumulators around them.
-        auto pass_c = [&]() {
+        if (l > 0) {   // all eight waves have read this group's columns of Y_{l-1}
+          pp_wait(RD + 2 * grp + 0, 4 * l, &g_fwd_fault);
+          pp_wait(RD + 2 * grp + 1, 4 * l, &g_fwd_fault);
+        }
+        BN_PH(2)
+        BN_TL(5)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+          DHalf<T> dh0[MT];     // derivative bytes of group gp = 0, stored with those of gp = 1 (one 16-byte piece per lane)
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-              float c0[8], c1[8];
+              float y[8], c[8];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float za = acc[nt][mt][e], zb = acc[nt][mt][8 + e];
-                c0[e] = ACTK == BN_ACT_SIN ? __builtin_amdgcn_cosf(za) : (za > 0.f ? 1.f : 0.f);
-                c1[e] = ACTK == BN_ACT_SIN ? __builtin_amdgcn_cosf(zb) : (zb > 0.f ? 1.f : 0.f);
-              }
-              const DHalf<T> h0 = dhalf_make<T>(c0, dsc), h1 = dhalf_make<T>(c1, dsc);
-              stash_store_buf(Dr, voff, ((wave_u * NT + nt) * MT + mt) * 1024, u32x4{h0.w[0], h0.w[1], h1.w[0], h1.w[1]});
-              __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        // pass S, one piece = 8 activations of a lane: value -> 16-bit pack; then LDS tile (in place) + native Y stash
-        auto s_piece = [&](int nt, int gp, int mt) -> frag {
-          float y[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float z = acc[nt][mt][8 * gp + e];
-            y[e] = ACTK == BN_ACT_SIN ? __builtin_amdgcn_sinf(z) : (z > 0.f ? z : 0.f);
-          }
-          return cvt8(T(), y);
-        };
-        auto s_write = [&](int nt, int gp, int mt, const frag &yq) {
-          const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h, m = mt * 32 + r;
-          *(vec4 *)(ACT + (size_t)m * LDA + n0) = __builtin_shufflevector(yq, yq, 0, 1, 2, 3);
-          *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = __builtin_shufflevector(yq, yq, 4, 5, 6, 7);
-          if (keep) stash_store_buf(Yr, voff, ((((wave_u * NT + nt) * MT + mt) * 2 + gp) * 1024), yq);
-        };
-#ifndef BN_PP_FULL_LAG     // ONE pass for both groups (sin, cos, LDS tile, both stashes per piece)
-        if (true) {
-          wait_rd();
-          BN_PH(2)
-          BN_TL(5)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            DHalf<T> dh0[MT];
-#pragma unroll
-            for (int gp = 0; gp < 2; ++gp)
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) {
-                const frag yq = s_piece(nt, gp, mt);
-                s_write(nt, gp, mt, yq);
-                if (keep) {
-                  float c[8];
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) {
-                    const float z = acc[nt][mt][8 * gp + e];
-                    c[e] = ACTK == BN_ACT_SIN ? __builtin_amdgcn_cosf(z) : (z > 0.f ? 1.f : 0.f);
-                  }
-                  if (gp == 0) dh0[mt] = dhalf_make<T>(c, dsc);
-                  else {
-                    const DHalf<T> h1 = dhalf_make<T>(c, dsc);
-                    stash_store_buf(Dr, voff, ((wave_u * NT + nt) * MT + mt) * 1024, u32x4{dh0[mt].w[0], dh0[mt].w[1], h1.w[0], h1.w[1]});
-                  }
+              for (int e = 0; e < 8; ++e) act_eval<FAST, ACTK>(acc[nt][mt][8 * gp + e], w0, y[e], c[e]);
+              const int m = mt * 32 + r;
+              const frag yq = cvt8(T(), y);     // one conversion serves the LDS tile (next layer's operand) and the native Y stash
+              *(vec4 *)(ACT + (size_t)m * LDA + n0) = __builtin_shufflevector(yq, yq, 0, 1, 2, 3);
+              *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = __builtin_shufflevector(yq, yq, 4, 5, 6, 7);
+              if (keep) {
+                stash_store_buf(Yr, voff, ((((wave_u * NT + nt) * MT + mt) * 2 + gp) * 1024), yq);
+                if (gp == 0) dh0[mt] = dhalf_make<T>(c, dsc);
+                else {
+                  const DHalf<T> h1 = dhalf_make<T>(c, dsc);
+                  stash_store_buf(Dr, voff, ((wave_u * NT + nt) * MT + mt) * 1024, u32x4{dh0[mt].w[0], dh0[mt].w[1], h1.w[0], h1.w[1]});
                 }
               }
+            }
           }
-          BN_TL(6)
-          pp_signal(WR + grp, lane);
-          BN_PH(3)
-        } else
-#endif
-        if (grp == 0) {
-          // late writer: every transcendental and pack first (64 packed registers replace the 128 accumulators), then the
-          // wait for group 1's reads of these columns, then nothing but LDS writes and stores
-          BN_TL(7)
-          if (keep) pass_c();
-          BN_TL(8)
-          frag yq[NT][2][MT];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int gp = 0; gp < 2; ++gp)
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) {
-                yq[nt][gp][mt] = s_piece(nt, gp, mt);
-                asm volatile("" : "+v"(yq[nt][gp][mt]));     // computed here, not below the wait
-                __builtin_amdgcn_sched_barrier(0);
-              }
-          BN_TL(10)
-          wait_rd();
-          BN_PH(2)
-          BN_TL(5)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int gp = 0; gp < 2; ++gp)
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) s_write(nt, gp, mt, yq[nt][gp][mt]);
-          BN_TL(6)
-          pp_signal(WR + grp, lane);
-          BN_PH(3)
-        } else {
-          // early writer: pass S piece by piece, signal, then pass C
-          wait_rd();
-          BN_PH(2)
-          BN_TL(5)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int gp = 0; gp < 2; ++gp)
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) {
-                const frag yq = s_piece(nt, gp, mt);
-                s_write(nt, gp, mt, yq);
-                __builtin_amdgcn_sched_barrier(0);
-              }
-          BN_TL(6)
-          pp_signal(WR + grp, lane);
-          BN_PH(3)
-          if (keep) {
-            BN_TL(7)
-            pass_c();
-            BN_TL(8)
-          }
-          BN_PH(5)
         }
+        BN_TL(6)
+        pp_signal(WR + grp, lane);
+        BN_PH(3)
       };
       if (g.act == BN_ACT_SIN) passes(std::integral_constant<int, BN_ACT_SIN>());
       else passes(std::integral_constant<int, BN_ACT_RELU>());

@@ -222,7 +222,7 @@ template <typename T> struct BwdDepth { static constexpr int value = Elem<T>::kF
 
 // LDS (B) fragments: ONE register set (`Bc = Bn` after the MFMAs; hipcc coalesces the two and issues the reads of k-step s + 1
 // behind the last MFMA of k-step s that uses the registers).  Two named sets with the reads pinned AHEAD of the MFMAs
-// (-DBN_GEMM_B2, round 4) measured slower wherever tried: the GEMM alone in a kernel 42 vs 35 cycles per MFMA with one wave
+// (round 4) measured slower wherever tried: the GEMM alone in a kernel 42 vs 35 cycles per MFMA with one wave
 // per SIMD and 78 vs 56 with two (profiles/r04_probe_gemm_rate.txt), the training forward +1 %, the backward chain +5 %
 // (profiles/r04_ablation.txt).
 template <typename T, int MT, int NTW, int DEPTH, typename Side>
@@ -258,37 +258,6 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
       B[mt] = lds_frag<T>(bl + (size_t)mt * 32 * ldb + ks * 16);
     }
   };
-#ifdef BN_GEMM_B2
-  frag B[2][MT];
-  auto step = [&](frag(&a)[NTW], frag(&bc)[MT], frag(&bn)[MT], int ks) {   // consumes bc (fragments of k-step ks), fills bn with those of ks+1
-    loadB(bn, ks + 1 < kend ? ks + 1 : ks0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], a[nt], bc[mt]);
-  };
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) loadA(A[d], ks0 + d);
-  loadB(B[0], ks0);
-  __builtin_amdgcn_sched_barrier(0);
-  int ks = ks0;
-  for (; ks + DEPTH <= kend; ks += DEPTH) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      step(A[d], B[d & 1], B[(d + 1) & 1], ks + d);
-      loadA(A[d], ks + d + DEPTH);
-      side.at(d & 1);   // constant after unrolling
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d)
-    if (ks + d < kend) {
-      step(A[d], B[d & 1], B[(d + 1) & 1], ks + d);
-      side.at(d & 1);
-    }
-#else
   frag Bc[MT];
   auto step = [&](frag(&a)[NTW], int ks) {   // consumes Bc (fragments of k-step ks), leaves those of ks+1 in Bc
     frag Bn[MT];
@@ -320,65 +289,7 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
       step(A[d], ks + d);
       side.at(d & 1);
     }
-#endif
 }
-// ---- The same GEMM fed by a CONTINUOUS weight stream (round 4).  The ring of DEPTH weight-fragment slots `A` belongs to the
-// caller and is never drained: while segment s runs its last DEPTH k-steps, the slots are re-filled with the FIRST k-steps of
-// the segment that follows (another k-range of the same matrix, the next layer's matrix, ...), which depend on nothing the
-// kernel computes.  What that buys (profiles/r04_probe_gemm_rate.txt): (a) no pipeline fill per segment - a chain kernel
-// starts 2-3 GEMM segments per layer, each of which exposed an L2 round trip; (b) a wave's loads retire in issue order behind
-// its own stores (vmcnt): the first weight loads of a GEMM used to be issued right after the epilogue's burst of stash
-// stores and waited for every one of them (the GEMM alone 35 / 56 cycles per MFMA at one / two waves per SIMD, 45 / 78 with a
-// layer's 24 stores per wave in front of it); now they are issued BEFORE the epilogue, and the loads behind the stores are
-// not needed for another DEPTH k-steps.  Segments are whole multiples of DEPTH k-steps (slot indices stay compile-time).
-template <typename T, int NTW, int DEPTH>
-__device__ __forceinline__ void wstream_start(typename Elem<T>::frag (&A)[DEPTH][NTW], const T *__restrict__ wp, int KS, int k0, int lane) {
-  const T *wl = wp + (size_t)lane * 8;
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d)
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) A[d][nt] = gld_frag<T>(wl + ((size_t)nt * KS + k0 + d) * 512);
-}
-// k-steps [k0, k0 + nks) of the packed matrix wp (n-tiles KS k-steps apart); the stream continues at k-step k0n of matrix wpn
-// (n-tiles KSn apart).  The last segment of a stream passes its own matrix and k0n = k0 + nks - DEPTH (a harmless re-read).
-template <typename T, int MT, int NTW, int DEPTH>
-__device__ __forceinline__ void gemm_stream(f32x16 (&acc)[NTW][MT], typename Elem<T>::frag (&A)[DEPTH][NTW], const T *__restrict__ wp, int KS,
-                                            int k0, int nks, const T *__restrict__ wpn, int KSn, int k0n, const T *bsrc, int ldb, int lane) {
-  typedef typename Elem<T>::frag frag;
-  const int r = lane & 31, h = lane >> 5;
-  const T *wl = wp + (size_t)lane * 8, *wln = wpn + (size_t)lane * 8;
-  const T *bl = bsrc + (size_t)r * ldb + 8 * h;
-  const int kend = k0 + nks;
-  frag Bc[MT];
-  auto loadB = [&](frag(&B)[MT], int ks) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) B[mt] = lds_frag<T>(bl + (size_t)mt * 32 * ldb + ks * 16);
-  };
-  loadB(Bc, k0);
-  __builtin_amdgcn_sched_barrier(0);
-  for (int ks = k0; ks < kend; ks += DEPTH) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      frag Bn[MT];
-      loadB(Bn, ks + d + 1 < kend ? ks + d + 1 : k0);
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], A[d][nt], Bc[mt]);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) Bc[mt] = Bn[mt];
-      // re-fill the slot: DEPTH k-steps ahead in this segment, or the head of the next one
-      const int kk = ks + d + DEPTH;
-      const bool cur = kk < kend;
-      const T *pw = cur ? wl : wln;
-      const int K2 = cur ? KS : KSn, ki = cur ? kk : k0n + (kk - kend);
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) A[d][nt] = gld_frag<T>(pw + ((size_t)nt * K2 + ki) * 512);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
 template <typename T, int MT, int NTW, int DEPTH, typename Side>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb,
                                          int lane, Side &side) {

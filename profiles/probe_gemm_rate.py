@@ -1,6 +1,7 @@
 """Probe: shader cycles per MFMA of the chain kernels' tile GEMM (field_kernels.h gemm_range) alone in a kernel
 (profiles/probes/gemm_rate.hip): 1 or 2 waves per SIMD, weight-prefetch depth 2 / 4 / 6 / 8, with and without the weight
-stream (L2 -> registers) and the LDS fragment reads, single-set (product) and two-set (-DBN_GEMM_B2) B fragments.
+stream (L2 -> registers) and the LDS fragment reads (a two-set B-fragment variant was measured in round 4 and dropped:
+profiles/r04_probe_gemm_rate.txt keeps its rows).
 32 cycles per MFMA per SIMD is the matrix pipe's rate.   python profiles/probe_gemm_rate.py [--build-only | --no-build]"""
 import ctypes as C
 import os
@@ -12,9 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "profiles", "probes", "gemm_rate.hip")
 OUT = os.path.join(ROOT, "brdf_nerf_amd", "build", "probe")
 VARIANTS = [(), ("BN_PROBE_NO_A",), ("BN_PROBE_NO_B",), ("BN_PROBE_NO_A", "BN_PROBE_NO_B"),
-            ("BN_GEMM_B2",), ("BN_GEMM_B2", "BN_PROBE_NO_A"), ("BN_GEMM_B2", "BN_PROBE_NO_B"), ("BN_GEMM_B2", "BN_PROBE_NO_A", "BN_PROBE_NO_B"),
             ("BN_PROBE_HALVES",), ("BN_PROBE_STREAM",)]
-TABLE1 = VARIANTS[:8]
+TABLE1 = VARIANTS[:4]
 
 
 def lib_of(defs):
@@ -60,7 +60,7 @@ if __name__ == "__main__":
                 torch.cuda.synchronize()
                 v = cyc.view(blocks, 8)[:, :4 * wps].reshape(-1).tolist()
                 row.append(statistics.median(v) / (layers * reps * 256))
-        name = "two-set B (-DBN_GEMM_B2)" if "BN_GEMM_B2" in defs else "single-set B (product)"
+        name = "chain GEMM (product)"
         name += "".join({"BN_PROBE_NO_A": ", no weight stream", "BN_PROBE_NO_B": ", no LDS reads"}.get(d, "") for d in defs)
         print(f"{name:44s} " + " ".join(f"{x:16.1f}" for x in row))
 

@@ -4,6 +4,64 @@
 // of one wave with 1 or 2 waves per SIMD, by weight-prefetch depth, with and without the operand traffic.
 #include "field_kernels.h"
 
+// ---- The chain GEMM fed by a CONTINUOUS weight stream (measured here, not adopted).  The ring of DEPTH weight-fragment slots `A` belongs to the
+// caller and is never drained: while segment s runs its last DEPTH k-steps, the slots are re-filled with the FIRST k-steps of
+// the segment that follows (another k-range of the same matrix, the next layer's matrix, ...), which depend on nothing the
+// kernel computes.  The idea: (a) no pipeline fill per segment - a chain kernel
+// starts 2-3 GEMM segments per layer, each of which exposed an L2 round trip; (b) a wave's loads retire in issue order behind
+// its own stores (vmcnt): the first weight loads of a GEMM used to be issued right after the epilogue's burst of stash
+// stores and waited for every one of them (the GEMM alone 35 / 56 cycles per MFMA at one / two waves per SIMD, 45 / 78 with a
+// layer's 24 stores per wave in front of it); here they are issued BEFORE the epilogue.  Result (profiles/r04_probe_gemm_rate.txt):
+// no gain - with the stores the probe is bound by HBM write bandwidth (4.9 TB/s), not by the order of the queue.  Segments are whole multiples of DEPTH k-steps (slot indices stay compile-time).
+template <typename T, int NTW, int DEPTH>
+__device__ __forceinline__ void wstream_start(typename Elem<T>::frag (&A)[DEPTH][NTW], const T *__restrict__ wp, int KS, int k0, int lane) {
+  const T *wl = wp + (size_t)lane * 8;
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) A[d][nt] = gld_frag<T>(wl + ((size_t)nt * KS + k0 + d) * 512);
+}
+// k-steps [k0, k0 + nks) of the packed matrix wp (n-tiles KS k-steps apart); the stream continues at k-step k0n of matrix wpn
+// (n-tiles KSn apart).  The last segment of a stream passes its own matrix and k0n = k0 + nks - DEPTH (a harmless re-read).
+template <typename T, int MT, int NTW, int DEPTH>
+__device__ __forceinline__ void gemm_stream(f32x16 (&acc)[NTW][MT], typename Elem<T>::frag (&A)[DEPTH][NTW], const T *__restrict__ wp, int KS,
+                                            int k0, int nks, const T *__restrict__ wpn, int KSn, int k0n, const T *bsrc, int ldb, int lane) {
+  typedef typename Elem<T>::frag frag;
+  const int r = lane & 31, h = lane >> 5;
+  const T *wl = wp + (size_t)lane * 8, *wln = wpn + (size_t)lane * 8;
+  const T *bl = bsrc + (size_t)r * ldb + 8 * h;
+  const int kend = k0 + nks;
+  frag Bc[MT];
+  auto loadB = [&](frag(&B)[MT], int ks) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) B[mt] = lds_frag<T>(bl + (size_t)mt * 32 * ldb + ks * 16);
+  };
+  loadB(Bc, k0);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int ks = k0; ks < kend; ks += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      frag Bn[MT];
+      loadB(Bn, ks + d + 1 < kend ? ks + d + 1 : k0);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], A[d][nt], Bc[mt]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) Bc[mt] = Bn[mt];
+      // re-fill the slot: DEPTH k-steps ahead in this segment, or the head of the next one
+      const int kk = ks + d + DEPTH;
+      const bool cur = kk < kend;
+      const T *pw = cur ? wl : wln;
+      const int K2 = cur ? KS : KSn, ki = cur ? kk : k0n + (kk - kend);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) A[d][nt] = gld_frag<T>(pw + ((size_t)nt * K2 + ki) * 512);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+
 template <int WPS, int DEPTH>
 __global__ __launch_bounds__(256 * WPS, WPS) void gemm_rate_kernel(const bf16 *packed, int layers, int reps, unsigned long long *cyc, float *sink,
                                                                    char *stream, size_t stream_bytes, int stores) {
