@@ -148,7 +148,7 @@ _SIGS = {
 }
 
 PROF_NAMES = ["pack", "field_fwd_sigma", "field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad", "composite_fwd",
-              "composite_bwd", "guided_samples", "stratified_z", "adam", "brdf", "field_adjoint", "field_adjoint_bwd"]
+              "composite_bwd", "guided_samples", "stratified_z", "adam", "brdf", "field_adjoint", "field_adjoint_bwd", "wgrad_reduce"]
 
 
 def prof_enable(on):
@@ -204,9 +204,10 @@ def lib():
 
 
 def set_deterministic(on=True):
-    """Run-to-run reproducible parameter gradients (bn_set_deterministic; the reference's Trainer(deterministic=True),
-    main.py:726): the split weight-gradient sums are added in a fixed order.  Also switched on by BRDFNERF_DETERMINISTIC=1.
-    Returns the previous setting."""
+    """The reference's Trainer(deterministic=True) (main.py:726).  Since round 4 the parameter gradients are bitwise reproducible
+    in EVERY mode (the weight-gradient kernels write per-split slabs that are summed in fixed order: no atomics); what the switch
+    still changes is the REPORTED loss of the launch-lean step: a fixed-order sum of the per-ray terms instead of atomically
+    added partial sums.  Also switched on by BRDFNERF_DETERMINISTIC=1.  Returns the previous setting."""
     return bool(lib().bn_set_deterministic(1 if on else 0))
 
 

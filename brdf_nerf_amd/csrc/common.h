@@ -51,7 +51,6 @@ int bn_configure_lds(const void *kernel, size_t lds, const char *what);
 // bn_set_deterministic(): process-wide switch read by bn_field_backward (field_bwd.hip, det_enter)
 int bn_deterministic();
 #define BN_MAX_CH 32             // channels of a field output row: rgb3 + sigma + beta + two normals + three 3-wide BRDF heads = 20 at most today
-#define BN_DET_TICKETS 4096      // turn counters per backward call: first half weight-gradient tiles, second half skinny jobs
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t bn_esize(int dtype) { return dtype == BN_F32 ? 4 : 2; }

@@ -48,9 +48,6 @@ extern "C" const char *bn_build_flags(void) {
 #ifdef BN_GEMM_PRIO
          "BN_GEMM_PRIO "
 #endif
-#ifdef BN_STASH_AUX
-         "BN_STASH_AUX "
-#endif
 #ifdef BN_NO_NT_STASH
          "BN_NO_NT_STASH "
 #endif

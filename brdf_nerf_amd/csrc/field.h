@@ -152,7 +152,6 @@ struct StashLayout {
   size_t gscale;                  // fp32 [2] as bits: max |d pre-activation| (primal chain), max |gbar_PE| (adjoint chain): fp16 loss scaling
   size_t sraw;                    // fp32 [Mpad]  pre-softplus sigma
   size_t nraw;                    // fp32 [Mpad][4] learned-normal pre-normalisation vector
-  size_t tickets;                 // u32 [BN_DET_TICKETS] turn counters of the deterministic mode (field_bwd.hip det_enter)
   size_t dpre_trunk;              // fp32 [Mpad][4]  (d sigma_raw, d normal_raw xyz)      (bwd-produced)
   size_t dpre_head;               // fp32 [Mpad][BN_DPH] (per head, 3 each)                   (bwd-produced)
   size_t pe;                      // T [Mpad][KP]
@@ -174,9 +173,27 @@ struct StashLayout {
   size_t adj_a[BN_MAX_LAYERS];      // T native      a_{l+1}
   size_t adj_abar[BN_MAX_LAYERS + 1];  // T [Mpad][F] abar_l, l = 1..L                                       (bwd-produced)
   size_t adj_zbar[BN_MAX_LAYERS];   // Elem<T>::wide native  extra d L / d z_l through D_l (bf16 in the fp16 mode)    (bwd-produced)
+  size_t wgpart, wgpart_bytes;    // fp32 slabs of the weight-gradient kernels: one per (output tile, point split) (field_wgrad.hip)
   size_t total;
   int64_t Mpad;
 };
+
+// Bytes of the weight-gradient slab workspace for a point set of Mpad rows: the launchers' largest grids (field_wgrad.hip
+// bn_launch_wgrad: <= 1024 workgroups of 256 x 256 tiles in the 16-bit modes, <= 2048 of 128 x 128 in fp32, splits of >= 512 / 256
+// points), bounded by the job list a model can have, and the skinny jobs' [job][split] slabs.
+static inline size_t bn_wgpart_bytes(const FieldGeom &g, int64_t Mpad, size_t esz) {
+  const bool half = esz != 4;
+  const int64_t tl = half ? 256 : 128, ft = (g.F + tl - 1) / tl;
+  const int64_t tiles_bound = (2 * g.L + 12) * ft * ft;
+  const int64_t by_grid = (half ? 1024 : 2048) + 2 * tiles_bound + 8;
+  const int64_t by_points = tiles_bound * ceil_div64(Mpad, half ? 512 : 256);
+  const int64_t slabs = by_grid < by_points ? by_grid : by_points;
+  const size_t wg = (size_t)slabs * (size_t)(tl * tl + tl) * 4;
+  int64_t sk_splits = ceil_div64(Mpad, g.BM);
+  if (sk_splits > 256) sk_splits = 256;
+  const size_t sk = (size_t)10 * (size_t)sk_splits * (4 * 512 + 4) * 4;
+  return wg > sk ? wg : sk;
+}
 
 static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, int BM, size_t esz, StashLayout *s) {
   const size_t dsz = esz == 4 ? 4 : 1;   // Elem<T>::kD8: one byte per derivative in the 16-bit modes
@@ -187,7 +204,6 @@ static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, in
   s->gscale = take(256);
   s->sraw = take((size_t)Mpad * 4);
   s->nraw = take((size_t)Mpad * 16);
-  s->tickets = take((size_t)BN_DET_TICKETS * 4);
   s->dpre_trunk = take((size_t)Mpad * 16);
   s->dpre_head = take((size_t)Mpad * BN_DPH * 4);
   s->pe = take((size_t)Mpad * g.KP * esz);
@@ -220,6 +236,8 @@ static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, in
       s->adj_zbar[l] = take((size_t)Mpad * g.F * esz);
     }
   }
+  s->wgpart_bytes = bn_wgpart_bytes(g, Mpad, esz);
+  s->wgpart = take(s->wgpart_bytes);
   s->total = off;
 }
 

@@ -408,7 +408,6 @@ extern "C" int bn_field_backward_parts(const bn_field_desc *desc, const bn_field
                                        pts->seg1_points % pts->n_samples == 0 && (pts->n_points - pts->seg1_points) % pts->n_samples2 == 0),
              "field_backward: bad two-block point set");
   BN_REQUIRE(pts->seg1_points == 0 || !(desc->t_dim > 0 && G->d_t_embed), "field_backward: d_t_embed is not served for a two-block point set");
-  BN_REQUIRE(parts == BN_BWD_ALL || !bn_deterministic(), "field_backward: the deterministic mode runs the whole backward in one call");
   const FieldGeom &g = a.g;
   a.d = *desc; a.p = *params; a.packed = packed; a.M = pts->n_points; a.out = out; a.d_out = d_out; a.stash = (char *)stash;
   bn_make_packed_layout(g, &a.pl);
@@ -453,7 +452,7 @@ extern "C" int bn_field_backward_parts(const bn_field_desc *desc, const bn_field
   char *S = (char *)stash;
   const int F = g.F, P0 = g.P;
   WgradArgs w;
-  w.n_jobs = 0; w.Mpad = sl.Mpad; w.tile0[0] = 0; w.amax = amax;
+  w.n_jobs = 0; w.Mpad = sl.Mpad; w.tile0[0] = 0; w.amax = amax; w.part = nullptr; w.n_split = 1;
   int scale_sel = 1;   // gradient operand of the jobs added next: 1 = primal chain (dZ_l, dG), 2 = adjoint chain (gbar_PE, abar_l)
   int b_native = 0;    // B operand of the jobs added next: a native-order layer-output stash (16-bit modes) or a row-major array
   int part = BN_BWD_WGRAD_TRUNK;   // which part of the backward the jobs added next belong to (bn_field_backward_parts)
@@ -513,46 +512,14 @@ extern "C" int bn_field_backward_parts(const bn_field_desc *desc, const bn_field
     add(S + sl.dG[0], g.pass_N[0], g.H2, S + sl.dirpe, g.KD, g.KT0, G->head1_wt, (int)G->head1_wt_ld, nullptr, g.H2, g.TD);
   }
   BN_REQUIRE(w.n_jobs <= BN_MAX_WGRAD_JOBS, "field_backward: too many wgrad jobs");
-  // deterministic mode (det_enter): turn counters in the stash, zeroed per call
-  const bool det = bn_deterministic() != 0;
-  unsigned int *tickets = det ? (unsigned int *)(S + sl.tickets) : nullptr;
-  unsigned int tk_used = 0;
-  if (det) {   // a kernel node, not a memset node: the deterministic step is captured and replayed too (see the amax clear above)
-    clear_words_kernel<<<BN_DET_TICKETS / 256, 256, 0, st>>>(tickets, BN_DET_TICKETS);
-    BN_LAUNCH_CHECK("clear tickets");
-  }
-  auto launch_wgrad = [&](WgradArgs &wv, unsigned int *tk) -> int { return bn_launch_wgrad(wv, tk, bf, f16m, sl.Mpad, st); };
-  if (!det) {
-    if (w.n_jobs > 0)
-      if (int e = launch_wgrad(w, nullptr)) return e;
-  } else {
-    // jobs that add into the same matrix (same C: the primal and the analytic-normal term of a trunk layer) take separate,
-    // stream-ordered launches, each job list in its original order
-    bool left[BN_MAX_WGRAD_JOBS];
-    for (int j = 0; j < w.n_jobs; ++j) left[j] = true;
-    for (int n_left = w.n_jobs; n_left > 0;) {
-      WgradArgs gen = w;
-      gen.n_jobs = 0; gen.tile0[0] = 0;
-      for (int j = 0; j < w.n_jobs; ++j) {
-        if (!left[j]) continue;
-        bool clash = false;
-        for (int q = 0; q < gen.n_jobs; ++q) clash = clash || gen.job[q].C == w.job[j].C;
-        if (clash) continue;
-        gen.job[gen.n_jobs++] = w.job[j];
-        left[j] = false; --n_left;
-      }
-      // capacity BEFORE the launch indexes the turn counters (an upper bound: the launcher's tiles are 128 x 128 or larger)
-      unsigned int need = 0;
-      for (int q = 0; q < gen.n_jobs; ++q) need += (unsigned int)(((gen.job[q].N + 127) / 128) * ((gen.job[q].K + 127) / 128));
-      BN_REQUIRE(tk_used + need <= BN_DET_TICKETS / 2, "field_backward: too many output tiles for the deterministic mode");
-      if (int e = launch_wgrad(gen, tickets + tk_used)) return e;
-      tk_used += (unsigned int)gen.tile0[gen.n_jobs];
-      BN_REQUIRE(tk_used <= BN_DET_TICKETS / 2, "field_backward: too many output tiles for the deterministic mode");
-    }
-  }
+  // the point splits' partial tiles go to slabs in the stash and are summed in fixed order (field_wgrad.hip): no atomics, a
+  // bitwise reproducible gradient in every mode
+  float *wgpart = (float *)(S + sl.wgpart);
+  if (w.n_jobs > 0)
+    if (int e = bn_launch_wgrad(w, bf, f16m, sl.Mpad, wgpart, sl.wgpart_bytes, st)) return e;
   if (!(parts & BN_BWD_SKINNY)) return 0;
   SkinnyArgs s;
-  s.n_jobs = 0; s.Mpad = sl.Mpad; s.amax = amax;
+  s.n_jobs = 0; s.Mpad = sl.Mpad; s.amax = amax; s.part = nullptr;
   for (int i = 0; i < BN_MAX_SKINNY_JOBS; ++i) { s.job[i].scale_sel = 0; s.job[i].unit_dpre = 0; }   // X = forward activations unless noted
   {
     SkinnyJob &j = s.job[s.n_jobs];
@@ -589,43 +556,18 @@ extern "C" int bn_field_backward_parts(const bn_field_desc *desc, const bn_field
 #ifndef SKINNY_SPLITS
 #define SKINNY_SPLITS 256   // 512: 0.129 ms, 256: 0.102 ms, 128: 0.169 ms per launch (the per-block LDS + global atomics tail vs parallelism)
 #endif
-    // deterministic mode: the splits of a job add one after the other (~3.5 us a turn): 64 instead of 256 (0.94 -> see
-    // profiles/r02_ablation.txt)
     // small batches (strong scaling: 512 rays per GPU = 32,768 points per launch): a block walks its points in a latency-bound
-    // loop, so fewer points per block is faster until the atomics tail takes over - at least 2 point tiles per split
+    // loop, so fewer points per block is faster until the per-block tail takes over - at least 2 point tiles per split
     // (session 50, 512 rays: 32 splits 0.085 ms, 64 0.066, 128 0.060, 256 0.089 per launch)
-    int skinny_splits = det ? 64 : SKINNY_SPLITS;
+    int skinny_splits = SKINNY_SPLITS;
     {
       int64_t most = sl.Mpad / (2 * (int64_t)BM) > 1 ? sl.Mpad / (2 * (int64_t)BM) : 1;
-      if (sl.Mpad <= 131072 && most > 128) most = 128;      // up to 2048 rays x 64 samples: 128 blocks per job keep the atomics tail short
+      if (sl.Mpad <= 131072 && most > 128) most = 128;      // up to 2048 rays x 64 samples: 128 blocks per job keep the tail short
       if (skinny_splits > most) skinny_splits = (int)most;
     }
     int64_t smpb = ceil_div64(ceil_div64(sl.Mpad, skinny_splits), BM) * BM;   // whole tiles per block (native jobs walk tile images)
     s.m_per_block = (int)smpb;
-    auto launch_skinny = [&](SkinnyArgs &sv, unsigned int *tk) -> int { return bn_launch_skinny(sv, tk, bf, f16m, sl.Mpad, smpb, st); };
-    if (!det) {
-      if (int e = launch_skinny(s, nullptr)) return e;
-    } else {     // same rule as above: two jobs that add into the same row (sigma_w: primal and analytic-normal term) never share a launch
-      bool left[BN_MAX_SKINNY_JOBS];
-      for (int j = 0; j < s.n_jobs; ++j) left[j] = true;
-      unsigned int tk2 = BN_DET_TICKETS / 2;
-      for (int n_left = s.n_jobs; n_left > 0;) {
-        SkinnyArgs gen = s;
-        gen.n_jobs = 0;
-        for (int j = 0; j < s.n_jobs; ++j) {
-          if (!left[j]) continue;
-          bool clash = false;
-          for (int q = 0; q < gen.n_jobs; ++q)
-            for (int c = 0; c < 4; ++c)
-              for (int c2 = 0; c2 < 4; ++c2) clash = clash || (s.job[j].out[c] && gen.job[q].out[c2] == s.job[j].out[c]);
-          if (clash) continue;
-          gen.job[gen.n_jobs++] = s.job[j];
-          left[j] = false; --n_left;
-        }
-        if (int e = launch_skinny(gen, tickets + tk2)) return e;
-        tk2 += (unsigned int)gen.n_jobs;
-      }
-    }
+    if (int e = bn_launch_skinny(s, bf, f16m, sl.Mpad, smpb, wgpart, sl.wgpart_bytes, st)) return e;
   }
   if (g.TD > 0 && G->d_t_embed) {   // gradient of the beta head's embedding input, per point
     BN_REQUIRE(params->head1_wt && params->head1_wt_ld >= g.TD && g.H2 <= 256, "field_backward: head1_wt missing (beta)");

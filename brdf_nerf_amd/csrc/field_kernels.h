@@ -104,20 +104,24 @@ template <typename V> __device__ __forceinline__ V stash_load(const V *p) {
 #endif
 }
 
-// The same stores as buffer instructions: `base` wave-uniform (kernel arguments and blockIdx only), the lane's part in one
-// VGPR (voff), everything else in a scalar offset - no 64-bit vector address arithmetic per store (16 stores of a layer's
-// epilogue otherwise pin 32 address registers).
+// The same stores as buffer instructions: `base` wave-uniform (kernel arguments and blockIdx only), the lane's part in one VGPR
+// (voff), everything else in the scalar offset - no 64-bit vector address arithmetic per store (16 stores of a layer's epilogue
+// otherwise pin 32 address registers).
+// Written as inline asm WITH its wait states: behind `__builtin_amdgcn_raw_buffer_store_b128(..., soffset = an SGPR, ...)` hipcc
+// (ROCm 7.2) schedules a VALU write of the store's data registers directly after the store - LLVM's hazard recognizer knows no
+// store-data hazard for MUBUF stores with a register soffset - and on gfx950 the first dword of the stored piece then came out
+// clobbered now and then: a stash that differed from run to run, found by the fuzz as non-finite gradients
+// (profiles/r04_ablation.txt item 5).  hipcc does not count an asm store in its vmcnt bookkeeping; that only makes its waits for
+// later loads wait for more than they need.
 __device__ __forceinline__ auto stash_rsrc(const void *base) { return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000); }
 template <typename R, typename V> __device__ __forceinline__ void stash_store_buf(R rsrc, int voff, int soff, const V &v) {
   static_assert(sizeof(V) == 16, "one 16-byte piece per lane");
-#ifndef BN_STASH_AUX      // A/B switch (results unchanged): cache policy of the stash stores: 0 plain, 2 nt, 16 sc1 (write-through), 18 sc1 nt
+  const u32x4 d = __builtin_bit_cast(u32x4, v);
 #ifdef BN_NO_NT_STASH
-#define BN_STASH_AUX 0
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(d), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 #else
-#define BN_STASH_AUX 2
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(d), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 #endif
-#endif
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff, soff, BN_STASH_AUX);
 }
 
 // Instantiate-and-call FN<T, MT, NT, WAVES> ARGS for the tile configuration in geometry G (returns from the caller).

@@ -26,8 +26,15 @@ struct WgradArgs {
   int64_t Mpad;
   int m_per_block;                   // points per split (multiple of 32)
   const float *amax;                 // fp16 mode only (else nullptr): see wg_unscale
-  unsigned int *tickets;             // deterministic mode: one turn counter per output tile of this launch (else nullptr)
+  float *part;                       // slab workspace: [output tile of the launch][point split][WG_SLAB256 / WG_SLAB128 floats]
+  int n_split;                       // point splits of this launch
+  int chain_next[BN_MAX_WGRAD_JOBS]; // next job that adds into the same matrix (-1: none): summed by the head job's reduce blocks
+  unsigned char head[BN_MAX_WGRAD_JOBS];
 };
+// floats per slab: the accumulators of one workgroup in register order + its bias column sums
+#define WG_SLAB256 (256 * 256 + 256)
+#define WG_SLAB128 (128 * 128 + 128)
+#define SK_SLAB (4 * 512 + 4)
 
 struct SkinnyJob {
   const void *X;       // [Mpad][ldx] T, or (native != 0) accumulator-order tile images: see native_off8
@@ -47,14 +54,14 @@ struct SkinnyArgs {
   int64_t Mpad;
   int m_per_block;
   const float *amax;
-  unsigned int *tickets;   // deterministic mode: one turn counter per job of this launch (else nullptr), see det_enter
+  float *part;             // slab workspace: [job][point split][SK_SLAB floats]
 };
 
-// Launch the weight-gradient jobs of `wv` (tile0 / m_per_block / tickets are filled in here).  bf: 16-bit modes (256 x 256
-// tiles, wgrad256_kernel), f16m: fp16; tk != nullptr: deterministic mode, one turn counter per output tile of this launch
-// (the number of tiles is returned in wv.tile0[wv.n_jobs]).
-int bn_launch_wgrad(WgradArgs &wv, unsigned int *tk, bool bf, bool f16m, int64_t Mpad, hipStream_t st);
-// Launch the skinny (<= 4 rows) jobs of `sv` with `m_per_block` points per split; tk as above, one counter per job.
-int bn_launch_skinny(SkinnyArgs &sv, unsigned int *tk, bool bf, bool f16m, int64_t Mpad, int64_t m_per_block, hipStream_t st);
-// 1 = a deterministic-mode turn wait timed out (bit 31: the word could not be read)
+// Launch the weight-gradient jobs of `wv` (tile0 / m_per_block / n_split / chains are filled in here) and the fixed-order sum of
+// their slabs into the gradient.  bf: 16-bit modes (256 x 256 tiles, wgrad256_kernel), f16m: fp16; part / part_bytes: the slab
+// workspace (StashLayout.wgpart).
+int bn_launch_wgrad(WgradArgs &wv, bool bf, bool f16m, int64_t Mpad, float *part, size_t part_bytes, hipStream_t st);
+// Launch the skinny (<= 4 rows) jobs of `sv` with `m_per_block` points per split, and their reduce.
+int bn_launch_skinny(SkinnyArgs &sv, bool bf, bool f16m, int64_t Mpad, int64_t m_per_block, float *part, size_t part_bytes, hipStream_t st);
+// (bn_device_faults bit 1; always 0 since round 4)
 unsigned int bn_bwd_fault_read(hipStream_t st);

@@ -9,39 +9,16 @@
 #include "field_kernels.h"
 #include "field_wgrad.h"
 
-// ---- deterministic accumulation (bn_set_deterministic(1)) ---------------------------------------------------------------------
-// The weight-gradient kernels split the points over many workgroups that add their partial sums into the same fp32 output with
-// atomics: the order of those additions - and with it the last bits of the gradient - changes from run to run.  In deterministic
-// mode the workgroups that add into one output tile take TURNS in split order: a ticket per output tile (zeroed per call, in the
-// stash) counts the splits that have added; split s waits for ticket == s, adds (the same atomics), fences, and passes the turn.
-// Blocks are numbered split-major, and the hardware starts blocks in id order on every XCD, so the block a waiter depends on was
-// always started before it: the smallest unfinished id never waits.  Jobs that add into the same matrix (the primal and the
-// analytic-normal term of a trunk layer) go to separate, stream-ordered launches.  The spin is bounded; a timeout is reported
-// through bn_device_faults() (bit 1) and the block proceeds.
-__device__ unsigned int g_det_fault = 0u;
-__device__ __forceinline__ void det_enter(unsigned int *ticket, unsigned int seq) {
-  if (ticket == nullptr) return;
-  if (threadIdx.x == 0) {
-    unsigned int spins = 0;
-    while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
-      __builtin_amdgcn_s_sleep(32);
-      if (++spins > (1u << 25)) { g_det_fault = 1u; break; }   // ~ 30 s: never in a correct run
-    }
-  }
-  __syncthreads();
-}
-__device__ __forceinline__ void det_leave(unsigned int *ticket) {
-  if (ticket == nullptr) return;
-  __threadfence();       // this workgroup's additions are performed before the next one's turn
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-unsigned int bn_bwd_fault_read(hipStream_t st) {   // (bn_device_faults, field_fwd.hip)
-  unsigned int v = 0u;
-  if (hipStreamSynchronize(st) != hipSuccess) return 0x80000000u;
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_det_fault), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) return 0x80000000u;
-  return v;
-}
+// ---- accumulation across the point splits: slabs + a fixed-order sum (round 4) ------------------------------------------------
+// The weight-gradient kernels split the points over many workgroups.  Rounds 1-3 added the workgroups' partial tiles into the
+// gradient with fp32 atomics (261 MB of atomic traffic per step at the 1.3 TB/s the chip gives them, and a run-to-run order: a
+// bitwise reproducible gradient needed a turn-taking mode that cost 13-16 % of a step).  Now every workgroup writes its partial
+// tile with plain 16-byte stores into ITS OWN slab of a workspace in the stash ([output tile][point split], accumulator-register
+// order: 1 KB per wave instruction), and wgrad_reduce_kernel / skinny_reduce_kernel add the slabs of an output element in split
+// order - and the jobs that feed the same matrix (primal + analytic-normal term of a trunk layer) in job order - into the gradient
+// with one read-modify-write per element.  The gradient is bitwise reproducible by construction (the reference trains with
+// Trainer(deterministic=True), main.py:726), there is no inter-workgroup protocol left, and the stores run at HBM speed.
+unsigned int bn_bwd_fault_read(hipStream_t) { return 0u; }   // (bn_device_faults bit 1: the turn-taking mode it reported on is gone)
 
 // 1 / (scale carried by the job's gradient operand): multiplies the fp32 sums before they are accumulated
 __device__ __forceinline__ float wg_unscale(const float *amax, int sel) {
@@ -135,23 +112,18 @@ template <typename T> __global__ __launch_bounds__(256) void wgrad_kernel(const 
       for (int row = 0; row < WG_BK; ++row) bsum += (float)sA[row * LD + tid];
     }
   }
-  // C[n][k]: accumulator row index = n (A operand rows), column (lane&31) = k
-  const int r = lane & 31, h = lane >> 5;
-  unsigned int *ticket = A.tickets ? A.tickets + blockIdx.x : nullptr;
-  det_enter(ticket, blockIdx.y);
+  // this workgroup's slab: accumulators in register order (C[n][k]: accumulator row index = n, column (lane & 31) = k), then the
+  // 128 bias column sums
+  float *P = A.part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * WG_SLAB128;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int k = k0 + wc * 64 + b * 32 + r;
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int n = n0 + wr * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (n < J.N && k < J.K) atomicAdd(J.C + (size_t)n * J.ldc + k, acc[a][b][i]);
-      }
-    }
-  if (do_bias && n0 + tid < J.N) atomicAdd(J.bias + n0 + tid, bsum);
-  det_leave(ticket);
+      for (int q = 0; q < 4; ++q)
+        *(f32x4 *)(P + (size_t)(((((wave * 2 + a) * 2 + b) * 4 + q) * 64 + lane) * 4)) =
+            f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+  if (do_bias) P[128 * 128 + tid] = bsum;
 }
 
 // ---- bf16 throughput variant: 256(n) x 256(k) output tile per 8-wave workgroup, 32-point stages double-buffered in
@@ -205,9 +177,8 @@ template <typename T> __device__ __forceinline__ typename Elem<T>::frag w2_frag(
 // One 256 x 256 output tile over the points [mb, me).  NBV = 32-column accumulator tiles this WAVE multiplies (4 for a
 // full tile; the 60-column positional-encoding operand only has columns for two tiles of the wc = 0 waves - the other
 // waves of such a block just take part in staging and barriers).
-template <typename T, int NBV, bool BNAT, bool DET>
-__device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64_t mb, int64_t me, T *sA, T *sB, float osc,
-                                        unsigned int *ticket, unsigned int seq) {
+template <typename T, int NBV, bool BNAT>
+__device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64_t mb, int64_t me, T *sA, T *sB, float *P) {
   typedef typename Elem<T>::frag frag_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
   const T *gA = (const T *)J.A + J.a_col0 + n0;
@@ -343,42 +314,36 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
     WG_PH(0)
     buf ^= 1;
   }
+  // the workgroup's slab P: accumulators in register order (tile (a, b) of wave w, registers 4 q .. 4 q + 3 of lane l at float
+  // ((((w W2_RA + a) 4 + b) 4 + q) 64 + l) 4: one 16-byte store per lane, 1 KB per wave instruction), then the 256 bias column sums
   const int r = lane & 31, h = lane >> 5;
-  if constexpr (DET) det_enter(ticket, seq);
 #pragma unroll
   for (int a = 0; a < W2_RA; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int k = k0 + wc * 128 + b * 32 + r;
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int n = n0 + wr * (W2_RA * 32) + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (n < J.N && k < J.K) atomicAdd(J.C + (size_t)n * J.ldc + k, acc[a][b][i] * osc);
-      }
-    }
+      for (int q = 0; q < 4; ++q)
+        *(f32x4 *)(P + (size_t)(((((wave * W2_RA + a) * 4 + b) * 4 + q) * 64 + lane) * 4)) =
+            f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
   if (do_bias) {
 #pragma unroll
     for (int a = 0; a < W2_RA; ++a) {
-      const float v = (bsum[a] + __shfl_xor(bsum[a], 32)) * osc;
-      const int n = n0 + wr * (W2_RA * 32) + a * 32 + r;
-      if (h == 0 && n < J.N) atomicAdd(J.bias + n, v);
+      const float v = bsum[a] + __shfl_xor(bsum[a], 32);
+      if (h == 0) P[256 * 256 + wr * (W2_RA * 32) + a * 32 + r] = v;
     }
   }
-  if constexpr (DET) det_leave(ticket);
   WG_PH(4)
   WG_PH_FLUSH
 }
 
-// DET (deterministic mode) is a template parameter: as a run-time branch it cost the default kernel 3 % (profiles/r02_ablation.txt)
-template <typename T, bool DET>
+template <typename T>
 __global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256_kernel(const WgradArgs A, int n_split, int n_blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem_w[];
   T *sA = (T *)smem_w;                 // [2][W2_BK][W2_LD]
   T *sB = sA + 2 * W2_STAGE;
   // XCD-aware id: hardware deals consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous range
-  // (deterministic mode: ids in dispatch order, see det_enter - the tiles of a split then sit on different XCDs)
   const int per = n_blocks / 8;              // n_blocks is a multiple of 8
-  const int lid = DET ? (int)blockIdx.x : (int)((blockIdx.x % 8) * per + blockIdx.x / 8);
+  const int lid = (int)((blockIdx.x % 8) * per + blockIdx.x / 8);
   const int total_tiles = A.tile0[A.n_jobs];
   if (lid >= total_tiles * n_split) return;
   const int split = lid / total_tiles, tt = lid % total_tiles;
@@ -393,19 +358,18 @@ __global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256
   if (mb >= me) return;
   const int wc = (threadIdx.x >> 6) & 1;
   const int cols = J.K - k0 - wc * 128;          // output columns this wave's tiles can reach
-  const float osc = wg_unscale(A.amax, J.scale_sel);
-  unsigned int *ticket = DET ? A.tickets + tt : nullptr;
+  float *P = A.part + ((size_t)tt * n_split + split) * WG_SLAB256;
 #ifdef BN_CLOCK_STAMP_WGRAD
   BN_CLK_BEGIN
 #endif
   if (J.b_native) {     // layer-output operand in native order: full-width column blocks only (F is a multiple of 64)
-    if (cols >= 65) w2_body<T, 4, true, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
-    else if (cols >= 33) w2_body<T, 2, true, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
-    else w2_body<T, 0, true, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
-  } else if (cols >= 65) w2_body<T, 4, false, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
-  else if (cols >= 33) w2_body<T, 2, false, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
-  else if (cols >= 1) w2_body<T, 1, false, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
-  else w2_body<T, 0, false, DET>(J, n0, k0, mb, me, sA, sB, osc, ticket, (unsigned int)split);
+    if (cols >= 65) w2_body<T, 4, true>(J, n0, k0, mb, me, sA, sB, P);
+    else if (cols >= 33) w2_body<T, 2, true>(J, n0, k0, mb, me, sA, sB, P);
+    else w2_body<T, 0, true>(J, n0, k0, mb, me, sA, sB, P);
+  } else if (cols >= 65) w2_body<T, 4, false>(J, n0, k0, mb, me, sA, sB, P);
+  else if (cols >= 33) w2_body<T, 2, false>(J, n0, k0, mb, me, sA, sB, P);
+  else if (cols >= 1) w2_body<T, 1, false>(J, n0, k0, mb, me, sA, sB, P);
+  else w2_body<T, 0, false>(J, n0, k0, mb, me, sA, sB, P);
 #ifdef BN_CLOCK_STAMP_WGRAD
   BN_CLK_END
 #endif
@@ -469,12 +433,10 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               float *dst = &red[c * 512 + cb * 32 + 16 * gp + 4 * h + (e & 3) + 8 * (e >> 2)];
-              if (A.tickets) {          // deterministic mode: a fixed butterfly over the 32 points instead of 32-way LDS atomics
-                float v = s[gp][c][e];
+              float v = s[gp][c][e];     // a fixed butterfly over the 32 points (no LDS atomics: the order of additions is part of the result)
 #pragma unroll
-                for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-                if (r == 0) *dst = v;   // (column blocks of different waves are disjoint)
-              } else atomicAdd(dst, s[gp][c][e]);   // LDS, 32-way
+              for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+              if (r == 0) *dst = v;      // (column blocks of different waves are disjoint)
             }
         }
       if (cb == 0) {   // the bias gradient is the dpre column sum: taken from the pass over the head's first column block
@@ -488,12 +450,10 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         if (c < J.nc) {
-          if (A.tickets) {
-            float v = bs0[c];
+          float v = bs0[c];
 #pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-            if (r == 0) red[4 * 512 + c] = v;
-          } else atomicAdd(&red[4 * 512 + c], bs0[c]);
+          for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+          if (r == 0) red[4 * 512 + c] = v;
         }
     }
   } else {
@@ -522,107 +482,241 @@ template <typename T> __global__ __launch_bounds__(256) void skinny_wgrad_kernel
       }
     }
   }
-  // row groups meet in LDS (nrg-way LDS atomics; deterministic mode: the row groups add one after the other)
-  if (A.tickets) {
-    for (int turn = 0; turn < nrg; ++turn) {
-      if (rg == turn) {
+  // row groups meet in LDS one after the other (fixed order)
+  for (int turn = 0; turn < nrg; ++turn) {
+    if (rg == turn) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (c < J.nc) {
+      for (int c = 0; c < 4; ++c)
+        if (c < J.nc) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[c * 512 + cg * 8 + e] += s[c][e];
-            if (cg == 0) red[4 * 512 + c] += bs[c];
-          }
-      }
-      __syncthreads();
+          for (int e = 0; e < 8; ++e) red[c * 512 + cg * 8 + e] += s[c][e];
+          if (cg == 0) red[4 * 512 + c] += bs[c];
+        }
     }
-  } else if (rg < nrg) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (c < J.nc) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(&red[c * 512 + cg * 8 + e], s[c][e]);
-        if (cg == 0) atomicAdd(&red[4 * 512 + c], bs[c]);
-      }
+    __syncthreads();
   }
   }
-  // ONE global atomic per output element per block (same-address atomics from thousands of adders serialise at the
-  // memory side)
+  // the block's sums go to ITS slab [job][split][4 x 512 + 4] (plain stores; skinny_reduce_kernel adds the splits up in order)
   __syncthreads();
-  unsigned int *ticket = A.tickets ? A.tickets + blockIdx.y : nullptr;
-  det_enter(ticket, blockIdx.x);
+  float *SP = A.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SK_SLAB;
   for (int i = tid; i < J.nc * J.K; i += 256) {
     const int c = i / J.K, k = i % J.K;
-    atomicAdd(J.out[c] + k, red[c * 512 + k] * osc);
+    SP[c * 512 + k] = red[c * 512 + k];
   }
-  if (tid < J.nc && J.bias[tid]) atomicAdd(J.bias[tid], red[4 * 512 + tid]);   // bias sums come from the unscaled fp32 dpre
-  det_leave(ticket);
+  if (tid < 4) SP[4 * 512 + tid] = tid < J.nc ? red[4 * 512 + tid] : 0.f;
+}
+
+// ---- fixed-order sums of the slabs into the gradient ------------------------------------------------------------------------
+// One thread per float4 of a HEAD job's slab image (256 per workgroup): element = sum over the job's splits in split order, then
+// over the jobs chained to it (same matrix, same tiling), each times its own loss-scale factor; one += per gradient element.
+// The loads of 8 splits are issued together (independent addresses), the additions stay in split order.
+template <int TILE> __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs A) {
+  constexpr int NB = TILE / 64;                          // 32-column accumulator tiles per wave (4: 256-tile, 2: 128-tile)
+  constexpr int SLAB = TILE * TILE + TILE;
+  constexpr int SUBS = TILE * TILE / 4 / 256;
+  const int tt = blockIdx.x / SUBS, sub = blockIdx.x % SUBS, tid = threadIdx.x;
+  int jb = 0;
+  while (jb + 1 < A.n_jobs && tt >= A.tile0[jb + 1]) ++jb;
+  if (!A.head[jb]) return;
+  const WgradJob &J = A.job[jb];
+  const int t = tt - A.tile0[jb];
+  const int tiles_k = (J.K + TILE - 1) / TILE;
+  const int n0 = (t / tiles_k) * TILE, k0 = (t % tiles_k) * TILE;
+  const int ns = A.n_split;
+  {
+    const int idx4 = sub * 256 + tid;
+    const int lane = idx4 & 63, q = (idx4 >> 6) & 3, b = (idx4 >> 8) % NB, a = ((idx4 >> 8) / NB) & 1, wave = (idx4 >> 8) / (NB * 2);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int jj = jb; jj >= 0; jj = A.chain_next[jj]) {
+      const float osc = wg_unscale(A.amax, A.job[jj].scale_sel);
+      const float *P = A.part + (size_t)(A.tile0[jj] + t) * ns * SLAB + (size_t)idx4 * 4;
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+      int sp = 0;
+      for (; sp + 8 <= ns; sp += 8) {
+        f32x4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = *(const f32x4 *)(P + (size_t)(sp + u) * SLAB);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += x[u];
+      }
+      for (; sp < ns; ++sp) sum += *(const f32x4 *)(P + (size_t)sp * SLAB);
+      v += sum * osc;
+    }
+    const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    const int k = k0 + wc * (TILE / 2) + b * 32 + r, nb = n0 + wr * 64 + a * 32 + 8 * q + 4 * h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (nb + e < J.N && k < J.K) J.C[(size_t)(nb + e) * J.ldc + k] += v[e];
+  }
+  if (sub == 0 && k0 == 0 && tid < TILE && n0 + tid < J.N) {      // bias gradients: column sums of the k = 0 tiles
+    float v = 0.f;
+    float *dst = nullptr;
+    for (int jj = jb; jj >= 0; jj = A.chain_next[jj]) {
+      if (!A.job[jj].bias) continue;
+      dst = A.job[jj].bias;
+      const float osc = wg_unscale(A.amax, A.job[jj].scale_sel);
+      const float *P = A.part + (size_t)(A.tile0[jj] + t) * ns * SLAB + TILE * TILE + tid;
+      float sum = 0.f;
+      for (int sp = 0; sp < ns; ++sp) sum += P[(size_t)sp * SLAB];
+      v += sum * osc;
+    }
+    if (dst) dst[n0 + tid] += v;
+  }
+}
+
+// Skinny slabs: one workgroup per (job, row c, 32 columns): thread (kk, g) adds splits g, g + 8, g + 16, ... of column kk in
+// order (8 independent loads at a time), the 8 partial sums meet in LDS and are added in order g = 0 .. 7; then the later jobs
+// that write the same row (the primal and the analytic-normal term of the sigma head), in job order.  Fixed order throughout.
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const SkinnyArgs A, int n_split) {
+  __shared__ float part[8][32], bpart[256];
+  const int jb = blockIdx.x, c = blockIdx.y, k0 = blockIdx.z * 32, tid = threadIdx.x, kk = tid & 31, g = tid >> 5;
+  const SkinnyJob &J = A.job[jb];
+  if (c >= J.nc || !J.out[c] || k0 >= J.K) return;
+  for (int j2 = 0; j2 < jb; ++j2)          // an earlier job owns this row
+    for (int c2 = 0; c2 < A.job[j2].nc; ++c2)
+      if (A.job[j2].out[c2] == J.out[c]) return;
+  float v = 0.f, vb = 0.f;
+  for (int j2 = jb; j2 < A.n_jobs; ++j2)
+    for (int c2 = 0; c2 < A.job[j2].nc; ++c2) {
+      if (A.job[j2].out[c2] != J.out[c]) continue;
+      const float osc = wg_unscale(A.amax, A.job[j2].scale_sel);
+      const float *P = A.part + (size_t)j2 * n_split * SK_SLAB;
+      // columns k0 + kk of row c2; lanes kk = 0 .. 3 of group 0 also carry the bias sum of row c2 (slab word 4 * 512 + c2)
+      const bool col = k0 + kk < A.job[j2].K;
+      float sum = 0.f;
+      int sp = g;
+      for (; sp + 56 < n_split; sp += 64) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = col ? P[(size_t)(sp + 8 * u) * SK_SLAB + c2 * 512 + k0 + kk] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += x[u];
+      }
+      for (; sp < n_split; sp += 8) sum += col ? P[(size_t)sp * SK_SLAB + c2 * 512 + k0 + kk] : 0.f;
+      __syncthreads();
+      part[g][kk] = sum;
+      __syncthreads();
+      if (g == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += part[q][kk];
+        v += t * osc;
+      }
+      if (k0 == 0 && A.job[j2].bias[c2] && J.bias[c]) {     // bias sums (of the unscaled fp32 dpre): one load per thread, added in split order
+        __syncthreads();
+        bpart[tid] = tid < n_split ? P[(size_t)tid * SK_SLAB + 4 * 512 + c2] : 0.f;
+        __syncthreads();
+        if (tid == 0) {
+          float t = 0.f;
+          for (int q = 0; q < n_split; ++q) t += bpart[q];
+          vb += t;
+        }
+      }
+    }
+  if (g == 0 && k0 + kk < J.K) J.out[c][k0 + kk] += v;
+  if (k0 == 0 && tid == 0 && J.bias[c]) *J.bias[c] += vb;
 }
 
 // ------------------------------------------------------------------------------------------------ host launchers
-int bn_launch_wgrad(WgradArgs &wv, unsigned int *tk, bool bf, bool f16m, int64_t Mpad, hipStream_t st) {
+// Chains of jobs that add into the same matrix (same C, extents and row stride: the primal and the analytic-normal term of a
+// trunk layer): the reduce kernel walks a chain from its head, in job order.
+static void wg_chain(WgradArgs &wv) {
+  for (int j = 0; j < wv.n_jobs; ++j) { wv.chain_next[j] = -1; wv.head[j] = 1; }
+  for (int j = 0; j < wv.n_jobs; ++j) {
+    if (!wv.head[j]) continue;
+    int last = j;
+    for (int q = j + 1; q < wv.n_jobs; ++q) {
+      const WgradJob &a = wv.job[j], &b = wv.job[q];
+      if (b.C == a.C && b.N == a.N && b.K == a.K && b.ldc == a.ldc) { wv.chain_next[last] = q; wv.head[q] = 0; last = q; }
+    }
+  }
+}
+
+int bn_launch_wgrad(WgradArgs &wv, bool bf, bool f16m, int64_t Mpad, float *part, size_t part_bytes, hipStream_t st) {
   if (wv.n_jobs == 0) { wv.tile0[0] = 0; return 0; }
-  wv.tickets = tk;
+  BN_REQUIRE(part, "wgrad: no slab workspace");
+  wv.part = part;
   wv.tile0[0] = 0;
+  wg_chain(wv);
   if (bf) {
     // 256 x 256 tiles, one 8-wave workgroup per CU: size the point splits for ~4 workgroups per CU in total
     for (int j = 0; j < wv.n_jobs; ++j)
       wv.tile0[j + 1] = wv.tile0[j] + ((wv.job[j].N + 255) / 256) * ((wv.job[j].K + 255) / 256);
     const int tiles = wv.tile0[wv.n_jobs];
 #ifndef W2_BLOCKS
-#define W2_BLOCKS 512   // tiles x point splits <= two rounds of the 256 CUs (one 144 KB workgroup per CU): 1024 -> 1.295 ms, 512 -> 1.253, 256 -> 1.290
+#define W2_BLOCKS 256   // tiles x point splits per round of the 256 CUs (one 144 KB workgroup per CU)
 #endif
-    // (small batches - up to 1024 rays x 64 samples per launch - run faster with one round of workgroups: 512 rays 0.232 ->
-    // 0.197 ms, 1024 rays 0.367 -> 0.345, session 51)
-    // (both passes of a 4096-ray step in one call - 524,288 points: four rounds, i.e. the points per workgroup of the tuned
-    // two-round shape; with twice the points per workgroup the launch ran 3-7 % slower than two launches, profiles/r03_ablation.txt)
-    int64_t n_split = (Mpad <= 65536 ? W2_BLOCKS / 2 : (Mpad <= 327680 ? W2_BLOCKS : 2 * W2_BLOCKS)) / tiles;
+    // One round of workgroups up to 327,680 points, two beyond (both passes of a 4096-ray step in one call: 524,288 points).
+    // With the fp32 atomics of rounds 1-3 four rounds were fastest for that launch (half the points per workgroup: a shorter
+    // atomic tail); with slabs every split costs a 257 KB slab written and read once more: 1020 -> 510 workgroups took the
+    // launch from 2.372 to 2.344 ms and its reduce from 0.089 to 0.059 ms (profiles/r04_ab_slab_lambert.txt).
+    int64_t n_split = (Mpad <= 327680 ? W2_BLOCKS : 2 * W2_BLOCKS) / tiles;
     if (n_split < 1) n_split = 1;
     int64_t mpb2 = ceil_div64(ceil_div64(Mpad, n_split), W2_BK) * W2_BK;
     if (mpb2 < 512) mpb2 = 512;
     n_split = ceil_div64(Mpad, mpb2);
     wv.m_per_block = (int)mpb2;
+    wv.n_split = (int)n_split;
+    BN_REQUIRE((size_t)tiles * n_split * WG_SLAB256 * sizeof(float) <= part_bytes, "wgrad: %d tiles x %d splits do not fit the slab workspace (%zu bytes)",
+               tiles, (int)n_split, part_bytes);
     const int n_blocks = (int)ceil_div64((int64_t)tiles * n_split, 8) * 8;
     const size_t lds = (size_t)4 * W2_STAGE * 2;
-    const void *kfn = tk ? (f16m ? (const void *)wgrad256_kernel<f16, true> : (const void *)wgrad256_kernel<bf16, true>)
-                         : (f16m ? (const void *)wgrad256_kernel<f16, false> : (const void *)wgrad256_kernel<bf16, false>);
+    const void *kfn = f16m ? (const void *)wgrad256_kernel<f16> : (const void *)wgrad256_kernel<bf16>;
     if (int e = bn_configure_lds(kfn, lds, "wgrad256")) return e;
-    BnProfScope prof_(BN_K_WGRAD, st);
-    const dim3 grd((unsigned)n_blocks), blk(W2_WAVES * 64);
-    if (tk) {
-      if (f16m) wgrad256_kernel<f16, true><<<grd, blk, lds, st>>>(wv, (int)n_split, n_blocks);
-      else wgrad256_kernel<bf16, true><<<grd, blk, lds, st>>>(wv, (int)n_split, n_blocks);
-    } else {
-      if (f16m) wgrad256_kernel<f16, false><<<grd, blk, lds, st>>>(wv, (int)n_split, n_blocks);
-      else wgrad256_kernel<bf16, false><<<grd, blk, lds, st>>>(wv, (int)n_split, n_blocks);
+    {
+      BnProfScope prof_(BN_K_WGRAD, st);
+      const dim3 grd((unsigned)n_blocks), blk(W2_WAVES * 64);
+      if (f16m) wgrad256_kernel<f16><<<grd, blk, lds, st>>>(wv, (int)n_split, n_blocks);
+      else wgrad256_kernel<bf16><<<grd, blk, lds, st>>>(wv, (int)n_split, n_blocks);
+      BN_LAUNCH_CHECK("wgrad256");
     }
-    BN_LAUNCH_CHECK("wgrad256");
+    BnProfScope prof_(BN_K_WGRAD_REDUCE, st);
+    wgrad_reduce_kernel<256><<<dim3((unsigned)tiles * 64), 256, 0, st>>>(wv);
+    BN_LAUNCH_CHECK("wgrad_reduce");
     return 0;
   }
   // fp32 parity path: 128 x 128 tiles; split the points so that the grid has a few thousand workgroups
   for (int j = 0; j < wv.n_jobs; ++j)
     wv.tile0[j + 1] = wv.tile0[j] + ((wv.job[j].N + 127) / 128) * ((wv.job[j].K + 127) / 128);
-  int64_t splits = 2048 / (wv.tile0[wv.n_jobs] > 0 ? wv.tile0[wv.n_jobs] : 1);
+  const int tiles = wv.tile0[wv.n_jobs];
+  int64_t splits = 2048 / (tiles > 0 ? tiles : 1);
   if (splits < 1) splits = 1;
   int64_t mpb = ceil_div64(ceil_div64(Mpad, splits), WG_BK) * WG_BK;
   if (mpb < 256) mpb = 256;
   wv.m_per_block = (int)mpb;
-  dim3 grid((unsigned)wv.tile0[wv.n_jobs], (unsigned)ceil_div64(Mpad, mpb));
-  BnProfScope prof_(BN_K_WGRAD, st);
-  wgrad_kernel<float><<<grid, 256, 0, st>>>(wv);
-  BN_LAUNCH_CHECK("wgrad");
+  wv.n_split = (int)ceil_div64(Mpad, mpb);
+  BN_REQUIRE((size_t)tiles * wv.n_split * WG_SLAB128 * sizeof(float) <= part_bytes, "wgrad: %d tiles x %d splits do not fit the slab workspace (%zu bytes)",
+             tiles, wv.n_split, part_bytes);
+  dim3 grid((unsigned)tiles, (unsigned)wv.n_split);
+  {
+    BnProfScope prof_(BN_K_WGRAD, st);
+    wgrad_kernel<float><<<grid, 256, 0, st>>>(wv);
+    BN_LAUNCH_CHECK("wgrad");
+  }
+  BnProfScope prof_(BN_K_WGRAD_REDUCE, st);
+  wgrad_reduce_kernel<128><<<dim3((unsigned)tiles * 16), 256, 0, st>>>(wv);
+  BN_LAUNCH_CHECK("wgrad_reduce");
   return 0;
 }
 
-int bn_launch_skinny(SkinnyArgs &sv, unsigned int *tk, bool bf, bool f16m, int64_t Mpad, int64_t m_per_block, hipStream_t st) {
+int bn_launch_skinny(SkinnyArgs &sv, bool bf, bool f16m, int64_t Mpad, int64_t m_per_block, float *part, size_t part_bytes, hipStream_t st) {
   if (sv.n_jobs == 0) return 0;
-  sv.tickets = tk;
+  sv.part = part;
   sv.m_per_block = (int)m_per_block;
-  dim3 grid((unsigned)ceil_div64(Mpad, m_per_block), (unsigned)sv.n_jobs);
-  BnProfScope prof_(BN_K_SKINNY, st);
-  if (f16m) skinny_wgrad_kernel<f16><<<grid, 256, 0, st>>>(sv);
-  else if (bf) skinny_wgrad_kernel<bf16><<<grid, 256, 0, st>>>(sv);
-  else skinny_wgrad_kernel<float><<<grid, 256, 0, st>>>(sv);
-  BN_LAUNCH_CHECK("skinny_wgrad");
+  const int n_split = (int)ceil_div64(Mpad, m_per_block);
+  BN_REQUIRE(n_split <= 256, "skinny_wgrad: %d splits (at most 256)", n_split);
+  BN_REQUIRE(part && (size_t)sv.n_jobs * n_split * SK_SLAB * sizeof(float) <= part_bytes, "skinny_wgrad: %d jobs x %d splits do not fit the slab workspace",
+             sv.n_jobs, n_split);
+  dim3 grid((unsigned)n_split, (unsigned)sv.n_jobs);
+  {
+    BnProfScope prof_(BN_K_SKINNY, st);
+    if (f16m) skinny_wgrad_kernel<f16><<<grid, 256, 0, st>>>(sv);
+    else if (bf) skinny_wgrad_kernel<bf16><<<grid, 256, 0, st>>>(sv);
+    else skinny_wgrad_kernel<float><<<grid, 256, 0, st>>>(sv);
+    BN_LAUNCH_CHECK("skinny_wgrad");
+  }
+  BnProfScope prof_(BN_K_WGRAD_REDUCE, st);
+  skinny_reduce_kernel<<<dim3((unsigned)sv.n_jobs, 4, 16), 256, 0, st>>>(sv, n_split);
+  BN_LAUNCH_CHECK("skinny_reduce");
   return 0;
 }

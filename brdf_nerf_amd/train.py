@@ -111,19 +111,15 @@ class TrainLoop:
 
     def check_device_faults(self):
         """The library's sticky device fault word, read synchronously (log / checkpoint time): bit 0 = a forward launch lost an
-        LDS hand-over (its results are invalid: raise); bit 1 = a deterministic-mode turn wait timed out - the sums are still
-        right, their order is no longer the fixed one (warn: bitwise reproducibility is lost for this run)."""
+        LDS hand-over (its results are invalid: raise); bit 1 is never set since round 4 (it reported on the turn-taking
+        deterministic mode of rounds 2-3; the weight gradients are summed in fixed order by construction now)."""
         import ctypes
-        import warnings
         from . import _lib as L
         from .functions import _stream
         w = ctypes.c_uint(0)
         L.check(L.lib().bn_device_faults(ctypes.byref(w), _stream()), "bn_device_faults")
         if w.value & 1:
             raise RuntimeError("brdf_nerf_amd: a fused forward launch lost an LDS hand-over (device fault word bit 0); its results are invalid")
-        if w.value & 2:
-            warnings.warn("brdf_nerf_amd: a deterministic-mode turn wait timed out (device fault word bit 1): gradients are correct "
-                          "but no longer bitwise reproducible in this run; the word is sticky until the process ends")
         return w.value
 
     # ------------------------------------------------------------------ checkpoints

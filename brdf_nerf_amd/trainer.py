@@ -7,6 +7,8 @@ autograd is used only for the per-ray loss glue ((R,3)/(R,) tensors).  Parameter
 nn.Parameters of the drop-in module are views into it, state_dict keys unchanged), so the optimizer and the
 collective are single launches over ~10 MB.
 """
+from collections import OrderedDict
+
 import torch
 
 from . import functions as Fn
@@ -54,7 +56,9 @@ class FusedTrainer:
                                         # field backward starts from) of a launch-lean step (tests; such steps are not captured)
         self.use_graph = True
         self.graph_after = 3            # eager steps with an unchanged signature before the step is captured
-        self._graphs, self._sig_seen, self._nf_dev, self._no_graph = {}, {}, {}, set()
+        self.max_graphs = 16            # captured steps kept (least recently used evicted; each owns a private memory pool)
+        self._graphs, self._sig_seen, self._nf_dev, self._no_graph = OrderedDict(), OrderedDict(), {}, set()
+        self._graph_cap_warned = False
         self.state = Fn.new_step_state(self.flat_param.device, torch.initial_seed(), lr)
         self._rng_step, self._state_lr, self._grads_clean = 0, float(lr), True
         self._state_adam = [0, 0, 0, 0]
@@ -336,11 +340,21 @@ class FusedTrainer:
         if not self._grads_clean:          # the general path leaves its gradient in the flat buffer
             self.flat_grad.zero_()
             self._grads_clean = True
-        f32 = lambda t: t if (t is None or (t.dtype == torch.float32)) else t.float()
-        rgbs = f32(rgbs).contiguous()
+        # fp32 / contiguous views of the inputs with STABLE addresses: a tensor that already is one is used as it is; anything
+        # else is copied into a trainer-owned staging buffer (a fresh temporary per step would give every step a new graph
+        # signature: up to max_graphs captures, each pinning its temporary, then eager forever)
+        def stage(key, t, flat=False):
+            if t is None:
+                return None
+            if t.dtype == torch.float32 and t.is_contiguous():
+                return t.reshape(-1) if flat else t
+            buf = self._buf("in_" + key, (t.numel(),) if flat else tuple(t.shape))
+            buf.copy_(t.reshape(-1) if flat else t)
+            return buf
+        rgbs = stage("rgbs", rgbs)
         use_ds = self.ds_lambda > 0 and depth_loss_on and valid_depth is not None
-        valid_depth, depths = f32(valid_depth), f32(depths)
-        depth_std = None if depth_std is None else f32(depth_std).reshape(-1)
+        valid_depth, depths = stage("valid_depth", valid_depth), stage("depths", depths)
+        depth_std = stage("depth_std", depth_std, flat=True)
         nf = self._near_far(rays, near_far)
         on = {"base": True, "brdf": bool(apply_brdf), "theta": bool(apply_brdf and apply_theta)}
         active = [on[g] for g, _, _ in self.groups]
@@ -358,12 +372,23 @@ class FusedTrainer:
                    float(reg.get("nr_lr", 0)))
             ent = self._graphs.get(sig)
             if ent is not None:
+                self._graphs.move_to_end(sig)
                 ent[0].replay()
                 res = ent[1]
             else:
-                n = self._sig_seen.get(sig, 0) + 1
+                n = self._sig_seen.pop(sig, 0) + 1
                 self._sig_seen[sig] = n
-                if n > self.graph_after and len(self._graphs) < 16 and sig not in self._no_graph:
+                while len(self._sig_seen) > 256:           # bounded: signatures that never recur (short last batches, changing flags)
+                    self._sig_seen.popitem(last=False)
+                if n > self.graph_after and sig not in self._no_graph:
+                    if len(self._graphs) >= self.max_graphs:     # evict the least recently replayed capture (and its inputs / pool)
+                        self._graphs.popitem(last=False)
+                        if not self._graph_cap_warned:
+                            import warnings
+                            warnings.warn(f"brdf_nerf_amd: more than {self.max_graphs} distinct training-step signatures were captured; the "
+                                          f"least recently used graph is dropped (inputs whose addresses change every step defeat the replay: "
+                                          f"keep batches in fixed buffers, e.g. RayTable.next_batch(out=...))")
+                            self._graph_cap_warned = True
                     # keep the inputs alive with the graph: their addresses are baked into it
                     keep = (rays, rgbs, valid_depth, depths, depth_std, nf)
                     g = torch.cuda.CUDAGraph()
@@ -493,7 +518,7 @@ class FusedTrainer:
                                           unfold=False, parts=parts)
                     Fn.field_backward_raw(spec, named, self.grad_views, packed, out2, d2o.reshape(R * G, C), stash2, rays=rays, z=z2,
                                           unfold=last, zero_folded=False, parts=parts)       # (bn_fold_heads clears the folded accumulators)
-            if self.world > 1 and self.overlap_allreduce and 0 < self.n_trunk < self.flat_grad.numel() and not L.deterministic():
+            if self.world > 1 and self.overlap_allreduce and 0 < self.n_trunk < self.flat_grad.numel():
                 # Two buckets (the reference: DDP's bucketed all-reduce overlapped with backward, main.py:720-731): the trunk's
                 # gradient is final after the trunk weight-gradient launch - its all-reduce (RCCL's own stream, ordered behind
                 # this one) runs under the head / skinny weight gradients and the unfold launch

@@ -61,11 +61,11 @@ const char *bn_last_error(void);
 const char *bn_build_flags(void);
 /* First 16 hex digits of the sha256 over the sources the library was compiled from (csrc/, this header, the build recipe). */
 const char *bn_source_hash(void);
-/* Run-to-run reproducible parameter gradients (the reference trains with Lightning's deterministic=True, main.py:726).
- * The weight-gradient kernels of bn_field_backward split the points over workgroups that add fp32 partial sums with
- * atomics; on = 1 makes the workgroups of one output tile add in a fixed order (a turn counter per tile): bitwise
- * identical gradients for identical inputs, for 13-16 % of a training step (profiles/r02_ablation.txt).  Process-wide; returns
- * the old value. */
+/* The reference trains with Lightning's deterministic=True (main.py:726).  Since ABI 5 bn_field_backward's parameter gradients
+ * are bitwise identical for identical inputs in EVERY mode: the weight-gradient kernels write the partial tile of every point
+ * split to a slab of the stash and a reduce kernel adds the slabs in split order (no fp32 atomics, no turn counters).  The
+ * switch remains for callers that keyed on it (the Python trainer reports a fixed-order loss sum with it); the library's kernels
+ * no longer read it.  Process-wide; returns the old value. */
 int bn_set_deterministic(int on);
 /* The current setting (read-only: callers that only want to know must not toggle a process-wide switch to find out). */
 int bn_get_deterministic(void);
@@ -447,8 +447,8 @@ int bn_adam_multi(float *param, float *grad, float *exp_avg, float *exp_avg_sq, 
 int bn_count_nonfinite(const float *x, int64_t n, unsigned long long *counts, void *stream);
 
 /* Device-side fault word of the fused kernels (bit 0: a wave of the barrier-free forward trunk gave up waiting for an LDS
- * hand-over - never in a correct run; the affected launch's results are invalid; bit 1: a workgroup of the deterministic
- * mode gave up waiting for its turn - its sums were still added, only the order is not the fixed one).  The library mirrors the word to the
+ * hand-over - never in a correct run; the affected launch's results are invalid; bit 1: reserved, always 0 since ABI 5 - it
+ * reported on the turn-taking deterministic mode of ABI 3-4).  The library mirrors the word to the
  * host asynchronously and fails the NEXT bn_field_* call with BN_ELAUNCH once it is set; this call synchronises `stream`
  * and reads it directly. */
 int bn_device_faults(unsigned int *faults, void *stream);

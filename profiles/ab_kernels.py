@@ -87,7 +87,7 @@ def main():
             torch.cuda.synchronize()
             if rnd:
                 step_ms[tag].append((time.perf_counter() - t0) / 30 * 1e3)
-    keys = ["pack", "field_fwd_sigma", "field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad", "field_adjoint", "field_adjoint_bwd",
+    keys = ["pack", "field_fwd_sigma", "field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad", "wgrad_reduce", "field_adjoint", "field_adjoint_bwd",
             "composite_fwd", "composite_bwd", "brdf", "guided_samples", "stratified_z", "adam"]
     print(f"config {config} dtype {dtype} rays {n_rays}: launches per step x ms per launch, median (min) over {rounds} alternating rounds")
     print(f"{'kernel':>18} " + " ".join(f"{t[:26]:>26}" for t in tags))
