@@ -224,11 +224,11 @@ def pack_field(spec, named_params, packed=None):
     return packed
 
 
-def field_sigma(spec, named_params, packed, xyz=None, rays=None, z=None):
-    """sigma-only forward, no autograd (pass 1 / sun pass)."""
+def field_sigma(spec, named_params, packed, xyz=None, rays=None, z=None, out=None):
+    """sigma-only forward, no autograd (pass 1 / sun pass).  out: a caller-owned [n_points] buffer (captured steps)."""
     pts = make_points(xyz, rays, z)
     ref = xyz if xyz is not None else z
-    sigma = torch.empty(pts.n_points, dtype=torch.float32, device=ref.device)
+    sigma = out if out is not None else torch.empty(pts.n_points, dtype=torch.float32, device=ref.device)
     ps = spec.params_struct(named_params)
     L.check(L.lib().bn_field_sigma(C.byref(spec.desc), C.byref(ps), _p(packed), C.byref(pts), _p(sigma), _stream()),
             "bn_field_sigma")
@@ -530,12 +530,14 @@ def _strided(t):
 
 
 def composite_guided(z, out1, G, near_far, d_range, use_target=None, target_depth=None, target_std=None, u=None, u_target=None,
-                     state=None, bufs=None, want_pass1=False, ray_offset=0):
-    """Pass-1 compositing of out1 [R][S][C] (sigma = channel 3) + depth-guided resampling + merge in one launch.
+                     state=None, bufs=None, want_pass1=False, ray_offset=0, sigma=None):
+    """Pass-1 compositing of out1 [R][S][C] (sigma = channel 3; or `sigma` [R][S] from a sigma-only pass 1, out1 = None) +
+    depth-guided resampling + merge in one launch.
     Draws: arrays u / u_target [R][G], or the in-kernel streams of `state`.  -> z2 [R][G], z_all [R][S+G], sort_idx [R][S+G]
     (+ pass-1 weights, depth when want_pass1)."""
     R, S = z.shape
-    Cc = out1.shape[-1]
+    Cc = out1.shape[-1] if sigma is None else 1
+    sig_ptr = C.c_void_p(out1.data_ptr() + 12) if sigma is None else _p(sigma)
     dev = z.device
     b = bufs if bufs is not None else {}
     mk = lambda k, shape, dt=torch.float32: b[k] if k in b else torch.empty(shape, dtype=dt, device=dev)
@@ -545,7 +547,7 @@ def composite_guided(z, out1, G, near_far, d_range, use_target=None, target_dept
     ut_p, ut_s = _strided(use_target)
     td_p, td_s = _strided(target_depth)
     ts_p, ts_s = _strided(target_std)
-    L.check(L.lib().bn_composite_guided(_p(z), C.c_void_p(out1.data_ptr() + 12), Cc, R, S, G, C.c_void_p(near_far.data_ptr()),
+    L.check(L.lib().bn_composite_guided(_p(z), sig_ptr, Cc, R, S, G, C.c_void_p(near_far.data_ptr()),
                                         float(d_range), ut_p, ut_s, td_p, td_s, ts_p, ts_s, _p(u), _p(u_target), _p(state),
                                         L.BN_RNG_GUIDED, L.BN_RNG_GUIDED_TARGET, int(ray_offset), _p(z2), _p(z_all), _p(idx), _p(w1), _p(d1),
                                         _stream()), "bn_composite_guided")

@@ -150,11 +150,11 @@ class FusedTrainer:
         reg0 = self.reg if regularisers else {}
         # (a loss that reads per-sample channels of the merged set beyond NormalRegLoss - MultiBRDF, NormalLoss - keeps the general path)
         per_sample0 = (bool(model.MultiBRDF) and apply_brdf) or abs(reg0.get("nr_spv", 0)) > 1e-5
-        if (self.lean and not self.strict_rng and args.noise_std == 0 and not gsam_only and self.reuse_coarse and not per_sample0
+        if (self.lean and not self.strict_rng and args.noise_std == 0 and self.reuse_coarse and not per_sample0
                 and not (getattr(model, "sun_v", "none") == "analystic" and apply_brdf)
                 and rays.dtype == torch.float32 and rays.is_contiguous() and rays.shape[1] >= 8 and S + G <= 512):
             return self._step_lean(spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, apply_theta, cos_irra_on,
-                                   depth_loss_on, near_far, regularisers)
+                                   depth_loss_on, near_far, regularisers, gsam_only)
         self._grads_clean = False
         named = model.named()
         packed = model.repack(spec)
@@ -333,7 +333,7 @@ class FusedTrainer:
             self._state_adam = list(want)
 
     def _step_lean(self, spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, apply_theta, cos_irra_on, depth_loss_on,
-                   near_far, regularisers):
+                   near_far, regularisers, gsam_only=False):
         model, args = self.model, self.args
         reg = self.reg if regularisers else {}
         lambertian = (len(spec.heads) == 1 and not spec.normal_an and not spec.normal_lr and reg.get("hs", 0) <= 0)
@@ -361,7 +361,7 @@ class FusedTrainer:
         self._sync_state(on)
         slot = self._rng_step % 64
         body = lambda: self._lean_body(spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, cos_irra_on, use_ds, nf, reg,
-                                       lambertian, active)
+                                       lambertian, active, gsam_only)
         res = None
         if self.use_graph and self.world == 1 and self.seed_hook is None:
             sig = (spec.key(), rays.shape, rays.data_ptr(), rgbs.data_ptr(), None if valid_depth is None else valid_depth.data_ptr(),
@@ -369,7 +369,7 @@ class FusedTrainer:
                    nf.data_ptr(), use_ds, tuple(active), float(self.ds_lambda), float(self.lambda_rgb), bool(self.usealldepth),
                    L.deterministic(), int(self.ray_offset), bool(self.keep_grads), bool(self.merge_passes), bool(apply_brdf),
                    bool(cos_irra_on), float(reg.get("hs", 0)), bool(self.sanitize_grads), float(reg.get("nr_an", 0)),
-                   float(reg.get("nr_lr", 0)))
+                   float(reg.get("nr_lr", 0)), bool(gsam_only))
             ent = self._graphs.get(sig)
             if ent is not None:
                 self._graphs.move_to_end(sig)
@@ -420,7 +420,7 @@ class FusedTrainer:
         return loss.detach(), rgb.detach()
 
     def _lean_body(self, spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, cos_irra_on, use_ds, nf, reg, lambertian,
-                   active):
+                   active, gsam_only=False):
         model, args = self.model, self.args
         S, G = args.n_samples, args.guided_samples
         R, C = rays.shape[0], spec.out_channels
@@ -433,9 +433,28 @@ class FusedTrainer:
             # pass 1's result to place its samples) into rows [R S, R (S + G)) of the same set, and the backward - chain,
             # weight gradients, skinny jobs - runs ONCE over all R (S + G) points (two launch sets before round 3's merge)
             tile = 64 if spec.dtype == L.BN_F32 else 128
-            merged = self.merge_passes and (R * S) % tile == 0
+            merged = self.merge_passes and (R * S) % tile == 0 and not gsam_only
             n_all = R * (S + G)
-            if merged:
+            has_t = valid_depth is not None
+            bufs = {"z2": self._buf("z2", (R, G)), "z_all": self._buf("z_all", (R, S + G)),
+                    "idx": self._buf("idx", (R, S + G), torch.int64)}
+            if gsam_only:
+                # gsam_only stage (main.py:201-203, rendering.py:266-269): pass 1 is a sigma-only forward that only places the
+                # guided samples; the step renders, and back-propagates through, the G guided samples alone
+                sig1 = Fn.field_sigma(spec, named, packed, rays=rays, z=z, out=self._buf("sig1", (R * S,)))
+                z2, _, _ = Fn.composite_guided(z, None, G, nf, args.std_range, valid_depth if has_t else None,
+                                               depths[:, 0] if has_t else None, depth_std if has_t else None, state=st, bufs=bufs,
+                                               ray_offset=self.ray_offset, sigma=sig1.view(R, S))
+                if self.seed_hook is not None:
+                    self.seed_hook("z2", z2)
+                out2 = self._buf("out2", (R * G, C))
+                stash2 = self._buf("stash2", (Fn.field_stash_bytes(spec, R * G),), torch.uint8)
+                Fn.field_forward_raw(spec, named, packed, out2, stash2, rays=rays, z=z2)
+                # the "merged set" is the guided block alone: no sort index, one source block
+                z_all, idx, out1v, out2v, S = z2, None, out2.view(R, G, C), None, G
+                d_all = self._buf("d_all", (R * G, C))
+                d1o, d2o = d_all.view(R, G, C), None
+            elif merged:
                 out_all = self._buf("out_all", (n_all, C))
                 stash_all = self._buf("stash_all", (Fn.field_stash_bytes(spec, n_all),), torch.uint8)
                 out1, out2 = out_all[:R * S], out_all[R * S:]
@@ -444,24 +463,22 @@ class FusedTrainer:
                 out1 = self._buf("out1", (R * S, C))
                 stash1 = self._buf("stash1", (Fn.field_stash_bytes(spec, R * S),), torch.uint8)
                 Fn.field_forward_raw(spec, named, packed, out1, stash1, rays=rays, z=z)
-            out1v = out1.view(R, S, C)
-            bufs = {"z2": self._buf("z2", (R, G)), "z_all": self._buf("z_all", (R, S + G)),
-                    "idx": self._buf("idx", (R, S + G), torch.int64)}
-            has_t = valid_depth is not None
-            z2, z_all, idx = Fn.composite_guided(z, out1v, G, nf, args.std_range, valid_depth if has_t else None,
-                                                 depths[:, 0] if has_t else None, depth_std if has_t else None, state=st, bufs=bufs,
-                                                 ray_offset=self.ray_offset)
-            if self.seed_hook is not None:   # (and the guided depths pass 2 is evaluated at)
-                self.seed_hook("z2", z2)
-            if merged:
-                Fn.field_forward_raw(spec, named, packed, out_all, stash_all, rays=rays, z=z2, point_offset=R * S, total_points=n_all)
-            else:
-                out2 = self._buf("out2", (R * G, C))
-                stash2 = self._buf("stash2", (Fn.field_stash_bytes(spec, R * G),), torch.uint8)
-                Fn.field_forward_raw(spec, named, packed, out2, stash2, rays=rays, z=z2)
-            out2v = out2.view(R, G, C)
-            d_all = self._buf("d_all", (n_all, C))
-            d1o, d2o = d_all[:R * S].view(R, S, C), d_all[R * S:].view(R, G, C)
+            if not gsam_only:
+                out1v = out1.view(R, S, C)
+                z2, z_all, idx = Fn.composite_guided(z, out1v, G, nf, args.std_range, valid_depth if has_t else None,
+                                                     depths[:, 0] if has_t else None, depth_std if has_t else None, state=st, bufs=bufs,
+                                                     ray_offset=self.ray_offset)
+                if self.seed_hook is not None:   # (and the guided depths pass 2 is evaluated at)
+                    self.seed_hook("z2", z2)
+                if merged:
+                    Fn.field_forward_raw(spec, named, packed, out_all, stash_all, rays=rays, z=z2, point_offset=R * S, total_points=n_all)
+                else:
+                    out2 = self._buf("out2", (R * G, C))
+                    stash2 = self._buf("stash2", (Fn.field_stash_bytes(spec, R * G),), torch.uint8)
+                    Fn.field_forward_raw(spec, named, packed, out2, stash2, rays=rays, z=z2)
+                out2v = out2.view(R, G, C)
+                d_all = self._buf("d_all", (n_all, C))
+                d1o, d2o = d_all[:R * S].view(R, S, C), d_all[R * S:].view(R, G, C)
         loss = None
         if lambertian:
             rgb = self._buf("rgb", (R, 3))
@@ -510,7 +527,10 @@ class FusedTrainer:
         with torch.no_grad():
             def backward(parts, last):
                 """bn_field_backward over the merged set, or over the two passes one after the other; `last`: unfold afterwards."""
-                if merged:
+                if gsam_only:
+                    Fn.field_backward_raw(spec, named, self.grad_views, packed, out2, d_all, stash2, rays=rays, z=z2,
+                                          unfold=last, zero_folded=False, parts=parts)
+                elif merged:
                     Fn.field_backward_raw(spec, named, self.grad_views, packed, out_all, d_all, stash_all, rays=rays, z=z, z2=z2,
                                           unfold=last, zero_folded=False, parts=parts)
                 else:

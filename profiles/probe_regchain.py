@@ -1,4 +1,4 @@
-"""Probe: sigma-only trunk with the activations held in registers (brdf_nerf_amd/csrc/probe/regchain_sigma.hip) against the
+"""Probe: sigma-only trunk with the activations held in registers (profiles/probes/regchain_sigma.hip) against the
 product sigma-only kernel (bn_field_sigma) on the bench shape: same weights, same points; prints max |diff| and ms / TFLOP/s of
 both.  Not part of the product path.   python profiles/probe_regchain.py [--build-only]"""
 import ctypes as C
@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SRC = os.path.join(ROOT, "brdf_nerf_amd", "csrc", "probe", "regchain_sigma.hip")
+SRC = os.path.join(ROOT, "profiles", "probes", "regchain_sigma.hip")
 OUT = os.path.join(ROOT, "brdf_nerf_amd", "build", "probe")
 DEFS = [a for a in sys.argv[1:] if a.startswith("-D")]
 LIB = os.path.join(OUT, "libregchain_probe" + "".join("_" + d[2:] for d in DEFS) + ".so")

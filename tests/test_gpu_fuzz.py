@@ -738,6 +738,8 @@ def test_random_lean_step_against_general_step(seed):
         prior = dict(valid_depth=(torch.rand(R, generator=g) < 0.6).float().to(DEV),
                      depths=torch.stack([0.8 + 0.4 * torch.rand(R, generator=g), torch.rand(R, generator=g)], -1).to(DEV),
                      depth_std=(0.03 * torch.rand(R, generator=g)).to(DEV))
+    if rng.random() < 0.3:                                   # round 4: the gsam_only stage is a lean step too
+        flags["gsam_only"] = True
     tag = (f"fuzz-lean {seed}: F={cfg.feat} L={cfg.layers} siren={int(cfg.siren)} pe={int(cfg.mapping)} normal={cfg.normal} viewdir={cfg.input_viewdir} "
            f"heads={cfg.brdf_head_names(flags['apply_brdf'], flags['apply_theta'])} funcH={cfg.funcH} shell={cfg.shell_hapke} R={R} S={S} G={G} "
            f"prior={bool(prior)} {lam} {flags}")

@@ -1701,7 +1701,7 @@ def test_train_loop_trajectory_against_oracle(name):
         n_valid = int((b["valid_depth"] > 0).sum())
         flags = dict(apply_brdf=out["apply_brdf"], apply_theta=out["apply_theta"], cos_irra_on=out["cos_irra_on"],
                      gsam_only=out["gsam_only"])
-        draws = [uz, torch.zeros(R, S), ug, ut[:n_valid], torch.zeros(R, S + G)]     # the randn draws act only through noise_std = 0
+        draws = [uz, torch.zeros(R, S), ug, ut[b["valid_depth"] > 0], torch.zeros(R, S + G)]     # (row r of the stream is ray r's; the randn draws act only through noise_std = 0)
         for grp in opt.param_groups:
             grp["lr"] = out["lr"]
         opt.zero_grad(set_to_none=True)
@@ -1857,6 +1857,17 @@ def test_full_size_render_and_train_step_properties(name):
         seeded_all, seeded_all_k = worst_cos("fp32", dtype + "_seeded")
         flat = lambda tag_: torch.cat([v.flatten().double() for v in grads[tag_].values()])
         whole = float(torch.nn.functional.cosine_similarity(flat("fp32"), flat(dtype + "_seeded"), dim=0))
+        # the END-TO-END (unseeded) whole flat gradient: its cosine weighs every matrix by the gradient mass it carries, so it says
+        # whether the matrices with a poor cosine matter; the referee's beside it
+        e2e = float(torch.nn.functional.cosine_similarity(flat("fp32"), flat(dtype), dim=0))
+        e2e_ref = float(torch.nn.functional.cosine_similarity(flat("fp32"), flat("fp32_w16"), dim=0))
+        mass = {k: float(v.double().norm() ** 2) for k, v in grads["fp32"].items()}
+        tot = sum(mass.values())
+        bad = [(k, float(torch.nn.functional.cosine_similarity(v.flatten().double(), grads[dtype][k].flatten().double(), dim=0)), mass[k] / tot)
+               for k, v in grads["fp32"].items() if v.numel() >= 256 and float(v.abs().max()) > 0]
+        bad.sort(key=lambda x: x[1])
+        diag(f"full size {name} ({dtype}): END-TO-END whole flat gradient cosine vs the fp32 HIP mode {e2e:.5f} (referee {e2e_ref:.5f}); "
+             f"the three worst matrices and their share of |g|^2: " + ", ".join(f"{k} {c:.3f} ({m:.1e})" for k, c, m in bad[:3]))
         diag(f"full size {name} ({dtype}): {dtype} field backward started from the fp32 mode's gradient rows - worst weight-matrix gradient "
              f"cosine {seeded:.5f} ({seeded_k}), worst of all parameters {seeded_all:.5f} ({seeded_all_k}), whole flat gradient {whole:.6f}")
         bf16_an = dtype == "bf16" and kw.get("normal") in ("analystic", "analystic_learned")
