@@ -301,12 +301,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
 #pragma unroll
       for (int nt = 0; nt < NPRE; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) dpre[nt][mt] = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
+        for (int mt = 0; mt < MT; ++mt) {
+#ifdef BN_PROBE_NO_D          // timing probe only (results wrong): no derivative loads
+          if constexpr (Elem<T>::kD8) { dpre[nt][mt].w = u32x4{0x80808080u + (unsigned)lane, 0x90909090u, 0xa0a0a0a0u, 0xb0b0b0b0u}; continue; }
+#endif
+          dpre[nt][mt] = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
+        }
       const size_t off = (l == g.L ? A.pl.bwd_feats : A.pl.bwd_trunk[l]) + (size_t)(ncol0 / 32) * KSF * 512;
       // the row-major stash copy of the tile this GEMM reads (dFeats, then dZ_l) rides inside the GEMM
       if (folded_top) {
       } else if (ride) {
+#ifdef BN_BWD_HALF_STORES
+        TileCopyHalves<T> zcopy(ACT, LDA, zdst, F, F, tid, WAVES * 64, BM, KSF);
+#else
         TileCopyExact<T> zcopy(ACT, LDA, zdst, F, F, tid, WAVES * 64);
+#endif
         gemm_seg<T, MT, NT, DP>(acc, packed + off, KSF, ACT, LDA, lane, zcopy);
       } else {
         gemm_seg<T, MT, NT, DP>(acc, packed + off, KSF, ACT, LDA, lane);
