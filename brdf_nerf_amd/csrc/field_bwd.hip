@@ -13,6 +13,14 @@
 int bn_field_adjoint_backward(const bn_field_desc *desc, const bn_field_params *params, const void *packed, const bn_points *pts,
                               const float *d_out, void *stash, void *stream);
 
+// bit 1 of bn_device_faults: a hand-over of the barrier-free backward trunk never arrived (pp_wait, field_kernels.h)
+__device__ unsigned int g_bwd_fault;
+unsigned int bn_bwd_fault_read(hipStream_t) {
+  unsigned int v = 0u;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_bwd_fault), sizeof(unsigned int), 0, hipMemcpyDeviceToHost) != hipSuccess) return 0x80000000u;
+  return v;
+}
+
 BN_PH_DEFINE_READER(bn_debug_phase_read_bwd)
 BN_CLK_DEFINE(bn_debug_clock_read_bwd)
 
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   T *ACT = (T *)smem;
   float *DPH = (float *)(ACT + (size_t)BM * LDA);  // [BM][BN_DPH] head pre-sigmoid gradients
   float *DPT = DPH + BM * BN_DPH;                        // [BM][4]  (d sigma_raw, d normal_raw)
+  int *WR = (int *)(DPT + BM * 4), *RD = WR + 2;         // hand-over counters of the barrier-free trunk (16 ints)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.M;
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   // kept for the skinny weight-gradient kernel stay unscaled, the 16-bit dZ_l / dG stashes carry S and the weight-gradient
   // kernel removes it from its fp32 sums.
   const float gs = chain_scale(A.amax);
+  if (tid < 16) WR[tid] = 0;
   if (tid < BM) {
     const int m = tid;
     const int64_t gm = m0 + m;
@@ -285,98 +295,179 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   BN_PH(8)
 
   // ---------------------------------------------------------------- trunk, top layer first
-  for (int l = g.L; l >= 1; --l) {
-    // l == L: dY_{L-1} = Wf^T dFeats + sigma/normal rank-1 terms; else dY_{l-1} = W_l^T dZ_l
-    const bool folded_top = g.fold && l == g.L;   // the product is already in the accumulators
-    if (!folded_top) zero_acc<MT, NT>(acc);
-    const int lo = l - 1;  // layer whose pre-activation gradient is produced
-    // D_lo = d act / d z of that layer, read back in accumulator order (DTile pieces).  The loads are issued BEFORE the
-    // GEMM - ahead of the stash stores riding in it, in flight while the MFMAs run - so the epilogue neither sits on HBM
-    // latency nor queues behind those stores (fp32 mode: only n-tile 0 fits there, the others follow the last MFMA).
-    const char *Ds = A.stash + A.sl.D[lo] + (size_t)tile * dtile_bytes<T>(BM, F);
-    DPiece<T> dpre[NT][MT];
-    T *zdst = (T *)(A.stash + (l == g.L ? A.sl.dfeats : A.sl.dZ[l])) + (size_t)m0 * F;
-    if (!ride && !folded_top) tile_to_global<T>(ACT, LDA, zdst, F, BM, F);
-    if (wave_on) {
-#pragma unroll
-      for (int nt = 0; nt < NPRE; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#ifdef BN_PROBE_NO_D          // timing probe only (results wrong): no derivative loads
-          if constexpr (Elem<T>::kD8) { dpre[nt][mt].w = u32x4{0x80808080u + (unsigned)lane, 0x90909090u, 0xa0a0a0a0u, 0xb0b0b0b0u}; continue; }
-#endif
-          dpre[nt][mt] = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
-        }
-      const size_t off = (l == g.L ? A.pl.bwd_feats : A.pl.bwd_trunk[l]) + (size_t)(ncol0 / 32) * KSF * 512;
-      // the row-major stash copy of the tile this GEMM reads (dFeats, then dZ_l) rides inside the GEMM
-      if (folded_top) {
-      } else if (ride) {
-#ifdef BN_BWD_HALF_STORES
-        TileCopyHalves<T> zcopy(ACT, LDA, zdst, F, F, tid, WAVES * 64, BM, KSF);
+  // 16-bit modes (round 4): dZ_l leaves in accumulator-native order straight from the epilogue registers that produce it (one
+  // coalesced 1 KB buffer store per wave instruction, like Y_l in the forward) - no row-major copy of the LDS tile riding in the
+  // next GEMM; the weight-gradient kernel stages native chunks for both operands (field_wgrad.hip, w2_body<.., ANAT>).
+  // F = 512 (NT == 2, all eight waves own columns): the trunk below the top layer runs WITHOUT workgroup barriers, as the
+  // forward's does (field_fwd.hip): waves 0-3 (group 0) own output columns 0-255, waves 4-7 (group 1) columns 256-511, one of
+  // each per SIMD; every wave multiplies over input-column half 0, then half 1; group 1 is held half a GEMM behind group 0, so
+  // a group's epilogue - the wait for its derivative bytes, the dZ stores - runs under the other group's MFMAs.  Counters in
+  // LDS (they only grow, 4 per layer each): WR[g] waves of group g past their epilogue; RD[2 h + g] waves of group g done
+  // reading column half h.
+  constexpr bool NATZ = Elem<T>::kNativeY;
+#ifndef BN_BWD_NO_PINGPONG
+  constexpr bool PING = NT == 2 && WAVES == 8 && Elem<T>::kFastMath;
 #else
-        TileCopyExact<T> zcopy(ACT, LDA, zdst, F, F, tid, WAVES * 64);
+  constexpr bool PING = false;
 #endif
-        gemm_seg<T, MT, NT, DP>(acc, packed + off, KSF, ACT, LDA, lane, zcopy);
-      } else {
-        gemm_seg<T, MT, NT, DP>(acc, packed + off, KSF, ACT, LDA, lane);
+  const int grp = wave >> 2;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  DPiece<T> dpre[NT][MT];
+  // D_lo = d act / d z of layer lo, read back in accumulator order (DTile pieces).  The loads are issued BEFORE the layer's
+  // GEMM - in flight while the MFMAs run - so the epilogue does not sit on HBM latency (fp32 mode: only n-tile 0 fits there,
+  // the others follow the last MFMA).
+  auto load_D = [&](int lo, int nt0, int nt1) {
+    const char *Ds = A.stash + A.sl.D[lo] + (size_t)tile * dtile_bytes<T>(BM, F);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (nt < nt0 || nt >= nt1) continue;
+#ifdef BN_PROBE_NO_D          // timing probe only (results wrong): no derivative loads
+        if constexpr (Elem<T>::kD8) { dpre[nt][mt].w = u32x4{0x80808080u + (unsigned)lane, 0x90909090u, 0xa0a0a0a0u, 0xb0b0b0b0u}; continue; }
+#endif
+        dpre[nt][mt] = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
       }
+  };
+  // epilogue of the layer that produces dZ_lo: (+ the top layer's rank-1 terms) x D_lo (+ zbar_lo), -> LDS tile and stash
+  auto epilogue = [&](int lo, auto top_tag) {
+    constexpr bool top = decltype(top_tag)::value;
+    const bool nlr = g.ch_normal_lr >= 0;
+    const float dscale = (g.act == BN_ACT_SIN && lo == 0) ? 30.f : 1.f;    // w0 of layer lo (the stash holds the unscaled derivative)
+    const auto Zr = stash_rsrc(A.stash + A.sl.dZ[lo] + (size_t)tile * BM * F * sizeof(T));
+    const int voff = lane * 16;
 #pragma unroll
-      for (int nt = NPRE; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) dpre[nt][mt] = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
-    }
-    BN_PH(9)
-    __syncthreads();
-    BN_PH(10)
-    if (wave_on) {
-      const bool top = l == g.L, nlr = g.ch_normal_lr >= 0;
-      const float dscale = (g.act == BN_ACT_SIN && lo == 0) ? 30.f : 1.f;    // w0 of layer lo (the stash holds the unscaled derivative)
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 32 + r;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+        for (int gp = 0; gp < 2; ++gp) {
+          const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
+          float dv[8], v[8];
+          dpiece_get<T>(dpre[nt][mt], gp, Elem<T>::kD8 ? dscale : 1.f, dv);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int m = mt * 32 + r;
+          for (int e = 0; e < 8; ++e) v[e] = acc[nt][mt][8 * gp + e];
+          if constexpr (top) {  // rank-1 terms of the sigma head and the learned-normal head
+            const float ds = DPT[m * 4], a0 = DPT[m * 4 + 1], a1 = DPT[m * 4 + 2], a2 = DPT[m * 4 + 3];
 #pragma unroll
-          for (int gp = 0; gp < 2; ++gp) {
-            const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
-            float dv[8], v[8];
-            dpiece_get<T>(dpre[nt][mt], gp, Elem<T>::kD8 ? dscale : 1.f, dv);
+            for (int half = 0; half < 2; ++half) {
+              const int n = n0 + 8 * half;
+              const f32x4 ws = *(const f32x4 *)(A.p.sigma_w + n);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = acc[nt][mt][8 * gp + e];
-            if (top) {  // rank-1 terms of the sigma head and the learned-normal head
-              const float ds = DPT[m * 4], a0 = DPT[m * 4 + 1], a1 = DPT[m * 4 + 2], a2 = DPT[m * 4 + 3];
+              for (int e = 0; e < 4; ++e) v[4 * half + e] += ws[e] * ds;
+              if (nlr) {
+                const f32x4 wn0 = *(const f32x4 *)(A.p.normal_w + n), wn1 = *(const f32x4 *)(A.p.normal_w + F + n),
+                            wn2 = *(const f32x4 *)(A.p.normal_w + 2 * F + n);
 #pragma unroll
-              for (int half = 0; half < 2; ++half) {
-                const int n = n0 + 8 * half;
-                const f32x4 ws = *(const f32x4 *)(A.p.sigma_w + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * half + e] += ws[e] * ds;
-                if (nlr) {
-                  const f32x4 wn0 = *(const f32x4 *)(A.p.normal_w + n), wn1 = *(const f32x4 *)(A.p.normal_w + F + n),
-                              wn2 = *(const f32x4 *)(A.p.normal_w + 2 * F + n);
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) v[4 * half + e] += wn0[e] * a0 + wn1[e] * a1 + wn2[e] * a2;
-                }
+                for (int e = 0; e < 4; ++e) v[4 * half + e] += wn0[e] * a0 + wn1[e] * a1 + wn2[e] * a2;
               }
             }
+          }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= dv[e];
-            if (A.an) {  // + dL/dz_l through D_l of the analytic-normal adjoint chain (stored at that chain's own scale)
-              float zb[8];
-              ld8((const typename Elem<T>::wide *)(A.stash + A.sl.adj_zbar[lo]) + (size_t)tile * BM * F + native_off8<MT, NT>(wave, nt, mt, gp, lane), zb);
+          for (int e = 0; e < 8; ++e) v[e] *= dv[e];
+          if (A.an) {  // + dL/dz_l through D_l of the analytic-normal adjoint chain (stored at that chain's own scale)
+            float zb[8];
+            ld8((const typename Elem<T>::wide *)(A.stash + A.sl.adj_zbar[lo]) + (size_t)tile * BM * F + native_off8<MT, NT>(wave, nt, mt, gp, lane), zb);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += zb[e] * zr;
-            }
+            for (int e = 0; e < 8; ++e) v[e] += zb[e] * zr;
+          }
+          if constexpr (NATZ) {   // one conversion serves the LDS tile (the next GEMM's operand) and the native dZ stash
+            const typename Elem<T>::frag q = cvt8(T(), v);
+            *(vec4 *)(ACT + (size_t)m * LDA + n0) = __builtin_shufflevector(q, q, 0, 1, 2, 3);
+            *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = __builtin_shufflevector(q, q, 4, 5, 6, 7);
+            stash_store_buf(Zr, voff, ((((wave_u * NT + nt) * MT + mt) * 2 + gp) * 1024), q);
+          } else {
             *(vec4 *)(ACT + (size_t)m * LDA + n0) = to_vec4(T(), v[0], v[1], v[2], v[3]);
             *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), v[4], v[5], v[6], v[7]);
           }
         }
+      }
+  };
+  // ---- top layer (under barriers: its input comes from the head passes): dY_{L-1} = Wf^T dFeats + sigma/normal rank-1 terms.
+  // With fold_feats the product is already in the accumulators.
+  {
+    if (!g.fold) {
+      zero_acc<MT, NT>(acc);
+      T *fdst = (T *)(A.stash + A.sl.dfeats) + (size_t)m0 * F;     // dFeats stays a row-major stash
+      if (!ride) tile_to_global<T>(ACT, LDA, fdst, F, BM, F);
+      if (wave_on) {
+        load_D(g.L - 1, 0, NPRE);
+        const size_t off = A.pl.bwd_feats + (size_t)(ncol0 / 32) * KSF * 512;
+        if (ride) {
+          TileCopyExact<T> zcopy(ACT, LDA, fdst, F, F, tid, WAVES * 64);
+          gemm_seg<T, MT, NT, DP>(acc, packed + off, KSF, ACT, LDA, lane, zcopy);
+        } else {
+          gemm_seg<T, MT, NT, DP>(acc, packed + off, KSF, ACT, LDA, lane);
+        }
+        load_D(g.L - 1, NPRE, NT);
+      }
+    } else if (wave_on) {
+      load_D(g.L - 1, 0, NT);
     }
+    BN_PH(9)
+    __syncthreads();
+    BN_PH(10)
+    if (wave_on) epilogue(g.L - 1, std::true_type());
     BN_PH(11)
     __syncthreads();
     BN_PH(12)
   }
-  tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dZ[0]) + (size_t)m0 * F, F, BM, F);
+  // ---- layers L-1 .. 1: dY_{l-1} = W_l^T dZ_l
+  for (int l = g.L - 1; l >= 1; --l) {
+    const int it = g.L - 1 - l;                   // barrier-free layers so far
+    const int lo = l - 1;                         // layer whose pre-activation gradient is produced
+    zero_acc<MT, NT>(acc);
+    T *zdst = (T *)(A.stash + A.sl.dZ[l]) + (size_t)m0 * F;
+    if (!NATZ && !ride) tile_to_global<T>(ACT, LDA, zdst, F, BM, F);
+#ifndef BN_BWD_D_AT      // where the barrier-free trunk issues a layer's derivative loads (A/B switch): 0 before the GEMM, 1 between its halves, 2 behind it
+#define BN_BWD_D_AT 0
+#endif
+    if (wave_on) {
+      if (!PING || BN_BWD_D_AT == 0) load_D(lo, 0, NPRE);
+      const size_t off = A.pl.bwd_trunk[l] + (size_t)(ncol0 / 32) * KSF * 512;
+      if constexpr (PING) {
+        const int half = KSF / 2;
+        NoSide none;
+        pp_wait(WR + 0, 4 * it, &g_bwd_fault);                        // half 0 of dZ_l is written
+        if (grp == 1) pp_wait(RD + 0, 4 * (it + 1), &g_bwd_fault);    // group 0 is done with its phase 1 of this layer: the lag
+        BN_PH(12)
+        __builtin_amdgcn_s_setprio(1);
+        gemm_range<T, MT, NT, DP>(acc, packed + off, KSF, 0, half, ACT, LDA, lane, none);
+        BN_PH(9)
+        pp_signal(RD + 0 + grp, lane);
+        pp_wait(WR + 1, 4 * it, &g_bwd_fault);                        // half 1
+        BN_PH(12)
+        if (BN_BWD_D_AT == 1) load_D(lo, 0, NPRE);
+        gemm_range<T, MT, NT, DP>(acc, packed + off, KSF, half, half, ACT, LDA, lane, none);
+        __builtin_amdgcn_s_setprio(0);
+        pp_signal(RD + 2 + grp, lane);
+        if (BN_BWD_D_AT == 2) load_D(lo, 0, NPRE);
+      } else if (!NATZ && ride) {
+        // fp32 mode: the row-major stash copy of the tile this GEMM reads (dZ_l) rides inside the GEMM
+        TileCopyExact<T> zcopy(ACT, LDA, zdst, F, F, tid, WAVES * 64);
+        gemm_seg<T, MT, NT, DP>(acc, packed + off, KSF, ACT, LDA, lane, zcopy);
+      } else {
+        gemm_seg<T, MT, NT, DP>(acc, packed + off, KSF, ACT, LDA, lane);
+      }
+      load_D(lo, NPRE, NT);
+    }
+    BN_PH(9)
+    if constexpr (PING) {     // all eight waves have read this group's columns of dZ_l
+      pp_wait(RD + 2 * grp + 0, 4 * (it + 1), &g_bwd_fault);
+      pp_wait(RD + 2 * grp + 1, 4 * (it + 1), &g_bwd_fault);
+    } else {
+      __syncthreads();
+    }
+    BN_PH(10)
+    if (wave_on) epilogue(lo, std::false_type());
+    BN_PH(11)
+    if constexpr (PING) pp_signal(WR + grp, lane);
+    else __syncthreads();
+    BN_PH(12)
+  }
+  if (PING) __syncthreads();   // (every wave signalled its last epilogue before arriving here)
+  if (!NATZ) tile_to_global<T>(ACT, LDA, (T *)(A.stash + A.sl.dZ[0]) + (size_t)m0 * F, F, BM, F);
   BN_PH(13)
 #ifndef BN_PHASE_TIMING_WGRAD
   BN_PH_FLUSH
@@ -389,7 +480,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
 // ------------------------------------------------------------------------------------------ weight gradients
 template <typename T, int MT, int NT, int WAVES> static int launch_bwd(const BwdArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
-  const size_t lds = (size_t)BM * (a.g.F + Elem<T>::kPad) * sizeof(T) + (size_t)BM * (BN_DPH + 4) * sizeof(float);
+  const size_t lds = (size_t)BM * (a.g.F + Elem<T>::kPad) * sizeof(T) + (size_t)BM * (BN_DPH + 4) * sizeof(float) + 64;
   if (int e = bn_configure_lds((const void *)field_bwd_kernel<T, MT, NT, WAVES>, lds, "field_bwd")) return e;
   BnProfScope prof_(BN_K_BWD_CHAIN, st);
   field_bwd_kernel<T, MT, NT, WAVES><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
@@ -464,17 +555,19 @@ extern "C" int bn_field_backward_parts(const bn_field_desc *desc, const bn_field
   w.n_jobs = 0; w.Mpad = sl.Mpad; w.tile0[0] = 0; w.amax = amax; w.part = nullptr; w.n_split = 1;
   int scale_sel = 1;   // gradient operand of the jobs added next: 1 = primal chain (dZ_l, dG), 2 = adjoint chain (gbar_PE, abar_l)
   int b_native = 0;    // B operand of the jobs added next: a native-order layer-output stash (16-bit modes) or a row-major array
+  int a_native = 0;    // A operand of the jobs added next: a native-order dZ_l stash (16-bit modes: the trunk's) or a row-major array
   int part = BN_BWD_WGRAD_TRUNK;   // which part of the backward the jobs added next belong to (bn_field_backward_parts)
   auto add = [&](const void *A_, int lda, int a0, const void *B_, int ldb, int b0, float *C, int ldc, float *bias, int N, int K) {
     if (!C || !(parts & part)) return;
     WgradJob &j = w.job[w.n_jobs];
     j.scale_sel = scale_sel;
-    j.b_native = b_native; j.b_bm = BM; j.b_F = F; j.b_bm_shift = BM == 128 ? 7 : 6;
+    j.b_native = (b_native ? WG_B_NATIVE : 0) | (a_native ? WG_A_NATIVE : 0); j.b_bm = BM; j.b_F = F; j.b_bm_shift = BM == 128 ? 7 : 6;
     j.A = A_; j.B = B_; j.C = C; j.bias = bias; j.lda = lda; j.ldb = ldb; j.ldc = ldc; j.a_col0 = a0; j.b_col0 = b0; j.N = N; j.K = K;
     w.tile0[w.n_jobs + 1] = w.tile0[w.n_jobs] + ((N + 127) / 128) * ((K + 127) / 128);
     ++w.n_jobs;
   };
   const int naty = bf ? 1 : 0;   // Elem<T>::kNativeY: the Y_l stashes of the 16-bit modes are in native order
+  a_native = naty;     // Elem<T>::kNativeY: the trunk's dZ_l are native images in the 16-bit modes (field_bwd_kernel's epilogue)
   for (int l = 0; l < g.L; ++l) {
     const void *dZ = S + sl.dZ[l];
     b_native = 0;
@@ -488,6 +581,7 @@ extern "C" int bn_field_backward_parts(const bn_field_desc *desc, const bn_field
       add(dZ, F, 0, S + sl.Y[l - 1], F, 0, G->trunk_w[l], F, G->trunk_b[l], F, F);
     }
   }
+  a_native = 0;
   b_native = naty;
   part = BN_BWD_WGRAD_HEADS;
   if (!g.fold) add(S + sl.dfeats, F, 0, S + sl.Y[g.L - 1], F, 0, G->feats_w, F, G->feats_b, F, F);

@@ -14,10 +14,14 @@ struct WgradJob {
   int a_col0, b_col0;  // first column used in A / B
   int N, K;            // valid output extents (rows of C, cols of C)
   int scale_sel;       // fp16 loss scaling carried by A: 0 none, 1 the primal chain's (amax[0]), 2 the adjoint chain's (amax[1])
-  int b_native;        // 16-bit modes: B is a layer-output stash in accumulator-native order (tiles of b_bm points, F columns:
+  int b_native;        // 16-bit modes, bit 0: B is a layer-output stash in accumulator-native order (tiles of b_bm points, F columns:
   int b_bm, b_F;       // chunk (col/32, point/32 % (bm/32), (col%32)/16) = 64 lanes x 16 B, see native_off8); else row-major [Mpad][ldb]
   int b_bm_shift;      // log2(b_bm)
+                       // b_native bit 1 (WG_A_NATIVE): A is a native-order image too (the trunk's dZ_l, written from the backward
+                       // chain's epilogue registers; same b_bm / b_F geometry, a_col0 = 0); else row-major [Mpad][lda]
 };
+#define WG_B_NATIVE 1
+#define WG_A_NATIVE 2
 #define BN_MAX_WGRAD_JOBS 44
 struct WgradArgs {
   WgradJob job[BN_MAX_WGRAD_JOBS];

@@ -18,7 +18,6 @@
 // order - and the jobs that feed the same matrix (primal + analytic-normal term of a trunk layer) in job order - into the gradient
 // with one read-modify-write per element.  The gradient is bitwise reproducible by construction (the reference trains with
 // Trainer(deterministic=True), main.py:726), there is no inter-workgroup protocol left, and the stores run at HBM speed.
-unsigned int bn_bwd_fault_read(hipStream_t) { return 0u; }   // (bn_device_faults bit 1: the turn-taking mode it reported on is gone)
 
 // 1 / (scale carried by the job's gradient operand): multiplies the fp32 sums before they are accumulated
 __device__ __forceinline__ float wg_unscale(const float *amax, int sel) {
@@ -177,7 +176,7 @@ template <typename T> __device__ __forceinline__ typename Elem<T>::frag w2_frag(
 // One 256 x 256 output tile over the points [mb, me).  NBV = 32-column accumulator tiles this WAVE multiplies (4 for a
 // full tile; the 60-column positional-encoding operand only has columns for two tiles of the wc = 0 waves - the other
 // waves of such a block just take part in staging and barriers).
-template <typename T, int NBV, bool BNAT>
+template <typename T, int NBV, bool BNAT, bool ANAT>
 __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64_t mb, int64_t me, T *sA, T *sB, float *P) {
   typedef typename Elem<T>::frag frag_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
@@ -199,10 +198,16 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   static_assert(W2_BK / (W2_WAVES * 2) == 4, "native staging: 4 wave-instructions per wave and stage");
   // chunk q = 4 w + c: 32-point block c & 1, column half (c >> 1) & 1, 32-column block w (one per wave): everything but the
   // wave / lane part of the addresses is a compile-time constant of c
-  const int mtn = BNAT ? J.b_bm / 32 : 1, ncb = BNAT ? J.b_F / 32 : 1;
+  const int mtn = (BNAT || ANAT) ? J.b_bm / 32 : 1, ncb = (BNAT || ANAT) ? J.b_F / 32 : 1;
   int cbg = (k0 >> 5) + wave;
   cbg = cbg < ncb ? cbg : ncb - 1;                           // beyond the operand: any valid block (those output columns are never stored)
   const int boff0 = (cbg * mtn * 2 * 64 + lane) * 8;         // + ((c & 1) * 2 + ((c >> 1) & 1)) * 512 elements
+  // Native-order A (ANAT; round 4: the dZ_l stashes of the 16-bit modes, written straight from the backward chain's epilogue
+  // registers like Y_l from the forward's): the same image (tiles of b_bm points x b_F columns), the same staging, with the
+  // 32-column block taken from the tile's first output row n0.
+  int cag = (n0 >> 5) + wave;
+  cag = cag < ncb ? cag : ncb - 1;                           // (rows beyond N are never stored by the reduce)
+  const int aoff0 = (cag * mtn * 2 * 64 + lane) * 8;
   const int lslot0 = 8 * wave + 2 * nh;                      // + 4 ((c >> 1) & 1); LDS row = 32 (c & 1) + nr
   const int64_t tile_elems = (int64_t)J.b_bm * J.b_F;
   // Stage pipeline with ONE register set: while stage s is multiplied, the registers (stage s+1, loaded during stage
@@ -217,22 +222,28 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   auto gload1 = [&](int64_t m, int c) {
     m = m < me ? m : me - W2_BK;   // the two prefetches past the end re-read the last stage: no branch in the stage loop
     const int64_t row = m + row0 + RPP * c;
-    ra[c] = *(const u32x4 *)(pa + row * sa);
-    if (BNAT) {
-      // tile = m >> log2(bm); first 32-point block of the stage inside its tile = (m mod bm) / 32; a tile image is bm x F elements
-      const int64_t tile_off = (m >> J.b_bm_shift) * tile_elems;
-      const int mt0 = ((int)m & (J.b_bm - 1)) >> 5;
-      rb[c] = *(const u32x4 *)((const T *)J.B + tile_off + mt0 * 1024 + boff0 + ((c & 1) * 2 + ((c >> 1) & 1)) * 512);
-    } else {
-      rb[c] = *(const u32x4 *)(pb + row * sb);
-    }
+    // tile = m >> log2(bm); first 32-point block of the stage inside its tile = (m mod bm) / 32; a tile image is bm x F elements
+    const int64_t tile_off = (m >> J.b_bm_shift) * tile_elems;
+    const int mt0 = ((int)m & (J.b_bm - 1)) >> 5;
+    if (ANAT) ra[c] = *(const u32x4 *)((const T *)J.A + tile_off + mt0 * 1024 + aoff0 + ((c & 1) * 2 + ((c >> 1) & 1)) * 512);
+    else ra[c] = *(const u32x4 *)(pa + row * sa);
+    if (BNAT) rb[c] = *(const u32x4 *)((const T *)J.B + tile_off + mt0 * 1024 + boff0 + ((c & 1) * 2 + ((c >> 1) & 1)) * 512);
+    else rb[c] = *(const u32x4 *)(pb + row * sb);
   };
   auto gload = [&](int64_t m) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) gload1(m, c);
   };
   auto sstore1 = [&](int buf, int c) {
-    *(u32x4 *)(sA + buf * W2_STAGE + (row0 + RPP * c) * W2_LD + scol) = ra[c];
+    if (ANAT) {
+      T *rowp = sA + buf * W2_STAGE + (32 * (c & 1) + nr) * W2_LD;
+      const int sl0 = lslot0 + 4 * ((c >> 1) & 1);
+      const auto s02 = __builtin_amdgcn_permlane32_swap(ra[c][0], ra[c][2], false, false);
+      const auto s13 = __builtin_amdgcn_permlane32_swap(ra[c][1], ra[c][3], false, false);
+      *(u32x4 *)(rowp + ((sl0 ^ nswz) << 2)) = u32x4{s02[0], s13[0], s02[1], s13[1]};
+    } else {
+      *(u32x4 *)(sA + buf * W2_STAGE + (row0 + RPP * c) * W2_LD + scol) = ra[c];
+    }
     if (BNAT) {
       T *rowp = sB + buf * W2_STAGE + (32 * (c & 1) + nr) * W2_LD;
       const int sl0 = lslot0 + 4 * ((c >> 1) & 1);
@@ -362,14 +373,23 @@ __global__ __launch_bounds__(W2_WAVES * 64, W2_WAVES == 8 ? 2 : 1) void wgrad256
 #ifdef BN_CLOCK_STAMP_WGRAD
   BN_CLK_BEGIN
 #endif
-  if (J.b_native) {     // layer-output operand in native order: full-width column blocks only (F is a multiple of 64)
-    if (cols >= 65) w2_body<T, 4, true>(J, n0, k0, mb, me, sA, sB, P);
-    else if (cols >= 33) w2_body<T, 2, true>(J, n0, k0, mb, me, sA, sB, P);
-    else w2_body<T, 0, true>(J, n0, k0, mb, me, sA, sB, P);
-  } else if (cols >= 65) w2_body<T, 4, false>(J, n0, k0, mb, me, sA, sB, P);
-  else if (cols >= 33) w2_body<T, 2, false>(J, n0, k0, mb, me, sA, sB, P);
-  else if (cols >= 1) w2_body<T, 1, false>(J, n0, k0, mb, me, sA, sB, P);
-  else w2_body<T, 0, false>(J, n0, k0, mb, me, sA, sB, P);
+  if (J.b_native & WG_A_NATIVE) {     // gradient operand in native order (the trunk's dZ_l)
+    if (J.b_native & WG_B_NATIVE) {   // layer-output operand in native order: full-width column blocks only (F is a multiple of 64)
+      if (cols >= 65) w2_body<T, 4, true, true>(J, n0, k0, mb, me, sA, sB, P);
+      else if (cols >= 33) w2_body<T, 2, true, true>(J, n0, k0, mb, me, sA, sB, P);
+      else w2_body<T, 0, true, true>(J, n0, k0, mb, me, sA, sB, P);
+    } else if (cols >= 65) w2_body<T, 4, false, true>(J, n0, k0, mb, me, sA, sB, P);
+    else if (cols >= 33) w2_body<T, 2, false, true>(J, n0, k0, mb, me, sA, sB, P);
+    else if (cols >= 1) w2_body<T, 1, false, true>(J, n0, k0, mb, me, sA, sB, P);
+    else w2_body<T, 0, false, true>(J, n0, k0, mb, me, sA, sB, P);
+  } else if (J.b_native & WG_B_NATIVE) {
+    if (cols >= 65) w2_body<T, 4, true, false>(J, n0, k0, mb, me, sA, sB, P);
+    else if (cols >= 33) w2_body<T, 2, true, false>(J, n0, k0, mb, me, sA, sB, P);
+    else w2_body<T, 0, true, false>(J, n0, k0, mb, me, sA, sB, P);
+  } else if (cols >= 65) w2_body<T, 4, false, false>(J, n0, k0, mb, me, sA, sB, P);
+  else if (cols >= 33) w2_body<T, 2, false, false>(J, n0, k0, mb, me, sA, sB, P);
+  else if (cols >= 1) w2_body<T, 1, false, false>(J, n0, k0, mb, me, sA, sB, P);
+  else w2_body<T, 0, false, false>(J, n0, k0, mb, me, sA, sB, P);
 #ifdef BN_CLOCK_STAMP_WGRAD
   BN_CLK_END
 #endif
