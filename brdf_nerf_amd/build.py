@@ -68,10 +68,11 @@ FILE_FLAGS = {"field_wgrad.hip": ("-mllvm", "-amdgpu-sched-strategy=max-ilp"),
               "field_bwd.hip": _TRACKERS, "field_adjoint.hip": _TRACKERS, "field_adjbwd.hip": _TRACKERS}
 
 
-def build(verbose=False, force=False, defines=(), out=None, extra_flags=(), tag=None):
+def build(verbose=False, force=False, defines=(), out=None, extra_flags=(), tag=None, file_flags=None):
     """defines/out/extra_flags/tag: build a VARIANT library (A/B experiments, profiles/): objects go to build/<tag>/, the result
     to `out`; load it with BRDFNERF_HIP_LIB=<out>.  extra_flags: hipcc flags for every file (e.g. -mllvm options)."""
-    variant = bool(defines) or out is not None or bool(extra_flags)
+    variant = bool(defines) or out is not None or bool(extra_flags) or bool(file_flags)
+    per_file = dict(FILE_FLAGS, **(file_flags or {}))     # file_flags: A/B override of one file's extra flags ({basename: (flags...)})
     if not variant and not force and not needs_build():
         return LIB
     tag = tag or "_".join(d.replace("=", "-") for d in defines) or "default"
@@ -88,7 +89,7 @@ def build(verbose=False, force=False, defines=(), out=None, extra_flags=(), tag=
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         stamp = os.path.basename(src) == "error.cpp"            # carries the source hash (so it is recompiled whenever any source changed)
-        cmd = [HIPCC] + FLAGS + list(FILE_FLAGS.get(os.path.basename(src), ())) + list(extra_flags) + ["-D" + d for d in defines] + \
+        cmd = [HIPCC] + FLAGS + list(per_file.get(os.path.basename(src), ())) + list(extra_flags) + ["-D" + d for d in defines] + \
             (['-DBN_SOURCE_HASH="%s"' % sh] if stamp else []) + ["-x", "hip", "-c", src, "-o", obj]
         # an object is reused when it was compiled from these bytes with this command line (content key, not mtimes)
         key = hashlib.sha256(open(src, "rb").read() + hdr_bytes + " ".join(cmd).encode()).hexdigest()
@@ -122,5 +123,7 @@ if __name__ == "__main__":
     outs = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")]
     xf = [w for a in sys.argv[1:] if a.startswith("--flags=") for w in a.split("=", 1)[1].split()]
     tags = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--tag=")]
-    print(build(verbose="--verbose" in sys.argv, force="--force" in sys.argv, defines=defs, out=outs[0] if outs else None,
+    # --file-flags=field_bwd.hip:-fno-slp-vectorize ...   (replaces FILE_FLAGS of that file; needs --tag)
+    ff = {a.split("=", 1)[1].split(":", 1)[0]: tuple(a.split("=", 1)[1].split(":", 1)[1].split()) for a in sys.argv[1:] if a.startswith("--file-flags=")}
+    print(build(file_flags=ff or None, verbose="--verbose" in sys.argv, force="--force" in sys.argv, defines=defs, out=outs[0] if outs else None,
                 extra_flags=xf, tag=tags[0] if tags else None))

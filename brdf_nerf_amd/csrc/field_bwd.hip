@@ -222,7 +222,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t tile = blockIdx.x, m0 = tile * BM, M = A.M;
   const T *packed = (const T *)A.packed;
-  constexpr int DP = BwdDepth<T>::value;
+  // weight fragments in flight per wave: the barrier-free trunk (F = 512, 16-bit) gains 1-2 % from the forward's depth
+  // (profiles/r04_ablation.txt item 7); the shapes under barriers keep the depth tuned for them in round 2
+#ifndef BN_BWD_PP_DEPTH
+#define BN_BWD_PP_DEPTH 6
+#endif
+  constexpr int DP = (NT == 2 && WAVES == 8 && Elem<T>::kFastMath) ? BN_BWD_PP_DEPTH : BwdDepth<T>::value;
   // D_lo pieces fetched before the layer's GEMM (the rest right after its last MFMA): all of them when a piece is 16 bytes
   constexpr int NPRE = Elem<T>::kD8 ? NT : 1;
   BN_PH_DECL

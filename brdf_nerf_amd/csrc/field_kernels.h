@@ -113,7 +113,13 @@ template <typename V> __device__ __forceinline__ V stash_load(const V *p) {
 // clobbered now and then: a stash that differed from run to run, found by the fuzz as non-finite gradients
 // (profiles/r04_ablation.txt item 5).  hipcc does not count an asm store in its vmcnt bookkeeping; that only makes its waits for
 // later loads wait for more than they need.
-__device__ __forceinline__ auto stash_rsrc(const void *base) { return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000); }
+// (the base goes through readfirstlane: the asm below wants the descriptor in scalar registers whatever the compiler's uniformity
+// analysis made of the address arithmetic behind it)
+__device__ __forceinline__ auto stash_rsrc(const void *base) {
+  const unsigned long long b = (unsigned long long)base;
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)b), hi = __builtin_amdgcn_readfirstlane((unsigned int)(b >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
 template <typename R, typename V> __device__ __forceinline__ void stash_store_buf(R rsrc, int voff, int soff, const V &v) {
   static_assert(sizeof(V) == 16, "one 16-byte piece per lane");
   const u32x4 d = __builtin_bit_cast(u32x4, v);
@@ -191,36 +197,6 @@ template <typename T> struct TileCopyExact {
   }
 };
 __host__ __device__ __forceinline__ bool tile_copy_exact(int F, int n_on, int waves) { return n_on == waves && F % 256 == 0; }
-
-// The same copy with its stores confined to ONE half of the k-loop per wave: waves 0..3 (one per SIMD) store during the first
-// half of the k-steps, their SIMD partners 4..7 during the second.  A wave's vector-memory operations retire in issue order
-// and a store into a saturated write path blocks the wave that issues it: with every wave storing at the same k-steps both
-// waves of a SIMD stall together and the matrix pipe idles; this way one wave of each SIMD always has a pure load queue.
-// Straight-line code: outside its half a wave issues the store with an offset beyond the buffer's num_records (the hardware
-// drops out-of-range buffer stores before they reach the data path).
-template <typename T> struct TileCopyHalves {
-  static constexpr int EPC = 16 / sizeof(T);
-  const T *lp;
-  decltype(stash_rsrc(nullptr)) rsrc;
-  int voff, lstep, gstepB, cnt, lo, per;
-  __device__ __forceinline__ TileCopyHalves(const T *lds, int ld, T *g, int gld, int width, int t, int nthr, int rows, int KS) {
-    const int cpr = width / EPC, row = t / cpr, cc = t % cpr, dr = nthr / cpr;
-    lp = lds + (size_t)row * ld + cc * EPC;
-    rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, rows * gld * (int)sizeof(T), 0x00020000);
-    voff = (row * gld + cc * EPC) * (int)sizeof(T);
-    lstep = dr * ld; gstepB = dr * gld * (int)sizeof(T);
-    per = KS / 2;
-    lo = (t >> 8) * per;          // waves 0-3: k-steps [0, KS/2), waves 4-7: [KS/2, KS)
-    cnt = 0;
-  }
-  __device__ __forceinline__ void at(int) {
-    const bool on = (unsigned)(cnt - lo) < (unsigned)per;
-    const u32x4 v = *(const u32x4 *)lp;
-    stash_store_buf(rsrc, on ? voff : 0x40000000, 0, v);
-    lp += on ? lstep : 0; voff += on ? gstepB : 0;
-    ++cnt;
-  }
-};
 
 // Flags of the two-group ping-pong (LDS ints, zeroed before first use): counters only grow; a waiter spins with
 // s_sleep until the count is reached.  LDS executes one wave's operations in issue order, so data written before a

@@ -54,8 +54,10 @@ if __name__ == "__main__":
     z = torch.sort(torch.rand(4096, 128, device=dev) * 2, -1)[0]
     FWD = ["pe", "gemm", "bar_gemm", "epilogue", "bar_epi", "stash", "sigma", "feats_gemm", "feats_epi+stash", "head_gemm",
            "head_epi", "head_reduce", "pp_wait_h0", "pp_wait_h1"]
-    BWD = ["seed", "head_dG", "bar", "dG_stash", "head_gemm", "bar", "dfeats_epi", "bar", "dfeats_stash", "gemm", "bar_gemm",
-           "epilogue", "bar_epi", "dZ_stash"]
+    # (round 4, barrier-free trunk: 10 = wait until every wave has read this group's columns, 12 = wait for the columns the
+    # next half-GEMM reads + the lag of group 1; under barriers: the two workgroup barriers of a layer)
+    BWD = ["seed", "head_dG", "bar", "dG_stash", "head_gemm", "bar", "dfeats_epi", "bar", "dfeats_stash", "gemm", "wait_readers",
+           "epilogue", "wait_writers", "tail"]
     buf = (ctypes.c_ulonglong * 17)()
 
     def report(tag, fn, reader, names):
