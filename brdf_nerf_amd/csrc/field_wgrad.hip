@@ -158,6 +158,7 @@ template <typename T> __device__ __forceinline__ typename Elem<T>::frag w2_frag(
 }
 
 #if defined(BN_PHASE_TIMING) && defined(BN_PHASE_TIMING_WGRAD)
+BN_PH_DEFINE_READER(bn_debug_phase_read_wgrad)
 #define WG_PH_DECL BN_PH_DECL
 #define WG_PH(i) BN_PH(i)
 #define WG_PH_FLUSH BN_PH_FLUSH

@@ -111,15 +111,16 @@ class TrainLoop:
 
     def check_device_faults(self):
         """The library's sticky device fault word, read synchronously (log / checkpoint time): bit 0 = a forward launch lost an
-        LDS hand-over (its results are invalid: raise); bit 1 is never set since round 4 (it reported on the turn-taking
-        deterministic mode of rounds 2-3; the weight gradients are summed in fixed order by construction now)."""
+        LDS hand-over, bit 1 = a backward-chain launch did (barrier-free trunks: field_fwd.hip / field_bwd.hip); either way the
+        launch's results are invalid: raise."""
         import ctypes
         from . import _lib as L
         from .functions import _stream
         w = ctypes.c_uint(0)
         L.check(L.lib().bn_device_faults(ctypes.byref(w), _stream()), "bn_device_faults")
-        if w.value & 1:
-            raise RuntimeError("brdf_nerf_amd: a fused forward launch lost an LDS hand-over (device fault word bit 0); its results are invalid")
+        if w.value & 3:
+            raise RuntimeError(f"brdf_nerf_amd: a fused {'forward' if w.value & 1 else 'backward'} launch lost an LDS hand-over "
+                               f"(device fault word {w.value}); its results are invalid")
         return w.value
 
     # ------------------------------------------------------------------ checkpoints

@@ -447,8 +447,8 @@ int bn_adam_multi(float *param, float *grad, float *exp_avg, float *exp_avg_sq, 
 int bn_count_nonfinite(const float *x, int64_t n, unsigned long long *counts, void *stream);
 
 /* Device-side fault word of the fused kernels (bit 0: a wave of the barrier-free forward trunk gave up waiting for an LDS
- * hand-over - never in a correct run; the affected launch's results are invalid; bit 1: reserved, always 0 since ABI 5 - it
- * reported on the turn-taking deterministic mode of ABI 3-4).  The library mirrors the word to the
+ * hand-over - never in a correct run; the affected launch's results are invalid; bit 1: the same for the barrier-free trunk of
+ * the backward chain (round 4; ABI 3-4 reported their turn-taking deterministic mode there).  The library mirrors bit 0 to the
  * host asynchronously and fails the NEXT bn_field_* call with BN_ELAUNCH once it is set; this call synchronises `stream`
  * and reads it directly. */
 int bn_device_faults(unsigned int *faults, void *stream);

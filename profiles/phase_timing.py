@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from brdf_nerf_amd import build as B
 
-TIMED = ("field_fwd.hip", "field_bwd.hip")
+TIMED = ("field_fwd.hip", "field_bwd.hip", "field_wgrad.hip")
 
 
 def build_timing(defines=(), tag=""):
@@ -42,7 +42,8 @@ if __name__ == "__main__":
     from brdf_nerf_amd import load_model
     from brdf_nerf_amd import functions as Fn
     L = _lib.lib()
-    for fn in (L.bn_debug_phase_read_fwd, L.bn_debug_phase_read_bwd):
+    wg = "BN_PHASE_TIMING_WGRAD" in defines
+    for fn in (L.bn_debug_phase_read_fwd, L.bn_debug_phase_read_bwd) + ((L.bn_debug_phase_read_wgrad,) if wg else ()):
         fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
     dev = torch.device("cuda", 0)
     args = bench.make_args(4096, 64, 64, "bf16")
@@ -85,6 +86,6 @@ if __name__ == "__main__":
     d_out = torch.randn_like(out)
     grads = {k: torch.zeros_like(v) for k, v in model.named().items()}
     if "BN_PHASE_TIMING_WGRAD" in defines:
-        BWD = ["mfma", "bias", "lds_store(wait gld)", "barrier", "atomics"] + [""] * 9 + ["prologue"]
+        BWD = ["stage: fragment reads + MFMAs + next stage's LDS stores / global loads", "", "", "barrier", "slab stores"] + [""] * 9 + ["prologue"]
     report("backward: wgrad256" if "BN_PHASE_TIMING_WGRAD" in defines else "backward chain", lambda: Fn.field_backward_raw(spec, model.named(), grads, packed, out, d_out, stash, rays=b["rays"], z=z),
-           L.bn_debug_phase_read_bwd, BWD)
+           L.bn_debug_phase_read_wgrad if wg else L.bn_debug_phase_read_bwd, BWD)
