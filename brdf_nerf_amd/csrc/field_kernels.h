@@ -89,6 +89,7 @@ static __device__ unsigned long long bn_tl_buf[BN_TL_BLOCKS][8][BN_TL_EVENTS];
 // Stash traffic is streaming (written once here, read once by a later kernel) and several times larger than the
 // packed weights every workgroup re-reads from L2: non-temporal stores / loads keep it from evicting the weights.
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 template <typename V> __device__ __forceinline__ void stash_store(V *p, const V &v) {
 #ifdef BN_NO_NT_STASH      // A/B switch (results unchanged): plain stores / loads for the stash
   *p = v;

@@ -194,7 +194,8 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   // of this workgroup's 256 columns; lane (r, h) holds point r, columns 4 h + {0..3} and 8 + 4 h + {0..3} of the half.
   // Before the LDS write the two lanes of a point trade one run (v_permlane32_swap: lanes 32-63 of the first operand with
   // lanes 0-31 of the second), so that lane (r, h) holds the 8 CONSECUTIVE columns 8 h .. 8 h + 7 = one 16-byte piece, written
-  // with one ds_write_b128 like a row-major piece.
+  // with one ds_write_b128 like a row-major piece (two ds_write_b64 of the lane's own runs instead: 2-way bank conflicts, the
+  // kernel +14 %, profiles/r04_ablation.txt item 9).
   const int nr = lane & 31, nh = lane >> 5, nswz = w2_swz(nr);
   static_assert(W2_BK / (W2_WAVES * 2) == 4, "native staging: 4 wave-instructions per wave and stage");
   // chunk q = 4 w + c: 32-point block c & 1, column half (c >> 1) & 1, 32-column block w (one per wave): everything but the
@@ -226,10 +227,10 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
     // tile = m >> log2(bm); first 32-point block of the stage inside its tile = (m mod bm) / 32; a tile image is bm x F elements
     const int64_t tile_off = (m >> J.b_bm_shift) * tile_elems;
     const int mt0 = ((int)m & (J.b_bm - 1)) >> 5;
-    if (ANAT) ra[c] = *(const u32x4 *)((const T *)J.A + tile_off + mt0 * 1024 + aoff0 + ((c & 1) * 2 + ((c >> 1) & 1)) * 512);
-    else ra[c] = *(const u32x4 *)(pa + row * sa);
-    if (BNAT) rb[c] = *(const u32x4 *)((const T *)J.B + tile_off + mt0 * 1024 + boff0 + ((c & 1) * 2 + ((c >> 1) & 1)) * 512);
-    else rb[c] = *(const u32x4 *)(pb + row * sb);
+    const T *qa = ANAT ? (const T *)J.A + tile_off + mt0 * 1024 + aoff0 + ((c & 1) * 2 + ((c >> 1) & 1)) * 512 : pa + row * sa;
+    const T *qb = BNAT ? (const T *)J.B + tile_off + mt0 * 1024 + boff0 + ((c & 1) * 2 + ((c >> 1) & 1)) * 512 : pb + row * sb;
+    ra[c] = *(const u32x4 *)qa;
+    rb[c] = *(const u32x4 *)qb;
   };
   auto gload = [&](int64_t m) {
 #pragma unroll
@@ -316,7 +317,16 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   };
   gload(mb);
   sstore(0);
-  gload(mb + W2_BK);
+  // The prefetch of stage 1 in the order the stage loop re-fills the registers (chunk by chunk, A then B), pinned: hipcc hoisted
+  // and REVERSED these loads, the chunk the loop stores first entered it as the youngest load in flight, and its wait-count pass
+  // kept the merged "s_waitcnt vmcnt(0)" in front of every stage's first LDS store instead of vmcnt(6).  (Timing: equal - the
+  // loads have landed by then either way; profiles/r04_ablation.txt item 9.)
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    __builtin_amdgcn_sched_barrier(0);
+    gload1(mb + W2_BK, c);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   WG_PH(14)
   int buf = 0;
   for (int64_t m = mb; m < me; m += W2_BK) {
