@@ -1,0 +1,26 @@
+#!/bin/bash
+# round-4 GPU session 22: validation of the barrier-free backward trunk: PMC passes, bench lines of every BASELINE configuration,
+# rocprofv3 kernel stats over bench.py, a 6-rank rehearsal of the N > 1 bench path on one GPU (gloo; the box allows 6 GPU processes)
+run() {  # name, args...
+  name=$1; shift
+  timeout -k 10 300 python bench.py "$@" > gpurun_out/r04_bench_$name.json 2> gpurun_out/r04_bench_$name.err || { echo "bench $name failed"; tail -5 gpurun_out/r04_bench_$name.err; return; }
+  python - $name <<'PY'
+import json, sys
+d = json.load(open(f"gpurun_out/r04_bench_{sys.argv[1]}.json"))
+r = d["roofline"]
+print(sys.argv[1], round(d["value"]), "rays/s", round(d["ms_per_step"], 3), "ms | sustained", d["sustained"] and round(d["sustained"]["ms_per_step"], 3), "| launches", d["launches_per_step"], "|", r["kernel"], "alg", round(r["frac_algorithmic"], 3), "exe", round(r["frac_executed"], 3), "| traffic", r["traffic"], "| step frac", round(d.get("step_frac_of_peak", 0), 3), "| cpu", (d.get("cpu_baseline") or {}).get("value"))
+PY
+}
+bash profiles/pmc_collect.sh lambert_bf16 rpv_nan_bf16 > gpurun_out/pmc_collect22.log 2>&1; tail -3 gpurun_out/pmc_collect22.log | cut -c1-300
+cd $GRAFT_REPO_ROOT
+cp gpurun_out/r04_pmc.json profiles/r04_pmc.json      # so that the bench lines below carry roofline.traffic / mfma_busy
+run config2_bf16
+run config2_fp16 --dtype fp16 --no-cpu-baseline
+run config3_rpv_nan_bf16 --config rpv_nan --no-cpu-baseline
+run config4_pergpu_rpv_nan_s128_bf16 --config rpv_nan --rays 1024 --samples 128 --no-cpu-baseline
+run config5_hapke_fp16 --config hapke --dtype fp16 --no-cpu-baseline
+run config5_microfacet_fp16 --config microfacet --dtype fp16 --no-cpu-baseline
+bash profiles/stats_bench.sh > gpurun_out/stats_bench22.log 2>&1; tail -8 gpurun_out/stats_bench22.log | cut -c1-200
+cd $GRAFT_REPO_ROOT
+BN_BENCH_SHARE_GPU=1 BN_BENCH_BACKEND=gloo timeout -k 10 400 python bench.py --gpus 6 --rays 512 --steps 10 --warmup 2 --no-cpu-baseline --sustained-seconds 1 > gpurun_out/r04_bench_n6_rehearsal_one_gpu_gloo.json 2> gpurun_out/r04_bench_n6_rehearsal.err || tail -5 gpurun_out/r04_bench_n6_rehearsal.err
+cut -c1-600 gpurun_out/r04_bench_n6_rehearsal_one_gpu_gloo.json
