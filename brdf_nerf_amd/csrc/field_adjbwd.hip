@@ -106,10 +106,27 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
   const int n_on = F / (32 * NT) < WAVES ? F / (32 * NT) : WAVES;
   // the row-major stash copy of abar_l (the tile layer l's GEMM reads) rides inside that GEMM when the shape fits
   const bool ride = NT == 2 ? true : tile_copy_exact(F, n_on, WAVES);
+  // 16-bit modes (round 4): the layer's derivative bytes leave HBM before its GEMM (32 registers, as in the primal backward
+  // chain), and its a_{l+1} / y_l pieces in batches of ADJ_GRP point tiles - one exposed latency per batch instead of one per
+  // piece (the loads used to sit beside their uses inside the epilogue loops).
+  constexpr bool PRE = Elem<T>::kD8;
+#ifndef ADJ_GRP
+#define ADJ_GRP 2      // point tiles per batch of a_{l+1} / y_l loads (4 = a whole n-tile: 212 B of scratch per lane)
+#endif
+  DPiece<T> dpre[PRE ? NT : 1][PRE ? MT : 1];
   for (int l = 0; l < g.L; ++l) {
     zero_acc<MT, NT>(acc);
     T *adst = (T *)(A.stash + A.sl.adj_abar[l]) + (size_t)m0 * F;   // abar_l, l >= 1
     if (!ride && l > 0) tile_to_global<T>(ACT, LDA, adst, F, BM, F);
+    if constexpr (PRE) {
+      if (wave_on) {
+        const char *Dp = A.stash + A.sl.D[l] + (size_t)tile * dtile_bytes<T>(BM, F);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) dpre[nt][mt] = dpiece_load<T>(Dp + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
+      }
+    }
     if (wave_on) {
       const size_t t0 = (size_t)(ncol0 / 32);
       const T *w_pe = packed + A.pl.fwd_trunk[l][0] + t0 * KSP * 512;
@@ -163,16 +180,35 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       const T *Yn = (const T *)(A.stash + A.sl.Y[l]) + (size_t)tile * BM * F;        // native-order y_l (16-bit modes)
       typename Elem<T>::wide *Zs = (typename Elem<T>::wide *)(A.stash + A.sl.adj_zbar[l]) + (size_t)tile * BM * F;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt) {
+        u32x4 araw[PRE ? MT : 1][2], yraw[PRE ? MT : 1][2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+          if constexpr (PRE) {
+            if (mt % ADJ_GRP == 0) {     // the pieces of the next ADJ_GRP point tiles together
+#pragma unroll
+              for (int q = mt; q < mt + ADJ_GRP && q < MT; ++q)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                  araw[q][gp] = stash_load((const u32x4 *)(As + native_off8<MT, NT>(wave, nt, q, gp, lane)));
+                  yraw[q][gp] = stash_load((const u32x4 *)(Yn + native_off8<MT, NT>(wave, nt, q, gp, lane)));
+                }
+            }
+          }
           const int m = mt * 32 + r;
-          const DPiece<T> pc = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
+          DPiece<T> pc;
+          if constexpr (PRE) pc = dpre[nt][mt];
+          else pc = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
 #pragma unroll
           for (int gp = 0; gp < 2; ++gp) {
             const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
             float dv[8], av[8], zb[8], db[8], yv[8];
             dpiece_get<T>(pc, gp, dscale, dv);
+            if constexpr (PRE) {
+              const auto aq = __builtin_bit_cast(typename Elem<T>::frag, araw[mt][gp]), yq = __builtin_bit_cast(typename Elem<T>::frag, yraw[mt][gp]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { av[e] = (float)aq[e]; yv[e] = (float)yq[e]; }
+            } else {
             ld8(As + native_off8<MT, NT>(wave, nt, mt, gp, lane), av);
             if (NATY) {
               ld8(Yn + native_off8<MT, NT>(wave, nt, mt, gp, lane), yv);
@@ -180,6 +216,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
               const vec4 ya = *(const vec4 *)(ACT + (size_t)m * LDA + n0), yb = *(const vec4 *)(ACT + (size_t)m * LDA + n0 + 8);
 #pragma unroll
               for (int e = 0; e < 4; ++e) { yv[e] = (float)ya[e]; yv[4 + e] = (float)yb[e]; }
+            }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) db[e] = acc[nt][mt][8 * gp + e] * unscale;
@@ -194,6 +231,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
             *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), db[4] * dv[4], db[5] * dv[5], db[6] * dv[6], db[7] * dv[7]);
           }
         }
+      }
     }
     __syncthreads();
   }

@@ -341,6 +341,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
     const float dscale = (g.act == BN_ACT_SIN && lo == 0) ? 30.f : 1.f;    // w0 of layer lo (the stash holds the unscaled derivative)
     const auto Zr = stash_rsrc(A.stash + A.sl.dZ[lo] + (size_t)tile * BM * F * sizeof(T));
     const int voff = lane * 16;
+    // analytic normals: all of the layer's zbar_lo pieces leave HBM together at the top of the epilogue (the GEMM's fragment
+    // registers are free by now) - one exposed latency per layer instead of one per group of pieces
+    typedef typename Elem<T>::wide WT;
+    constexpr bool ZPRE = sizeof(WT) == 2;
+    u32x4 zraw[ZPRE ? NT : 1][ZPRE ? MT : 1][2];
+    if constexpr (ZPRE) {
+      if (A.an) {
+        const WT *Zb = (const WT *)(A.stash + A.sl.adj_zbar[lo]) + (size_t)tile * BM * F;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) zraw[nt][mt][gp] = stash_load((const u32x4 *)(Zb + native_off8<MT, NT>(wave, nt, mt, gp, lane)));
+      }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -373,7 +389,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
           for (int e = 0; e < 8; ++e) v[e] *= dv[e];
           if (A.an) {  // + dL/dz_l through D_l of the analytic-normal adjoint chain (stored at that chain's own scale)
             float zb[8];
-            ld8((const typename Elem<T>::wide *)(A.stash + A.sl.adj_zbar[lo]) + (size_t)tile * BM * F + native_off8<MT, NT>(wave, nt, mt, gp, lane), zb);
+            if constexpr (ZPRE) {
+              const auto zq = __builtin_bit_cast(bf16x8, zraw[nt][mt][gp]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) zb[e] = (float)zq[e];
+            } else {
+              ld8((const WT *)(A.stash + A.sl.adj_zbar[lo]) + (size_t)tile * BM * F + native_off8<MT, NT>(wave, nt, mt, gp, lane), zb);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += zb[e] * zr;
           }
