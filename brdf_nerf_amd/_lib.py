@@ -65,6 +65,10 @@ class NormalReg(C.Structure):         # bn_normal_reg
                 ("lambda_an", C.c_float), ("lambda_lr", C.c_float)]
 
 
+class Noise(C.Structure):             # bn_noise
+    _fields_ = [("rng", fptr), ("noise_std", C.c_float), ("rng_stream", C.c_uint32), ("ray_offset", C.c_int64)]
+
+
 class FoldDesc(C.Structure):          # bn_fold_desc
     _fields_ = [("n_heads", C.c_int32), ("F", C.c_int32), ("rows", C.c_int32), ("wf", fptr), ("bf", fptr),
                 ("w1", fptr * BN_MAX_HEADS), ("w1_ld", C.c_int64 * BN_MAX_HEADS), ("b1", fptr * BN_MAX_HEADS),
@@ -74,7 +78,7 @@ class FoldDesc(C.Structure):          # bn_fold_desc
 
 
 BN_STATE_BYTES, BN_STATE_LOSS_OFF, BN_STATE_LOSS_SLOTS, BN_STATE_POW_OFF, BN_STATE_PART_OFF = 1024, 64, 64, 320, 512
-BN_RNG_COARSE, BN_RNG_GUIDED, BN_RNG_GUIDED_TARGET = 1, 2, 3
+BN_RNG_COARSE, BN_RNG_GUIDED, BN_RNG_GUIDED_TARGET, BN_RNG_NOISE_COARSE, BN_RNG_NOISE_MERGED = 1, 2, 3, 4, 5
 BN_BWD_CHAIN, BN_BWD_WGRAD_TRUNK, BN_BWD_WGRAD_HEADS, BN_BWD_SKINNY, BN_BWD_ALL = 1, 2, 4, 8, 15
 
 
@@ -125,19 +129,20 @@ _SIGS = {
     "bn_count_nonfinite": (C.c_int, [fptr, C.c_int64, fptr, fptr]),
     "bn_stratified_z_rng": (C.c_int, [fptr, fptr, C.c_int64, fptr, C.c_uint32, C.c_int64, C.c_int64, C.c_int32, fptr, fptr]),
     "bn_rng_uniform": (C.c_int, [fptr, C.c_uint32, C.c_int64, fptr, fptr]),
+    "bn_rng_normal": (C.c_int, [fptr, C.c_uint32, C.c_int64, fptr, fptr]),
     "bn_composite_guided": (C.c_int, [fptr, fptr, C.c_int64, C.c_int64, C.c_int32, C.c_int32, fptr, C.c_float, fptr, C.c_int64,
                                       fptr, C.c_int64, fptr, C.c_int64, fptr, fptr, fptr, C.c_uint32, C.c_uint32, C.c_int64, fptr, fptr,
-                                      fptr, fptr, fptr, fptr]),
+                                      fptr, fptr, fptr, fptr, fptr]),
     "bn_merged_composite_forward": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, fptr,
-                                              fptr, fptr, fptr, fptr, fptr, fptr, fptr]),
+                                              fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr]),
     "bn_merged_composite_backward": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, fptr,
-                                               fptr, C.c_float, fptr, fptr, fptr, fptr, fptr, fptr]),
+                                               fptr, C.c_float, fptr, fptr, fptr, fptr, fptr, fptr, fptr]),
     "bn_ray_shade_loss": (C.c_int, [fptr, fptr, fptr, fptr, fptr, fptr, C.c_int64, fptr, C.c_int64, fptr, fptr, C.c_int64, fptr,
                                     C.c_int64, fptr, C.c_int64, fptr, C.c_int64, C.c_int64, fptr, fptr, fptr, C.c_int32, fptr, fptr,
                                     fptr, fptr, fptr, fptr]),
     "bn_lambert_tail": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, C.c_int64, fptr,
                                   C.c_int64, fptr, C.c_int64, fptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, fptr, fptr,
-                                  C.c_int32, fptr, fptr, fptr, fptr, fptr, fptr, fptr]),
+                                  C.c_int32, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr]),
     "bn_fold_heads": (C.c_int, [fptr, fptr]),
     "bn_unfold_heads": (C.c_int, [fptr, fptr]),
     "bn_adam_multi": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, fptr, fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float,
@@ -181,7 +186,7 @@ def load(path, baseline=False):
             continue
         fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if not baseline and L.bn_abi_version() != 5:
+    if not baseline and L.bn_abi_version() != 6:
         raise LibraryMissing(f"{path}: ABI version mismatch; rebuild")
     if not baseline and os.environ.get("BRDFNERF_ALLOW_STALE_LIB", "0") in ("", "0"):
         # a library older than the sources beside it must not pass for them (tests, bench and profiles all run through here)

@@ -51,6 +51,30 @@ __device__ __forceinline__ float philox_uniform(const unsigned long long *rng, u
   return (float)(o[index & 3] >> 8) * 5.9604644775390625e-08f;
 }
 
+// standard normal by Box-Muller on one pair of a Philox block (two normals per block: pair index & 1); u1 in (0, 1]
+__device__ __forceinline__ float philox_normal(const unsigned long long *rng, unsigned int stream, unsigned long long index) {
+  unsigned int o[4];
+  philox4(rng[0], rng[1], stream, index >> 1, o);
+  const int q = (int)(index & 1) * 2;
+  const float u1 = (float)((o[q] >> 8) + 1u) * 5.9604644775390625e-08f, u2 = (float)(o[q + 1] >> 8) * 5.9604644775390625e-08f;
+  return sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
+}
+// sigma + noise of sample position s of ray `ray` in a compositing over S positions (bn_noise; rng == nullptr: sigma as it is)
+struct NoiseArgs {
+  const unsigned long long *rng;
+  float noise_std;
+  unsigned int stream;
+  int64_t ray_offset;
+};
+__device__ __forceinline__ float noised(const NoiseArgs &N, float sg, int64_t ray, int S, int s) {
+  return N.rng ? sg + philox_normal(N.rng, N.stream, (unsigned long long)((ray + N.ray_offset) * S + s)) * N.noise_std : sg;
+}
+static NoiseArgs make_noise(const bn_noise *n) {
+  NoiseArgs a = {nullptr, 0.f, 0u, 0};
+  if (n && n->rng && n->noise_std != 0.f) { a.rng = n->rng; a.noise_std = n->noise_std; a.stream = n->rng_stream; a.ray_offset = n->ray_offset; }
+  return a;
+}
+
 // ------------------------------------------------------------------------------------------ stratified z
 __global__ void stratified_z_kernel(const float *near, const float *far, int64_t nf_stride, const float *u,
                                     const unsigned long long *rng, unsigned int rng_stream, int64_t draw_offset, int64_t R, int S,
@@ -94,6 +118,16 @@ extern "C" int bn_stratified_z_rng(const float *near, const float *far, int64_t 
 __global__ void rng_uniform_kernel(const unsigned long long *rng, unsigned int rng_stream, int64_t n, float *u) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) u[i] = philox_uniform(rng, rng_stream, (unsigned long long)i);
+}
+__global__ void rng_normal_kernel(const unsigned long long *rng, unsigned int rng_stream, int64_t n, float *x) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = philox_normal(rng, rng_stream, (unsigned long long)i);
+}
+extern "C" int bn_rng_normal(const unsigned long long *rng, uint32_t rng_stream, int64_t n, float *x, void *stream) {
+  BN_REQUIRE(rng && x && n > 0, "rng_normal: bad arguments");
+  rng_normal_kernel<<<dim3((unsigned)ceil_div64(n, 256)), 256, 0, (hipStream_t)stream>>>(rng, rng_stream, n, x);
+  BN_LAUNCH_CHECK("rng_normal");
+  return 0;
 }
 extern "C" int bn_rng_uniform(const unsigned long long *rng, uint32_t rng_stream, int64_t n, float *u, void *stream) {
   BN_REQUIRE(rng && u && n > 0, "rng_uniform: bad arguments");
@@ -664,6 +698,7 @@ struct CompGuidedArgs {
   const float *sigma;        // [R][S] with element stride sigma_stride
   int64_t sigma_stride;
   float *weights, *depth;    // optional copies of the pass-1 weights / depth (nullable)
+  NoiseArgs noise;           // --noise_std on the pass-1 compositing
 };
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void composite_guided_kernel(const CompGuidedArgs A) {
   __shared__ float s_edges[WAVES_PER_BLOCK][BN_MAX_G];
@@ -685,7 +720,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void composite_guided_kernel(
     if (j < cpl && s < S) {
       zv[j] = z[s];
       const float delta = s == S - 1 ? 1e10f : z[s + 1] - zv[j];
-      const float sg = A.sigma[(ray * S + s) * A.sigma_stride];
+      const float sg = noised(A.noise, A.sigma[(ray * S + s) * A.sigma_stride], ray, S, s);
       const float rs = sg > 0.f ? sg : 0.f;
       al[j] = 1.f - expf(-delta * rs);
       u[j] = 1.f - al[j] + 1e-10f;
@@ -752,7 +787,7 @@ extern "C" int bn_composite_guided(const float *z, const float *sigma, int64_t s
                                    const float *target_depth, int64_t td_stride, const float *target_std, int64_t ts_stride,
                                    const float *u, const float *u_target, const unsigned long long *rng, uint32_t rng_u,
                                    uint32_t rng_ut, int64_t ray_offset, float *z2_sorted, float *z_all, int64_t *sort_idx, float *weights,
-                                   float *depth, void *stream) {
+                                   float *depth, const bn_noise *noise, void *stream) {
   BN_REQUIRE(z && sigma && near_far && z2_sorted && R > 0, "composite_guided: null argument");
   BN_REQUIRE(G >= 3 && G <= BN_MAX_G && S >= 1 && S <= 64 * BN_MAX_CPL && S + G <= BN_MAX_SG, "composite_guided: S=%d G=%d unsupported", S, G);
   BN_REQUIRE(!use_target || (target_depth && target_std && (u_target || rng)), "composite_guided: target arrays");
@@ -760,7 +795,7 @@ extern "C" int bn_composite_guided(const float *z, const float *sigma, int64_t s
   CompGuidedArgs a;
   a.g = GuidedArgs{z, nullptr, nullptr, u, use_target, target_depth, target_std, u_target, nullptr, R, S, G,
                    0.f, 0.f, d_range, z2_sorted, z_all, sort_idx, near_far, td_stride, ts_stride, ut_stride, rng, rng_u, rng_ut, ray_offset};
-  a.sigma = sigma; a.sigma_stride = sigma_stride; a.weights = weights; a.depth = depth;
+  a.sigma = sigma; a.sigma_stride = sigma_stride; a.weights = weights; a.depth = depth; a.noise = make_noise(noise);
   BnProfScope prof_(BN_K_GUIDED, (hipStream_t)stream);
   composite_guided_kernel<<<dim3((unsigned)ceil_div64(R, WAVES_PER_BLOCK)), 64 * WAVES_PER_BLOCK, 0, (hipStream_t)stream>>>(a);
   BN_LAUNCH_CHECK("composite_guided");
@@ -798,6 +833,7 @@ struct MergedArgs {
   // MODE 1, 2
   float *d_out1, *d_out2;
   unsigned long long *nonfinite;   // nullable: zero non-finite gradient elements and count them ([0] NaN, [1] Inf)
+  NoiseArgs noise;                 // --noise_std on the merged set (position = sorted position)
 };
 
 // C4 (C == 4 and 16-byte aligned blocks: the Lambertian model): a sample's row is ONE 16-byte load kept in registers for the
@@ -824,7 +860,7 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
       zv[j] = z[s];
       const float delta = s == S - 1 ? 1e10f : z[s + 1] - zv[j];
       if (C4) rv[C4 ? j : 0] = *(const f32x4 *)rowp(roff[j]);
-      const float sg = chan(j, 3);
+      const float sg = noised(A.noise, chan(j, 3), ray, S, s);
       const float rs = sg > 0.f ? sg : 0.f;
       const float e = expf(-delta * rs);
       al[j] = 1.f - e;
@@ -1053,8 +1089,9 @@ static bool merged_c4(const MergedArgs &a) {
 extern "C" int bn_merged_composite_forward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
                                            int32_t S2, int32_t C, int64_t R, float *alphas, float *trans, float *weights, float *depth,
                                            float *acc, float *wsum, float *var, const bn_normal_reg *nreg, float *reg_out,
-                                           void *stream) {
+                                           const bn_noise *noise, void *stream) {
   MergedArgs a = {};
+  a.noise = make_noise(noise);
   a.z = z; a.idx = sort_idx; a.out1 = out1; a.out2 = out2; a.S1 = S1; a.S2 = S2; a.C = C; a.R = R;
   a.alphas = alphas; a.trans = trans; a.weights = weights; a.depth = depth; a.acc = acc; a.wsum = wsum; a.var = var;
   if (nreg && nreg->rays_d) {
@@ -1074,8 +1111,9 @@ extern "C" int bn_merged_composite_backward(const float *z, const int64_t *sort_
                                             int32_t S2, int32_t C, int64_t R, const float *d_weights, const float *d_depth,
                                             const float *d_acc, const float *d_wsum, float hs_scale, const float *depth,
                                             const bn_normal_reg *nreg, float *d_out1, float *d_out2, unsigned long long *nonfinite,
-                                            void *stream) {
+                                            const bn_noise *noise, void *stream) {
   MergedArgs a = {};
+  a.noise = make_noise(noise);
   a.z = z; a.idx = sort_idx; a.out1 = out1; a.out2 = out2; a.S1 = S1; a.S2 = S2; a.C = C; a.R = R;
   a.d_weights = d_weights; a.d_depth = d_depth; a.d_acc = d_acc; a.d_wsum = d_wsum; a.d_out1 = d_out1; a.d_out2 = d_out2;
   a.nonfinite = nonfinite; a.hs_scale = hs_scale; a.depth_in = depth;
@@ -1099,8 +1137,10 @@ extern "C" int bn_lambert_tail(const float *z, const int64_t *sort_idx, const fl
                                const float *target_depth, int64_t td_stride, const float *target_weight, int64_t tw_stride,
                                const float *target_std, int64_t ts_stride, float rgb_padding, float lambda_rgb, float lambda_ds,
                                int32_t usealldepth, float *ray_loss, float *loss_acc, int32_t loss_slots, float *rgb,
-                               float *weights, float *depth, float *d_out1, float *d_out2, unsigned long long *nonfinite, void *stream) {
+                               float *weights, float *depth, float *d_out1, float *d_out2, unsigned long long *nonfinite,
+                               const bn_noise *noise, void *stream) {
   MergedArgs a = {};
+  a.noise = make_noise(noise);
   a.z = z; a.idx = sort_idx; a.out1 = out1; a.out2 = out2; a.S1 = S1; a.S2 = S2; a.C = C; a.R = R;
   a.rgbs = rgbs; a.valid = valid_depth; a.tdepth = target_depth; a.tweight = target_weight; a.tstd = target_std;
   a.v_stride = v_stride; a.td_stride = td_stride; a.tw_stride = tw_stride; a.ts_stride = ts_stride;

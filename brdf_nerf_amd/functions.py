@@ -521,6 +521,26 @@ def rng_uniform(state, stream_id, n):
     return u
 
 
+def rng_normal(state, stream_id, n):
+    x = torch.empty(n, dtype=torch.float32, device=state.device)
+    L.check(L.lib().bn_rng_normal(_p(state), int(stream_id), n, _p(x), _stream()), "bn_rng_normal")
+    return x
+
+
+def noise_arg(state, noise_std, stream_id, ray_offset=0):
+    """bn_noise: --noise_std with in-kernel draws (stream `stream_id` of the step state); None when noise_std == 0."""
+    if not noise_std:
+        return None
+    n = L.Noise()
+    n.rng, n.noise_std, n.rng_stream, n.ray_offset = state.data_ptr(), float(noise_std), int(stream_id), int(ray_offset)
+    n._keep = state
+    return n
+
+
+def _nz(noise):
+    return None if noise is None else C.byref(noise)
+
+
 def _strided(t):
     """(pointer, element stride) of a 1-d float32 view (e.g. depths[:, 0]); None -> (None, 1)."""
     if t is None:
@@ -530,7 +550,7 @@ def _strided(t):
 
 
 def composite_guided(z, out1, G, near_far, d_range, use_target=None, target_depth=None, target_std=None, u=None, u_target=None,
-                     state=None, bufs=None, want_pass1=False, ray_offset=0, sigma=None):
+                     state=None, bufs=None, want_pass1=False, ray_offset=0, sigma=None, noise=None):
     """Pass-1 compositing of out1 [R][S][C] (sigma = channel 3; or `sigma` [R][S] from a sigma-only pass 1, out1 = None) +
     depth-guided resampling + merge in one launch.
     Draws: arrays u / u_target [R][G], or the in-kernel streams of `state`.  -> z2 [R][G], z_all [R][S+G], sort_idx [R][S+G]
@@ -550,7 +570,7 @@ def composite_guided(z, out1, G, near_far, d_range, use_target=None, target_dept
     L.check(L.lib().bn_composite_guided(_p(z), sig_ptr, Cc, R, S, G, C.c_void_p(near_far.data_ptr()),
                                         float(d_range), ut_p, ut_s, td_p, td_s, ts_p, ts_s, _p(u), _p(u_target), _p(state),
                                         L.BN_RNG_GUIDED, L.BN_RNG_GUIDED_TARGET, int(ray_offset), _p(z2), _p(z_all), _p(idx), _p(w1), _p(d1),
-                                        _stream()), "bn_composite_guided")
+                                        _nz(noise), _stream()), "bn_composite_guided")
     return (z2, z_all, idx, w1, d1) if want_pass1 else (z2, z_all, idx)
 
 
@@ -569,7 +589,7 @@ def normal_reg(rays_d, ch_an, ch_lr, lambda_an, lambda_lr):
     return nr
 
 
-def merged_composite_forward(z_all, idx, out1, out2, bufs=None, want=("weights", "depth", "acc"), nreg=None):
+def merged_composite_forward(z_all, idx, out1, out2, bufs=None, want=("weights", "depth", "acc"), nreg=None, noise=None):
     """Compositing of the depth-sorted union of out1 [R][S1][C] and out2 [R][G][C] read through sort_idx (no cat / gather).
     -> dict with the requested entries of alphas, trans, weights, depth, acc, wsum, var (+ reg: the rays' NormalRegLoss terms,
     with nreg = normal_reg(...))."""
@@ -584,13 +604,13 @@ def merged_composite_forward(z_all, idx, out1, out2, bufs=None, want=("weights",
     L.check(L.lib().bn_merged_composite_forward(_p(z_all), _p(idx), _p(out1), _p(out2), S1, S2, Cc, R, g("alphas"), g("trans"),
                                                 g("weights"), g("depth"), g("acc"), g("wsum"), g("var"),
                                                 None if nreg is None else C.byref(nreg), g("reg") if nreg is not None else None,
-                                                _stream()),
+                                                _nz(noise), _stream()),
             "bn_merged_composite_forward")
     return o
 
 
 def merged_composite_backward(z_all, idx, out1, out2, d_weights, d_depth, d_acc, d_out1, d_out2, d_wsum=None, nonfinite=None,
-                              hs_scale=0.0, depth=None, nreg=None):
+                              hs_scale=0.0, depth=None, nreg=None, noise=None):
     """Gradient rows in the SOURCE layouts (d_out1 [R][S1][C], d_out2 [R][G][C]); channel 3 receives d sigma.  hs_scale (with
     the forward's depth): + hs_scale (z - depth)^2 on d loss / d w (HardSurfaceLoss, see ray_shade_loss)."""
     R, S2 = z_all.shape
@@ -598,7 +618,7 @@ def merged_composite_backward(z_all, idx, out1, out2, d_weights, d_depth, d_acc,
     L.check(L.lib().bn_merged_composite_backward(_p(z_all), _p(idx), _p(out1), _p(out2), S1, S2, Cc, R, _p(d_weights), _p(d_depth),
                                                  _p(d_acc), _p(d_wsum), float(hs_scale), _p(depth if hs_scale else None),
                                                  None if nreg is None else C.byref(nreg), _p(d_out1), _p(d_out2), _p(nonfinite),
-                                                 _stream()),
+                                                 _nz(noise), _stream()),
             "bn_merged_composite_backward")
 
 
@@ -636,7 +656,7 @@ def ray_shade_loss(desc, acc, wsum, depth, var, rays_d, sun_d, rgbs, bufs=None, 
 
 def lambert_tail(z_all, idx, out1, out2, rgbs, rgb_padding, lambda_rgb, d_out1, d_out2, valid_depth=None, target_depth=None,
                  target_weight=None, target_std=None, lambda_ds=0.0, usealldepth=False, ray_loss=None, loss_acc=None, rgb=None,
-                 weights=None, depth=None, nonfinite=None):
+                 weights=None, depth=None, nonfinite=None, noise=None):
     """Ray-level tail of a Lambertian step in one launch (bn_lambert_tail): merged compositing + shading + SNerfLoss +
     DepthLoss + the backward of all of it, gradient rows written to d_out1 / d_out2.  nonfinite ([2] int64 counters): rays with a
     non-finite loss term are left out and counted, non-finite gradient elements zeroed and counted."""
@@ -651,7 +671,7 @@ def lambert_tail(z_all, idx, out1, out2, rgbs, rgb_padding, lambda_rgb, d_out1, 
                                     tsp, tss, float(rgb_padding), float(lambda_rgb), float(lambda_ds if use else 0.0),
                                     int(bool(usealldepth)), _p(ray_loss), _p(loss_acc), 0 if loss_acc is None else loss_acc.numel(),
                                     _p(rgb), _p(weights), _p(depth),
-                                    _p(d_out1), _p(d_out2), _p(nonfinite), _stream()), "bn_lambert_tail")
+                                    _p(d_out1), _p(d_out2), _p(nonfinite), _nz(noise), _stream()), "bn_lambert_tail")
 
 
 def adam_multi(param, grad, exp_avg, exp_avg_sq, groups, active, state, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,

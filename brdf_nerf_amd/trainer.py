@@ -150,7 +150,7 @@ class FusedTrainer:
         reg0 = self.reg if regularisers else {}
         # (a loss that reads per-sample channels of the merged set beyond NormalRegLoss - MultiBRDF, NormalLoss - keeps the general path)
         per_sample0 = (bool(model.MultiBRDF) and apply_brdf) or abs(reg0.get("nr_spv", 0)) > 1e-5
-        if (self.lean and not self.strict_rng and args.noise_std == 0 and self.reuse_coarse and not per_sample0
+        if (self.lean and not self.strict_rng and self.reuse_coarse and not per_sample0
                 and not (getattr(model, "sun_v", "none") == "analystic" and apply_brdf)
                 and rays.dtype == torch.float32 and rays.is_contiguous() and rays.shape[1] >= 8 and S + G <= 512):
             return self._step_lean(spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, apply_theta, cos_irra_on,
@@ -369,7 +369,7 @@ class FusedTrainer:
                    nf.data_ptr(), use_ds, tuple(active), float(self.ds_lambda), float(self.lambda_rgb), bool(self.usealldepth),
                    L.deterministic(), int(self.ray_offset), bool(self.keep_grads), bool(self.merge_passes), bool(apply_brdf),
                    bool(cos_irra_on), float(reg.get("hs", 0)), bool(self.sanitize_grads), float(reg.get("nr_an", 0)),
-                   float(reg.get("nr_lr", 0)), bool(gsam_only))
+                   float(reg.get("nr_lr", 0)), bool(gsam_only), float(args.noise_std))
             ent = self._graphs.get(sig)
             if ent is not None:
                 self._graphs.move_to_end(sig)
@@ -436,6 +436,11 @@ class FusedTrainer:
             merged = self.merge_passes and (R * S) % tile == 0 and not gsam_only
             n_all = R * (S + G)
             has_t = valid_depth is not None
+            # --noise_std (models/spsbrdfnerf.py:57-59, decayed per epoch by main.py:246): in-kernel normal draws, one stream for
+            # the pass-1 compositing and one for the final compositing of the merged set (the general step draws randn(R, S) and
+            # randn(R, S + G) at the same two places)
+            nz1 = Fn.noise_arg(st, args.noise_std, L.BN_RNG_NOISE_COARSE, self.ray_offset)
+            nz2 = Fn.noise_arg(st, args.noise_std, L.BN_RNG_NOISE_MERGED, self.ray_offset)
             bufs = {"z2": self._buf("z2", (R, G)), "z_all": self._buf("z_all", (R, S + G)),
                     "idx": self._buf("idx", (R, S + G), torch.int64)}
             if gsam_only:
@@ -444,7 +449,7 @@ class FusedTrainer:
                 sig1 = Fn.field_sigma(spec, named, packed, rays=rays, z=z, out=self._buf("sig1", (R * S,)))
                 z2, _, _ = Fn.composite_guided(z, None, G, nf, args.std_range, valid_depth if has_t else None,
                                                depths[:, 0] if has_t else None, depth_std if has_t else None, state=st, bufs=bufs,
-                                               ray_offset=self.ray_offset, sigma=sig1.view(R, S))
+                                               ray_offset=self.ray_offset, sigma=sig1.view(R, S), noise=nz1)
                 if self.seed_hook is not None:
                     self.seed_hook("z2", z2)
                 out2 = self._buf("out2", (R * G, C))
@@ -467,7 +472,7 @@ class FusedTrainer:
                 out1v = out1.view(R, S, C)
                 z2, z_all, idx = Fn.composite_guided(z, out1v, G, nf, args.std_range, valid_depth if has_t else None,
                                                      depths[:, 0] if has_t else None, depth_std if has_t else None, state=st, bufs=bufs,
-                                                     ray_offset=self.ray_offset)
+                                                     ray_offset=self.ray_offset, noise=nz1)
                 if self.seed_hook is not None:   # (and the guided depths pass 2 is evaluated at)
                     self.seed_hook("z2", z2)
                 if merged:
@@ -489,7 +494,7 @@ class FusedTrainer:
                                 valid_depth if use_ds else None, depths[:, 0] if use_ds else None, depths[:, 1] if use_ds else None,
                                 depth_std if use_ds else None, self.ds_lambda if use_ds else 0.0, self.usealldepth,
                                 ray_loss=ray_loss, loss_acc=None if det else Fn.state_loss_partials(st), rgb=rgb,
-                                nonfinite=self._nonfinite if self.sanitize_grads else None)
+                                nonfinite=self._nonfinite if self.sanitize_grads else None, noise=nz2)
                 if det:
                     loss = ray_loss.sum()
         else:
@@ -507,7 +512,7 @@ class FusedTrainer:
                 o = Fn.merged_composite_forward(z_all, idx, out1v, out2v,
                                                 {k: self._buf("m_" + k, sh) for k, sh in (("depth", (R,)), ("acc", (R, C)),
                                                                                           ("wsum", (R,)), ("var", (R,)), ("reg", (R,)))},
-                                                want=("depth", "acc", "wsum", "var"), nreg=nreg)
+                                                want=("depth", "acc", "wsum", "var"), nreg=nreg, noise=nz2)
                 sun_d = rays[:, 8:11] if args.data == "sat" else None
                 sb = {k: self._buf("s_" + k, sh) for k, sh in (("rgb", (R, 3)), ("d_acc", (R, C)), ("d_wsum", (R,)),
                                                                ("d_depth", (R,)))}
@@ -519,7 +524,7 @@ class FusedTrainer:
                 rgb = g["rgb"]
                 Fn.merged_composite_backward(z_all, idx, out1v, out2v, None, g["d_depth"], g["d_acc"], d1o, d2o, d_wsum=g["d_wsum"],
                                              nonfinite=self._nonfinite if self.sanitize_grads else None, hs_scale=hs / R if hs > 0 else 0.0,
-                                             depth=o["depth"], nreg=nreg)
+                                             depth=o["depth"], nreg=nreg, noise=nz2)
                 if det:
                     loss = ray_loss.sum()
         if self.seed_hook is not None:       # test hook: sees (and may overwrite) the gradient rows [R (S + G)][C] the field backward starts from

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BN_ABI_VERSION 5
+#define BN_ABI_VERSION 6
 #define BN_MAX_LAYERS 12
 #define BN_MAX_HEADS 6 /* rgb (+ beta) + up to 3 BRDF heads evaluated together, two per pass */
 
@@ -321,7 +321,21 @@ int bn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
 #define BN_STATE_PART_OFF 512
 #define BN_ADAM_MAX_GROUPS 4
 /* in-kernel draw streams of one step */
-enum { BN_RNG_COARSE = 1, BN_RNG_GUIDED = 2, BN_RNG_GUIDED_TARGET = 3 };
+enum { BN_RNG_COARSE = 1, BN_RNG_GUIDED = 2, BN_RNG_GUIDED_TARGET = 3, BN_RNG_NOISE_COARSE = 4, BN_RNG_NOISE_MERGED = 5 };
+
+/* --noise_std (models/spsbrdfnerf.py:57-59: alphas = 1 - exp(-deltas * relu(sigmas + randn * noise_std)), main.py:246) with
+ * in-kernel draws (ABI 6): a standard normal per (ray, sample position) from stream `rng_stream` of the state at `rng`
+ * (Box-Muller on a Philox pair), element (ray_offset + r) * S + s of the stream, S = the sample count of the compositing it
+ * perturbs (pass 1: the S coarse samples; the final compositing: the depth-sorted S + G set, position = sorted position).
+ * NULL, or noise_std == 0: no noise.  The forward and the backward of a step name the same stream and see the same draws. */
+typedef struct {
+  const unsigned long long *rng;
+  float noise_std;
+  uint32_t rng_stream;
+  int64_t ray_offset;
+} bn_noise;
+/* The standard normals an in-kernel noise stream hands to elements 0..n-1, as an array (tests, replay). */
+int bn_rng_normal(const unsigned long long *rng, uint32_t rng_stream, int64_t n, float *x, void *stream);
 
 /* bn_stratified_z with in-kernel uniforms (stream `rng_stream` of the state at `rng` = &state[0]).  The draw of sample s of
  * ray r is element (ray_offset + r) * S + s of the stream: a rank that holds rays [ray_offset, ray_offset + R) of a global
@@ -331,8 +345,8 @@ int bn_stratified_z_rng(const float *near, const float *far, int64_t nf_stride, 
 /* The uniforms an in-kernel stream hands to elements 0..n-1, as an array (tests, and callers that want to replay a step). */
 int bn_rng_uniform(const unsigned long long *rng, uint32_t rng_stream, int64_t n, float *u, void *stream);
 
-/* Pass-1 compositing (cal_weight on sigma [R][S], element stride sigma_stride, no noise) + bn_guided_samples_nf in one
- * launch.  Per-ray prior arrays carry an element stride (depths[:, 0] of the [R][2] table, satellite_rgb_dep.py:339).
+/* Pass-1 compositing (cal_weight on sigma [R][S], element stride sigma_stride; `noise` nullable, see bn_noise) +
+ * bn_guided_samples_nf in one launch.  Per-ray prior arrays carry an element stride (depths[:, 0] of the [R][2] table, satellite_rgb_dep.py:339).
  * Draws: arrays u [R][G] / u_target [R][G] (one row per ray), or - when u == NULL - the in-kernel streams rng_u / rng_ut
  * of `rng`.  weights [R][S] / depth [R] (nullable) receive the pass-1 weights and depth. */
 int bn_composite_guided(const float *z, const float *sigma, int64_t sigma_stride, int64_t R, int32_t S, int32_t G,
@@ -340,7 +354,7 @@ int bn_composite_guided(const float *z, const float *sigma, int64_t sigma_stride
                         const float *target_depth, int64_t td_stride, const float *target_std, int64_t ts_stride,
                         const float *u, const float *u_target, const unsigned long long *rng, uint32_t rng_u,
                         uint32_t rng_ut, int64_t ray_offset, float *z2_sorted, float *z_all, int64_t *sort_idx, float *weights,
-                        float *depth, void *stream);
+                        float *depth, const bn_noise *noise, void *stream);
 
 /* Compositing of the depth-sorted union of two field outputs without materialising it: sample s of ray r is row
  * sort_idx[r][s] of cat[out1[r] ([S1][C]), out2[r] ([S2-S1][C])] (rendering.py:263-272; sigma = channel 3).  sort_idx ==
@@ -360,14 +374,15 @@ typedef struct {
 } bn_normal_reg;
 int bn_merged_composite_forward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
                                 int32_t S2, int32_t C, int64_t R, float *alphas, float *trans, float *weights, float *depth,
-                                float *acc, float *wsum, float *var, const bn_normal_reg *nreg, float *reg_out, void *stream);
+                                float *acc, float *wsum, float *var, const bn_normal_reg *nreg, float *reg_out,
+                                const bn_noise *noise, void *stream);
 /* hs_scale != 0 (with depth [R], the forward's result): adds hs_scale (z_s - depth)^2 to d loss / d w_s - the per-sample part
  * of HardSurfaceLoss's gradient (metrics.py:263-290), see bn_ray_shade_loss. */
 int bn_merged_composite_backward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
                                  int32_t S2, int32_t C, int64_t R, const float *d_weights, const float *d_depth,
                                  const float *d_acc, const float *d_wsum, float hs_scale, const float *depth,
                                  const bn_normal_reg *nreg, float *d_out1, float *d_out2, unsigned long long *nonfinite,
-                                 void *stream);
+                                 const bn_noise *noise, void *stream);
 
 /* Ray-level shading + losses of a training step whose rays have ONE BRDF each (MultiBRDF == 0) and no per-sample
  * irradiance, forward AND backward in one launch (one thread per ray), between bn_merged_composite_forward and
@@ -406,7 +421,8 @@ int bn_lambert_tail(const float *z, const int64_t *sort_idx, const float *out1, 
                     const float *target_depth, int64_t td_stride, const float *target_weight, int64_t tw_stride,
                     const float *target_std, int64_t ts_stride, float rgb_padding, float lambda_rgb, float lambda_ds,
                     int32_t usealldepth, float *ray_loss, float *loss_acc, int32_t loss_slots, float *rgb,
-                    float *weights, float *depth, float *d_out1, float *d_out2, unsigned long long *nonfinite, void *stream);
+                    float *weights, float *depth, float *d_out1, float *d_out2, unsigned long long *nonfinite,
+                    const bn_noise *noise, void *stream);
 
 /* Folding of the linear feats layer into the heads' first layers (bn_field_desc.fold_feats) and the chain rule back, as
  * two launches of exact-fp32 MFMA tiles:

@@ -54,6 +54,25 @@ def test_in_kernel_draws_are_uniform_and_step_dependent():
     assert torch.equal(Fn.rng_uniform(st, 1, n), u)                       # a pure function of (seed, step, stream, index)
 
 
+def test_in_kernel_normal_draws_are_standard_normal():
+    """bn_rng_normal (the --noise_std draws of the launch-lean step): Box-Muller on the Philox pairs of a stream."""
+    from brdf_nerf_amd import functions as Fn
+    st = Fn.new_step_state(DEV, 4321, 5e-4)
+    n = 1 << 20
+    x = Fn.rng_normal(st, 4, n).double()
+    assert torch.isfinite(x).all()
+    assert abs(float(x.mean())) < 4e-3 and abs(float(x.var()) - 1.0) < 6e-3
+    assert abs(float((x ** 3).mean())) < 2e-2 and abs(float((x ** 4).mean()) - 3.0) < 6e-2
+    # tails: P(|x| > 2) = 0.0455, P(|x| > 3) = 0.0027
+    assert abs(float((x.abs() > 2).double().mean()) - 0.0455) < 1.5e-3 and abs(float((x.abs() > 3).double().mean()) - 0.0027) < 4e-4
+    assert abs(float((x[1:] * x[:-1]).mean())) < 5e-3                      # the two normals of a Philox block, and neighbours
+    y = Fn.rng_normal(st, 5, n).double()
+    assert abs(float((x * y).mean())) < 5e-3                               # streams
+    u = Fn.rng_uniform(st, 4, n).double()
+    assert abs(float((x * (u - 0.5)).mean())) < 5e-3
+    assert torch.equal(Fn.rng_normal(st, 4, n).double(), x)                # a pure function of (seed, step, stream, index)
+
+
 def test_stratified_z_rng_is_stratified_z_of_the_streams_draws():
     from brdf_nerf_amd import functions as Fn
     g = torch.Generator().manual_seed(0)
@@ -604,6 +623,69 @@ def test_lean_step_matches_general_step_on_the_same_draws(name, dtype):
         assert len(tb._graphs) == 1, "the lean step was not captured into a HIP graph"
         diag(f"lean vs general step {name} {dtype}: worst flat-gradient difference over 6 steps {worst_g:.2e} of the largest entry; "
              f"graphs {len(tb._graphs)}")
+    finally:
+        brdf_nerf_amd.set_deterministic(prev)
+
+
+@pytest.mark.parametrize("name,gsam", [("lambert", False), ("rpv111_nlr", False), ("lambert", True), ("rpv111_nan", True)])
+def test_lean_step_with_noise_std_matches_general_step(name, gsam):
+    """--noise_std > 0 (models/spsbrdfnerf.py:57-59) on the launch-lean step: in-kernel normal draws in the pass-1 compositing
+    and in the compositing of the merged set (forward and backward see the same draws), against the general step fed with the
+    streams' normals as arrays (torch.randn at the same two places); eager, then replayed from a HIP graph."""
+    import brdf_nerf_amd
+    from test_gpu_parity import build_model, make_args, Replay, diag
+    from brdf_nerf_amd import functions as Fn
+    from brdf_nerf_amd.trainer import FusedTrainer
+    cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16, **_lean_cfgs()[name])
+    args = make_args(cfg, "fp32")
+    args.noise_std = 0.7
+    R, S, G = 96, 16, 16
+    g = torch.Generator().manual_seed(5)
+    rays = _sat_rays(R, g).to(DEV)
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    valid = (torch.rand(R, generator=g) < 0.6).float().to(DEV)
+    depths = torch.stack([0.8 + 0.4 * torch.rand(R, generator=g), torch.rand(R, generator=g)], -1).to(DEV)
+    dstd = (0.03 * torch.rand(R, generator=g)).to(DEV)
+    brdf = name != "lambert"
+    flags = dict(apply_brdf=brdf, apply_theta=brdf, cos_irra_on=brdf, gsam_only=gsam)
+    prev = brdf_nerf_amd.set_deterministic(True)
+    try:
+        torch.manual_seed(13)
+        ma, mb = build_model(cfg, 23, "fp32"), build_model(cfg, 23, "fp32")
+        ta = FusedTrainer(ma, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+        tb = FusedTrainer(mb, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+        ta.lean = False
+        tb.graph_after = 1
+        tb.keep_grads = True
+        worst = 0.0
+        for step in range(4):
+            tb.flat_param.copy_(ta.flat_param)
+            tb.exp_avg.copy_(ta.exp_avg)
+            tb.exp_avg_sq.copy_(ta.exp_avg_sq)
+            S2 = G if gsam else S + G
+            draws = [Fn.rng_uniform(tb.state, 1, R * S).view(R, S), Fn.rng_normal(tb.state, 4, R * S).view(R, S),
+                     Fn.rng_uniform(tb.state, 2, R * G).view(R, G), Fn.rng_uniform(tb.state, 3, R * G).view(R, G),
+                     Fn.rng_normal(tb.state, 5, R * S2).view(R, S2)]
+            with Replay(draws) as rp:
+                la, rgb_a = ta.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+                assert rp.draws == []
+            lb, rgb_b = tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+            la, lb = float(la), float(lb)
+            assert abs(la - lb) <= 2e-5 * abs(la) + 1e-7, (name, gsam, step, la, lb)
+            assert float((rgb_a - rgb_b).abs().max()) <= 2e-5, (name, gsam, step)
+            ga, gb = ta.flat_grad, tb.flat_grad
+            e = float((ga - gb).abs().max()) / float(ga.abs().max())
+            worst = max(worst, e)
+            # (sigma + noise * noise_std is one fma in the kernels, a product and a sum in the general step's torch statement: a
+            # last-bit difference in front of the exponential; measured 7e-5 with the BRDF heads, 5e-6 without)
+            assert e <= (5e-4 if brdf else 5e-5), (name, gsam, step, e)
+        # the noise matters: the same step without it differs
+        args.noise_std = 0.0
+        l0, _ = tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+        args.noise_std = 0.7
+        assert abs(float(l0) - lb) > 1e-4 * abs(lb)
+        assert len(tb._graphs) >= 1, "the lean step was not captured into a HIP graph"
+        diag(f"lean step with noise_std {name} gsam_only={gsam}: worst flat-gradient difference over 4 steps {worst:.2e} of the largest entry")
     finally:
         brdf_nerf_amd.set_deterministic(prev)
 
