@@ -62,7 +62,8 @@ BN_SHADE_LAMBERT, BN_SHADE_RPV, BN_SHADE_HAPKE, BN_SHADE_MICROFACET = 0, 1, 2, 3
 
 class NormalReg(C.Structure):         # bn_normal_reg
     _fields_ = [("rays_d", fptr), ("rd_stride", C.c_int64), ("ch_an", C.c_int32), ("ch_lr", C.c_int32),
-                ("lambda_an", C.c_float), ("lambda_lr", C.c_float)]
+                ("lambda_an", C.c_float), ("lambda_lr", C.c_float), ("lambda_spv", C.c_float), ("spv_ch_an", C.c_int32),
+                ("spv_ch_lr", C.c_int32), ("spv_ray", fptr), ("spv_tot", fptr)]
 
 
 class Noise(C.Structure):             # bn_noise
@@ -130,6 +131,7 @@ _SIGS = {
     "bn_stratified_z_rng": (C.c_int, [fptr, fptr, C.c_int64, fptr, C.c_uint32, C.c_int64, C.c_int64, C.c_int32, fptr, fptr]),
     "bn_rng_uniform": (C.c_int, [fptr, C.c_uint32, C.c_int64, fptr, fptr]),
     "bn_rng_normal": (C.c_int, [fptr, C.c_uint32, C.c_int64, fptr, fptr]),
+    "bn_normal_spv_reduce": (C.c_int, [fptr, C.c_int64, C.c_int32, C.c_float, fptr, fptr, fptr, fptr]),
     "bn_composite_guided": (C.c_int, [fptr, fptr, C.c_int64, C.c_int64, C.c_int32, C.c_int32, fptr, C.c_float, fptr, C.c_int64,
                                       fptr, C.c_int64, fptr, C.c_int64, fptr, fptr, fptr, C.c_uint32, C.c_uint32, C.c_int64, fptr, fptr,
                                       fptr, fptr, fptr, fptr, fptr]),

@@ -939,6 +939,21 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
       reg = wave_sum(reg);
       if (lane == 0) A.reg_out[ray] = reg;
     }
+    if (MODE == 0 && A.nreg.lambda_spv != 0.f && A.nreg.spv_ray) {     // NormalLoss 'an_lr': this ray's (sum w, sum |n_an - n_lr|)
+      const int ca = A.nreg.spv_ch_an, cl = A.nreg.spv_ch_lr;
+      float sw = 0.f, sd = 0.f;
+#pragma unroll
+      for (int j = 0; j < BN_MAX_CPL; ++j) {
+        const int s = lane * cpl + j;
+        if (j < cpl && s < S) {
+          const float *row = rowp(roff[j]);
+          sw += w[j];
+          sd += fabsf(row[ca] - row[cl]) + fabsf(row[ca + 1] - row[cl + 1]) + fabsf(row[ca + 2] - row[cl + 2]);
+        }
+      }
+      sw = wave_sum(sw); sd = wave_sum(sd);
+      if (lane == 0) { A.nreg.spv_ray[ray * 2] = sw; A.nreg.spv_ray[ray * 2 + 1] = sd; }
+    }
     float var = 0.f;
     if (MODE == 1 || A.var) {
 #pragma unroll
@@ -995,6 +1010,8 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
   const bool nreg_on = MODE == 2 && A.nreg.rays_d != nullptr;
   float nvx = 0.f, nvy = 0.f, nvz = 0.f;
   if (nreg_on) { const float *rd = A.nreg.rays_d + ray * A.nreg.rd_stride; nvx = -rd[0]; nvy = -rd[1]; nvz = -rd[2]; }
+  const bool spv_on = MODE == 2 && A.nreg.lambda_spv != 0.f && A.nreg.spv_tot != nullptr;
+  const float spv_w = spv_on ? A.nreg.spv_tot[0] : 0.f, spv_n = spv_on ? A.nreg.spv_tot[1] : 0.f;
   float g[BN_MAX_CPL], gw = 0.f;
 #pragma unroll
   for (int j = 0; j < BN_MAX_CPL; ++j) {
@@ -1004,6 +1021,7 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
       float gg = dd * zv[j] + dws;
       if (MODE == 2 && A.d_weights) gg += A.d_weights[ray * S + s];
       if (MODE == 2 && hs != 0.f) { const float dz = zv[j] - hs_depth; gg += hs * (dz * dz); }
+      if (MODE == 2 && spv_on) gg += spv_w;
       if (MODE == 2 && nreg_on) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -1058,6 +1076,11 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
             if (A.nreg.ch_an >= 0 && ca >= 0 && ca < 3) v += nr_g[0] * (ca == 0 ? nvx : ca == 1 ? nvy : nvz);
             if (A.nreg.ch_lr >= 0 && cl >= 0 && cl < 3) v += nr_g[1] * (cl == 0 ? nvx : cl == 1 ? nvy : nvz);
           }
+          if (spv_on) {     // d |n_an - n_lr| / d n: the sign of the difference (0 at 0, as torch's L1), opposite on the two fields
+            const int ka = c - A.nreg.spv_ch_an, kl = c - A.nreg.spv_ch_lr;
+            if (ka >= 0 && ka < 3) { const float d = chan(j, c) - chan(j, A.nreg.spv_ch_lr + ka); v += spv_n * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)); }
+            if (kl >= 0 && kl < 3) { const float d = chan(j, A.nreg.spv_ch_an + kl) - chan(j, c); v -= spv_n * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)); }
+          }
           if (A.nonfinite) {
             if (isnan(v)) { ++n_nan; v = 0.f; }
             else if (isinf(v)) { ++n_inf; v = 0.f; }
@@ -1073,6 +1096,38 @@ template <int MODE, bool C4> __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) 
     if (lane == 0 && n_nan) atomicAdd(A.nonfinite, (unsigned long long)n_nan);
     if (lane == 0 && n_inf) atomicAdd(A.nonfinite + 1, (unsigned long long)n_inf);
   }
+}
+
+// NormalLoss 'an_lr' (metrics.py:218-261): the two batch-wide means from the rays' sums, added up in a fixed order (one workgroup:
+// thread t takes rays t, t + 1024, ... in order, then a binary tree over the threads) - bitwise reproducible like the rest of the step.
+__global__ __launch_bounds__(1024) void normal_spv_reduce_kernel(const float *spv_ray, int64_t R, int S, float lambda, float *tot,
+                                                                 float *ray_loss, float *loss_acc) {
+  __shared__ float sw[1024], sd[1024];
+  float a = 0.f, b = 0.f;
+  for (int64_t r = threadIdx.x; r < R; r += 1024) { a += spv_ray[r * 2]; b += spv_ray[r * 2 + 1]; }
+  sw[threadIdx.x] = a; sd[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 512; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) { sw[threadIdx.x] += sw[threadIdx.x + o]; sd[threadIdx.x] += sd[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float n = (float)R * (float)S;
+    const float mean_w = sw[0] / n, mean_d = sd[0] / (3.f * n);
+    const float term = lambda * mean_w * mean_d;
+    tot[0] = lambda * mean_d / n;              // d loss / d w_s
+    tot[1] = lambda * mean_w / (3.f * n);      // d loss / d n_an[c] per unit sign(n_an - n_lr)
+    tot[2] = term; tot[3] = 0.f;
+    if (ray_loss) ray_loss[0] += term;
+    if (loss_acc) atomicAdd(loss_acc, term);
+  }
+}
+extern "C" int bn_normal_spv_reduce(const float *spv_ray, int64_t R, int32_t S, float lambda_spv, float *spv_tot, float *ray_loss,
+                                    float *loss_acc, void *stream) {
+  BN_REQUIRE(spv_ray && spv_tot && R > 0 && S > 0, "normal_spv_reduce: bad arguments");
+  normal_spv_reduce_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(spv_ray, R, S, lambda_spv, spv_tot, ray_loss, loss_acc);
+  BN_LAUNCH_CHECK("normal_spv_reduce");
+  return 0;
 }
 
 static int merged_check(const MergedArgs &a, const char *what) {
@@ -1094,11 +1149,13 @@ extern "C" int bn_merged_composite_forward(const float *z, const int64_t *sort_i
   a.noise = make_noise(noise);
   a.z = z; a.idx = sort_idx; a.out1 = out1; a.out2 = out2; a.S1 = S1; a.S2 = S2; a.C = C; a.R = R;
   a.alphas = alphas; a.trans = trans; a.weights = weights; a.depth = depth; a.acc = acc; a.wsum = wsum; a.var = var;
-  if (nreg && nreg->rays_d) {
+  if (nreg && nreg->lambda_spv != 0.f)
+    BN_REQUIRE(nreg->spv_ray && nreg->spv_ch_an >= 4 && nreg->spv_ch_an + 3 <= C && nreg->spv_ch_lr >= 4 && nreg->spv_ch_lr + 3 <= C,
+               "merged_composite_forward: bad NormalLoss arguments (channels %d, %d)", nreg->spv_ch_an, nreg->spv_ch_lr);
+  if (nreg && nreg->rays_d)
     BN_REQUIRE(reg_out && (nreg->ch_an < 0 || (nreg->ch_an >= 4 && nreg->ch_an + 3 <= C)) && (nreg->ch_lr < 0 || (nreg->ch_lr >= 4 && nreg->ch_lr + 3 <= C)),
                "merged_composite_forward: bad normal-regulariser channels (%d, %d)", nreg->ch_an, nreg->ch_lr);
-    a.nreg = *nreg; a.reg_out = reg_out;
-  }
+  if (nreg && (nreg->rays_d || nreg->lambda_spv != 0.f)) { a.nreg = *nreg; a.reg_out = reg_out; }
   if (int e = merged_check(a, "merged_composite_forward")) return e;
   BnProfScope prof_(BN_K_COMPOSITE_FWD, (hipStream_t)stream);
   if (merged_c4(a)) merged_composite_kernel<0, true><<<MERGED_GRID(R)>>>(a);
@@ -1117,11 +1174,13 @@ extern "C" int bn_merged_composite_backward(const float *z, const int64_t *sort_
   a.z = z; a.idx = sort_idx; a.out1 = out1; a.out2 = out2; a.S1 = S1; a.S2 = S2; a.C = C; a.R = R;
   a.d_weights = d_weights; a.d_depth = d_depth; a.d_acc = d_acc; a.d_wsum = d_wsum; a.d_out1 = d_out1; a.d_out2 = d_out2;
   a.nonfinite = nonfinite; a.hs_scale = hs_scale; a.depth_in = depth;
-  if (nreg && nreg->rays_d) {
+  if (nreg && nreg->lambda_spv != 0.f)
+    BN_REQUIRE(nreg->spv_tot && nreg->spv_ch_an >= 4 && nreg->spv_ch_an + 3 <= C && nreg->spv_ch_lr >= 4 && nreg->spv_ch_lr + 3 <= C,
+               "merged_composite_backward: bad NormalLoss arguments (channels %d, %d)", nreg->spv_ch_an, nreg->spv_ch_lr);
+  if (nreg && nreg->rays_d)
     BN_REQUIRE((nreg->ch_an < 0 || (nreg->ch_an >= 4 && nreg->ch_an + 3 <= C)) && (nreg->ch_lr < 0 || (nreg->ch_lr >= 4 && nreg->ch_lr + 3 <= C)),
                "merged_composite_backward: bad normal-regulariser channels (%d, %d)", nreg->ch_an, nreg->ch_lr);
-    a.nreg = *nreg;
-  }
+  if (nreg && (nreg->rays_d || nreg->lambda_spv != 0.f)) a.nreg = *nreg;
   if (int e = merged_check(a, "merged_composite_backward")) return e;
   BN_REQUIRE(hs_scale == 0.f || depth, "merged_composite_backward: hs_scale needs the forward's depth");
   BN_REQUIRE(d_out1 && (S1 == S2 || d_out2), "merged_composite_backward: null gradient buffer");

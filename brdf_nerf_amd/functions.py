@@ -574,19 +574,32 @@ def composite_guided(z, out1, G, near_far, d_range, use_target=None, target_dept
     return (z2, z_all, idx, w1, d1) if want_pass1 else (z2, z_all, idx)
 
 
-def normal_reg(rays_d, ch_an, ch_lr, lambda_an, lambda_lr):
+def normal_reg(rays_d, ch_an, ch_lr, lambda_an, lambda_lr, lambda_spv=0.0, spv_ray=None, spv_tot=None):
     """bn_normal_reg: NormalRegLoss (metrics.py:179-216) inside the merged-set compositing; rays_d (R,3) view with unit inner
-    stride.  None when no field is regularised."""
+    stride - and / or NormalLoss 'an_lr' (metrics.py:218-261) between the two normal fields at channels ch_an / ch_lr (lambda_spv
+    != 0, with spv_ray [R][2] and spv_tot [4]: see normal_spv_reduce).  None when neither is on."""
     on_an, on_lr = ch_an >= 0 and lambda_an > 0, ch_lr >= 0 and lambda_lr > 0
-    if not (on_an or on_lr):
+    on_spv = bool(lambda_spv) and ch_an >= 0 and ch_lr >= 0
+    if not (on_an or on_lr or on_spv):
         return None
-    assert rays_d.is_cuda and rays_d.dtype == torch.float32 and rays_d.dim() == 2 and rays_d.stride(1) == 1
     nr = L.NormalReg()
-    nr.rays_d, nr.rd_stride = rays_d.data_ptr(), rays_d.stride(0)
+    if on_an or on_lr:
+        assert rays_d.is_cuda and rays_d.dtype == torch.float32 and rays_d.dim() == 2 and rays_d.stride(1) == 1
+        nr.rays_d, nr.rd_stride = rays_d.data_ptr(), rays_d.stride(0)
     nr.ch_an, nr.ch_lr = (ch_an if on_an else -1), (ch_lr if on_lr else -1)
     nr.lambda_an, nr.lambda_lr = float(lambda_an), float(lambda_lr)
-    nr._keep = rays_d
+    if on_spv:
+        nr.lambda_spv, nr.spv_ch_an, nr.spv_ch_lr = float(lambda_spv), int(ch_an), int(ch_lr)
+        nr.spv_ray, nr.spv_tot = spv_ray.data_ptr(), spv_tot.data_ptr()
+    nr._keep = (rays_d, spv_ray, spv_tot)
     return nr
+
+
+def normal_spv_reduce(nreg, R, S, ray_loss=None, loss_acc=None):
+    """The two batch-wide means of NormalLoss 'an_lr' from the rays' sums (fixed order), the loss term added to the step's loss."""
+    _, spv_ray, spv_tot = nreg._keep
+    L.check(L.lib().bn_normal_spv_reduce(_p(spv_ray), int(R), int(S), float(nreg.lambda_spv), _p(spv_tot), _p(ray_loss), _p(loss_acc),
+                                         _stream()), "bn_normal_spv_reduce")
 
 
 def merged_composite_forward(z_all, idx, out1, out2, bufs=None, want=("weights", "depth", "acc"), nreg=None, noise=None):
@@ -598,12 +611,12 @@ def merged_composite_forward(z_all, idx, out1, out2, bufs=None, want=("weights",
     dev = z_all.device
     b = bufs if bufs is not None else {}
     shapes = dict(alphas=(R, S2), trans=(R, S2), weights=(R, S2), depth=(R,), acc=(R, Cc), wsum=(R,), var=(R,), reg=(R,))
-    want = tuple(want) + (("reg",) if (nreg is not None and "reg" not in want) else ())
+    want = tuple(want) + (("reg",) if (nreg is not None and nreg.rays_d and "reg" not in want) else ())
     o = {k: (b[k] if k in b else torch.empty(shapes[k], dtype=torch.float32, device=dev)) for k in want}
     g = lambda k: _p(o.get(k))
     L.check(L.lib().bn_merged_composite_forward(_p(z_all), _p(idx), _p(out1), _p(out2), S1, S2, Cc, R, g("alphas"), g("trans"),
                                                 g("weights"), g("depth"), g("acc"), g("wsum"), g("var"),
-                                                None if nreg is None else C.byref(nreg), g("reg") if nreg is not None else None,
+                                                None if nreg is None else C.byref(nreg), g("reg") if (nreg is not None and nreg.rays_d) else None,
                                                 _nz(noise), _stream()),
             "bn_merged_composite_forward")
     return o

@@ -148,8 +148,8 @@ class FusedTrainer:
         dev = rays.device
         spec = model.spec(apply_brdf, apply_theta, self.nr_lr, self.nr_an, beta=False)   # (field.py spec(): the loss never reads beta)
         reg0 = self.reg if regularisers else {}
-        # (a loss that reads per-sample channels of the merged set beyond NormalRegLoss - MultiBRDF, NormalLoss - keeps the general path)
-        per_sample0 = (bool(model.MultiBRDF) and apply_brdf) or abs(reg0.get("nr_spv", 0)) > 1e-5
+        # (a loss that reads per-sample channels of the merged set beyond NormalRegLoss / NormalLoss - MultiBRDF - keeps the general path)
+        per_sample0 = bool(model.MultiBRDF) and apply_brdf
         if (self.lean and not self.strict_rng and self.reuse_coarse and not per_sample0
                 and not (getattr(model, "sun_v", "none") == "analystic" and apply_brdf)
                 and rays.dtype == torch.float32 and rays.is_contiguous() and rays.shape[1] >= 8 and S + G <= 512):
@@ -369,7 +369,7 @@ class FusedTrainer:
                    nf.data_ptr(), use_ds, tuple(active), float(self.ds_lambda), float(self.lambda_rgb), bool(self.usealldepth),
                    L.deterministic(), int(self.ray_offset), bool(self.keep_grads), bool(self.merge_passes), bool(apply_brdf),
                    bool(cos_irra_on), float(reg.get("hs", 0)), bool(self.sanitize_grads), float(reg.get("nr_an", 0)),
-                   float(reg.get("nr_lr", 0)), bool(gsam_only), float(args.noise_std))
+                   float(reg.get("nr_lr", 0)), bool(gsam_only), float(args.noise_std), float(reg.get("nr_spv", 0)))
             ent = self._graphs.get(sig)
             if ent is not None:
                 self._graphs.move_to_end(sig)
@@ -506,8 +506,12 @@ class FusedTrainer:
             det = L.deterministic()
             ray_loss = self._buf("ray_loss", (R,)) if det else None
             # NormalRegLoss on the per-sample normals (metrics.py:179-216): its value and gradient come from the compositing kernels
+            # NormalLoss between the two normal fields (nr_spv_type 1, main.py:297-303): two batch-wide means - the rays' sums come
+            # from the forward compositing, a one-workgroup reduce adds them up in fixed order, the backward compositing reads them
+            spv = float(reg.get("nr_spv", 0)) if (spec.normal_an and spec.normal_lr and abs(reg.get("nr_spv", 0)) > 1e-5) else 0.0
             nreg = Fn.normal_reg(rays[:, 3:6], spec.ch_normal_an if spec.normal_an else -1, spec.ch_normal_lr if spec.normal_lr else -1,
-                                 float(reg.get("nr_an", 0)), float(reg.get("nr_lr", 0)))
+                                 float(reg.get("nr_an", 0)), float(reg.get("nr_lr", 0)), lambda_spv=spv,
+                                 spv_ray=self._buf("spv_ray", (R, 2)) if spv else None, spv_tot=self._buf("spv_tot", (4,)) if spv else None)
             with torch.no_grad():
                 o = Fn.merged_composite_forward(z_all, idx, out1v, out2v,
                                                 {k: self._buf("m_" + k, sh) for k, sh in (("depth", (R,)), ("acc", (R, C)),
@@ -522,6 +526,8 @@ class FusedTrainer:
                                       loss_acc=None if det else Fn.state_loss_partials(st),
                                       nonfinite=self._nonfinite if self.sanitize_grads else None, extra_loss=o.get("reg"))
                 rgb = g["rgb"]
+                if spv:
+                    Fn.normal_spv_reduce(nreg, R, z_all.shape[1], ray_loss=ray_loss, loss_acc=None if det else Fn.state_loss_partials(st))
                 Fn.merged_composite_backward(z_all, idx, out1v, out2v, None, g["d_depth"], g["d_acc"], d1o, d2o, d_wsum=g["d_wsum"],
                                              nonfinite=self._nonfinite if self.sanitize_grads else None, hs_scale=hs / R if hs > 0 else 0.0,
                                              depth=o["depth"], nreg=nreg, noise=nz2)

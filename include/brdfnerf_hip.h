@@ -371,7 +371,18 @@ typedef struct {
   int64_t rd_stride;
   int32_t ch_an, ch_lr;
   float lambda_an, lambda_lr;
+  /* NormalLoss between the two per-sample normal fields (metrics.py:218-261, keyword 'an_lr' = --nr_spv_type 1, main.py:297-303):
+   * lambda_spv * mean(weights) * mean|n_an - n_lr| over the whole batch - two batch-wide means, so the step makes three stops:
+   * the forward writes each ray's (sum_s w_s, sum_s sum_c |n_an - n_lr|) to spv_ray [R][2]; bn_normal_spv_reduce adds them up in a
+   * fixed order into spv_tot [4] = (d loss / d w_s, d loss / d n_an per component and unit sign, the loss term, 0) and adds the
+   * term to the step's loss; the backward reads spv_tot.  lambda_spv == 0: off.  (ABI 6) */
+  float lambda_spv;
+  int32_t spv_ch_an, spv_ch_lr;
+  float *spv_ray;
+  float *spv_tot;
 } bn_normal_reg;
+int bn_normal_spv_reduce(const float *spv_ray, int64_t R, int32_t S, float lambda_spv, float *spv_tot, float *ray_loss,
+                         float *loss_acc, void *stream);
 int bn_merged_composite_forward(const float *z, const int64_t *sort_idx, const float *out1, const float *out2, int32_t S1,
                                 int32_t S2, int32_t C, int64_t R, float *alphas, float *trans, float *weights, float *depth,
                                 float *acc, float *wsum, float *var, const bn_normal_reg *nreg, float *reg_out,

@@ -741,8 +741,11 @@ def test_random_lean_step_against_general_step(seed):
     if rng.random() < 0.3:                                   # round 4: the gsam_only stage is a lean step too
         flags["gsam_only"] = True
     # round 4: --noise_std on the lean step (in-kernel normal draws); a generator of its own keeps the other draws of a seed as they were
-    noise_std = 0.4 if np.random.default_rng(91000 + seed).random() < 0.3 else 0.0
+    rng4 = np.random.default_rng(91000 + seed)
+    noise_std = 0.4 if rng4.random() < 0.3 else 0.0
     args.noise_std = noise_std
+    if cfg.normal == "analystic_learned" and rng4.random() < 0.6:      # NormalLoss between the two normal fields (nr_spv_type 1)
+        lam["nr_spv_lambda"] = 0.3
     tag = (f"fuzz-lean {seed}: noise={noise_std} F={cfg.feat} L={cfg.layers} siren={int(cfg.siren)} pe={int(cfg.mapping)} normal={cfg.normal} viewdir={cfg.input_viewdir} "
            f"heads={cfg.brdf_head_names(flags['apply_brdf'], flags['apply_theta'])} funcH={cfg.funcH} shell={cfg.shell_hapke} R={R} S={S} G={G} "
            f"prior={bool(prior)} {lam} {flags}")

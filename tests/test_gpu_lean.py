@@ -690,6 +690,64 @@ def test_lean_step_with_noise_std_matches_general_step(name, gsam):
         brdf_nerf_amd.set_deterministic(prev)
 
 
+@pytest.mark.parametrize("gsam", [False, True])
+@pytest.mark.parametrize("with_reg", [False, True])
+def test_lean_step_with_normal_loss_matches_general_step(with_reg, gsam):
+    """NormalLoss between the two per-sample normal fields (--nr_spv_lambda, nr_spv_type 1: metrics.py:218-261, main.py:297-303)
+    on the launch-lean step: the rays' sums from the forward compositing, bn_normal_spv_reduce (the two batch-wide means, fixed
+    order), the gradient in the backward compositing - against the general step's torch statement; eager, then replayed."""
+    import brdf_nerf_amd
+    from test_gpu_parity import build_model, make_args, Replay, diag
+    from brdf_nerf_amd import functions as Fn
+    from brdf_nerf_amd.trainer import FusedTrainer
+    cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16, funcM=1, funcF=1, funcH=1, normal="analystic_learned")
+    args = make_args(cfg, "fp32")
+    R, S, G = 96, 16, 16
+    g = torch.Generator().manual_seed(7)
+    rays = _sat_rays(R, g).to(DEV)
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    valid = (torch.rand(R, generator=g) < 0.6).float().to(DEV)
+    depths = torch.stack([0.8 + 0.4 * torch.rand(R, generator=g), torch.rand(R, generator=g)], -1).to(DEV)
+    dstd = (0.03 * torch.rand(R, generator=g)).to(DEV)
+    flags = dict(apply_brdf=True, apply_theta=True, cos_irra_on=True, gsam_only=gsam)
+    lam = dict(nr_spv_lambda=0.5, **(dict(hs_lambda=0.1, nr_reg_an_lambda=0.2, nr_reg_lr_lambda=0.1) if with_reg else {}))
+    prev = brdf_nerf_amd.set_deterministic(True)
+    try:
+        torch.manual_seed(17)
+        ma, mb = build_model(cfg, 29, "fp32"), build_model(cfg, 29, "fp32")
+        ta = FusedTrainer(ma, args, lr=5e-4, ds_lambda=10.0, strict_rng=False, **lam)
+        tb = FusedTrainer(mb, args, lr=5e-4, ds_lambda=10.0, strict_rng=False, **lam)
+        ta.lean = False
+        tb.graph_after = 1
+        tb.keep_grads = True
+        worst = 0.0
+        for step in range(4):
+            tb.flat_param.copy_(ta.flat_param)
+            tb.exp_avg.copy_(ta.exp_avg)
+            tb.exp_avg_sq.copy_(ta.exp_avg_sq)
+            draws = [Fn.rng_uniform(tb.state, 1, R * S).view(R, S), Fn.rng_uniform(tb.state, 2, R * G).view(R, G),
+                     Fn.rng_uniform(tb.state, 3, R * G).view(R, G)]
+            with Replay(draws) as rp:
+                la, rgb_a = ta.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+                assert rp.draws == []
+            lb, rgb_b = tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+            la, lb = float(la), float(lb)
+            assert abs(la - lb) <= 2e-5 * abs(la) + 1e-7, (with_reg, gsam, step, la, lb)
+            ga, gb = ta.flat_grad, tb.flat_grad
+            e = float((ga - gb).abs().max()) / float(ga.abs().max())
+            worst = max(worst, e)
+            assert e <= 5e-4, (with_reg, gsam, step, e)          # (analytic normals: test_lean_step_matches_general_step's bound)
+        # the term is there: the same step without it has another loss
+        tb.reg["nr_spv"] = 0.0
+        l0, _ = tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+        tb.reg["nr_spv"] = 0.5
+        assert abs(float(l0) - lb) > 1e-4 * abs(lb)
+        assert len(tb._graphs) >= 1, "the lean step was not captured into a HIP graph"
+        diag(f"lean step with NormalLoss an_lr reg={with_reg} gsam_only={gsam}: worst flat-gradient difference over 4 steps {worst:.2e} of the largest entry")
+    finally:
+        brdf_nerf_amd.set_deterministic(prev)
+
+
 @pytest.mark.parametrize("name", ["lambert", "rpv111_nan", "hapke_bct"])
 def test_lean_step_gsam_only_matches_general_step(name):
     """The gsam_only stage (main.py:201-203: pass 1 only places the guided samples, the step renders and back-propagates through
