@@ -54,7 +54,8 @@ class Points(C.Structure):
 class ShadeDesc(C.Structure):         # bn_shade_desc
     _fields_ = [(k, C.c_int32) for k in ("kind", "C", "ch_normal", "ch_p0", "ch_p1", "ch_p2", "rhoc_is_albedo", "shell",
                                          "cos_irradiance", "usealldepth")] + \
-               [(k, C.c_float) for k in ("hpk_scl", "f0", "rgb_padding", "lambda_rgb", "lambda_ds", "lambda_hs")]
+               [(k, C.c_float) for k in ("hpk_scl", "f0", "rgb_padding", "lambda_rgb", "lambda_ds", "lambda_hs")] + \
+               [("irr", fptr), ("irr_stride", C.c_int64)]
 
 
 BN_SHADE_LAMBERT, BN_SHADE_RPV, BN_SHADE_HAPKE, BN_SHADE_MICROFACET = 0, 1, 2, 3
@@ -79,7 +80,7 @@ class FoldDesc(C.Structure):          # bn_fold_desc
 
 
 BN_STATE_BYTES, BN_STATE_LOSS_OFF, BN_STATE_LOSS_SLOTS, BN_STATE_POW_OFF, BN_STATE_PART_OFF = 1024, 64, 64, 320, 512
-BN_RNG_COARSE, BN_RNG_GUIDED, BN_RNG_GUIDED_TARGET, BN_RNG_NOISE_COARSE, BN_RNG_NOISE_MERGED = 1, 2, 3, 4, 5
+BN_RNG_COARSE, BN_RNG_GUIDED, BN_RNG_GUIDED_TARGET, BN_RNG_NOISE_COARSE, BN_RNG_NOISE_MERGED, BN_RNG_SUN = 1, 2, 3, 4, 5, 6
 BN_BWD_CHAIN, BN_BWD_WGRAD_TRUNK, BN_BWD_WGRAD_HEADS, BN_BWD_SKINNY, BN_BWD_ALL = 1, 2, 4, 8, 15
 
 

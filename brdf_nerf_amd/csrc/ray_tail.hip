@@ -48,7 +48,8 @@ template <int KIND> __global__ __launch_bounds__(64) void ray_shade_loss_kernel(
   const bool has_n = q.ch_normal >= 0;
   const float sun[3] = {A.sun_d ? A.sun_d[ray * A.sd_stride] : 1.f, A.sun_d ? A.sun_d[ray * A.sd_stride + 1] : 1.f,
                         A.sun_d ? A.sun_d[ray * A.sd_stride + 2] : 1.f};
-  const float irr = (q.cos_irradiance && has_n) ? fabsf(sun[2]) : 1.f;     // upward normal: |sun_z| (spsbrdfnerf.py:260-264)
+  // upward normal: |sun_z| (spsbrdfnerf.py:260-264); else the sun pass's visibility of the ray's last sample (:354), else 1
+  const float irr = (q.cos_irradiance && has_n) ? fabsf(sun[2]) : (q.irr ? q.irr[ray * q.irr_stride] : 1.f);
   // composited albedo sum_s w (albedo (1 + 2 pad) - pad)   (:270, :275)
   D w[3], out[3];
 #pragma unroll

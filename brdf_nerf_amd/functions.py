@@ -503,14 +503,17 @@ def state_loss_partials(state):
     return state.view(torch.float32)[L.BN_STATE_PART_OFF // 4:L.BN_STATE_PART_OFF // 4 + L.BN_STATE_LOSS_SLOTS]
 
 
-def stratified_z_rng(rays, S, state, z=None, ray_offset=0):
-    """Stratified depths from rays[:, 6], rays[:, 7] with in-kernel uniforms (stream BN_RNG_COARSE of `state`)."""
-    R = rays.shape[0]
-    assert rays.is_contiguous() and rays.dtype == torch.float32 and rays.shape[1] >= 8
+def stratified_z_rng(rays, S, state, z=None, ray_offset=0, near_far=None, stream_id=None):
+    """Stratified depths from rays[:, 6], rays[:, 7] - or from near_far [R][2] - with in-kernel uniforms (stream BN_RNG_COARSE of
+    `state`, or stream_id)."""
+    src, col = (rays, 6) if near_far is None else (near_far, 0)
+    R = src.shape[0]
+    assert src.is_contiguous() and src.dtype == torch.float32 and src.shape[1] >= col + 2
     if z is None:
-        z = torch.empty(R, S, dtype=torch.float32, device=rays.device)
-    base = rays.data_ptr()
-    L.check(L.lib().bn_stratified_z_rng(C.c_void_p(base + 24), C.c_void_p(base + 28), rays.shape[1], _p(state), L.BN_RNG_COARSE,
+        z = torch.empty(R, S, dtype=torch.float32, device=src.device)
+    base = src.data_ptr() + 4 * col
+    L.check(L.lib().bn_stratified_z_rng(C.c_void_p(base), C.c_void_p(base + 4), src.shape[1], _p(state),
+                                        L.BN_RNG_COARSE if stream_id is None else int(stream_id),
                                         int(ray_offset), R, S, _p(z), _stream()), "bn_stratified_z_rng")
     return z
 

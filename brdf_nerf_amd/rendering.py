@@ -255,7 +255,7 @@ def shade_ray(model, args, spec, z_vals, weights, depth, acc, rays_d, sun_d, app
     return {"rgb": rgb.clamp(0.0, 1.0)}, kind
 
 
-def shade_desc(model, args, spec, apply_brdf, cos_irra_on, lambda_rgb=1.0, lambda_ds=0.0, lambda_hs=0.0, usealldepth=False):
+def shade_desc(model, args, spec, apply_brdf, cos_irra_on, lambda_rgb=1.0, lambda_ds=0.0, lambda_hs=0.0, usealldepth=False, irr=None):
     """bn_shade_desc of shade_ray() for this model / spec: which BRDF (the same selection as shade(), models/spsbrdfnerf.py:
     277-357) and where its inputs sit among the composited channels."""
     from . import _lib as L
@@ -285,6 +285,9 @@ def shade_desc(model, args, spec, apply_brdf, cos_irra_on, lambda_rgb=1.0, lambd
     d.shell, d.cos_irradiance, d.usealldepth = shell, int(bool(cos_irra_on)), int(bool(usealldepth))
     d.hpk_scl, d.f0 = float(getattr(args, "hpk_scl", 1.0)), float(getattr(args, "fresnel_f0", 0.04))
     d.rgb_padding, d.lambda_rgb, d.lambda_ds, d.lambda_hs = float(model.rgb_padding), float(lambda_rgb), float(lambda_ds), float(lambda_hs)
+    if irr is not None:          # per-ray irradiance of the sun pass (1-d float32 view)
+        assert irr.is_cuda and irr.dtype == torch.float32 and irr.dim() == 1
+        d.irr, d.irr_stride, d._keep = irr.data_ptr(), (irr.stride(0) if irr.shape[0] > 1 else 1), irr
     return d
 
 

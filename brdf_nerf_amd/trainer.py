@@ -150,8 +150,14 @@ class FusedTrainer:
         reg0 = self.reg if regularisers else {}
         # (a loss that reads per-sample channels of the merged set beyond NormalRegLoss / NormalLoss - MultiBRDF - keeps the general path)
         per_sample0 = bool(model.MultiBRDF) and apply_brdf
+        # the sun-visibility pass (rendering.py:244-259) is a lean step where the reference runs it (gsam_only) and a BRDF shades the
+        # ray (its rgb then reads the sun pass through ONE per-ray factor, spsbrdfnerf.py:354); per-sample irradiance of a
+        # Lambertian rgb, and the sun pass's own noise draws, keep the general path
+        sun_on = getattr(model, "sun_v", "none") == "analystic" and apply_brdf
+        sun_lean = (sun_on and gsam_only and args.noise_std == 0 and args.data == "sat"
+                    and shade_desc(model, args, spec, apply_brdf, cos_irra_on).kind != L.BN_SHADE_LAMBERT)
         if (self.lean and not self.strict_rng and self.reuse_coarse and not per_sample0
-                and not (getattr(model, "sun_v", "none") == "analystic" and apply_brdf)
+                and (not sun_on or sun_lean)
                 and rays.dtype == torch.float32 and rays.is_contiguous() and rays.shape[1] >= 8 and S + G <= 512):
             return self._step_lean(spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, apply_theta, cos_irra_on,
                                    depth_loss_on, near_far, regularisers, gsam_only)
@@ -447,9 +453,25 @@ class FusedTrainer:
                 # gsam_only stage (main.py:201-203, rendering.py:266-269): pass 1 is a sigma-only forward that only places the
                 # guided samples; the step renders, and back-propagates through, the G guided samples alone
                 sig1 = Fn.field_sigma(spec, named, packed, rays=rays, z=z, out=self._buf("sig1", (R * S,)))
-                z2, _, _ = Fn.composite_guided(z, None, G, nf, args.std_range, valid_depth if has_t else None,
-                                               depths[:, 0] if has_t else None, depth_std if has_t else None, state=st, bufs=bufs,
-                                               ray_offset=self.ray_offset, sigma=sig1.view(R, S), noise=nz1)
+                sun_on = getattr(model, "sun_v", "none") == "analystic" and apply_brdf
+                if sun_on:
+                    bufs = dict(bufs, w1=self._buf("w1", (R, S)), d1=self._buf("d1", (R,)))
+                cg = Fn.composite_guided(z, None, G, nf, args.std_range, valid_depth if has_t else None,
+                                         depths[:, 0] if has_t else None, depth_std if has_t else None, state=st, bufs=bufs,
+                                         ray_offset=self.ray_offset, sigma=sig1.view(R, S), noise=nz1, want_pass1=sun_on)
+                z2 = cg[0]
+                if sun_on:
+                    # sun-visibility pass (rendering.py:244-259), detached upstream: sigma only along the sun direction from the
+                    # pass-1 surface point, G stratified samples in [0.01 far_sun, far_sun] (in-kernel draws, stream BN_RNG_SUN);
+                    # the BRDF-shaded rgb reads the transparency in front of its LAST sample (spsbrdfnerf.py:354)
+                    d1 = cg[4]
+                    rays_d, sun_d = rays[:, 3:6], rays[:, 8:11]
+                    far_sun = sun_far(d1, rays_d, sun_d)
+                    z_sun = Fn.stratified_z_rng(None, G, st, self._buf("z_sun", (R, G)), ray_offset=self.ray_offset,
+                                                near_far=torch.cat([far_sun * 0.01, far_sun], -1).contiguous(), stream_id=L.BN_RNG_SUN)
+                    sun_rays = torch.cat([rays[:, 0:3] + rays_d * d1.unsqueeze(-1), sun_d], -1).contiguous()
+                    sig_sun = Fn.field_sigma(spec, named, packed, rays=sun_rays, z=z_sun)
+                    sun_irr = Fn.composite(z_sun, sig_sun.view(R, G), None, 0.0)[1][:, -1]
                 if self.seed_hook is not None:
                     self.seed_hook("z2", z2)
                 out2 = self._buf("out2", (R * G, C))
@@ -502,7 +524,8 @@ class FusedTrainer:
             # their gradients w.r.t. those sums (bn_ray_shade_loss), and the composite backward
             hs = float(reg.get("hs", 0))
             desc = shade_desc(model, args, spec, apply_brdf, cos_irra_on, self.lambda_rgb, self.ds_lambda if use_ds else 0.0,
-                              hs, self.usealldepth)
+                              hs, self.usealldepth,
+                              irr=sun_irr if (gsam_only and getattr(model, "sun_v", "none") == "analystic" and apply_brdf) else None)
             det = L.deterministic()
             ray_loss = self._buf("ray_loss", (R,)) if det else None
             # NormalRegLoss on the per-sample normals (metrics.py:179-216): its value and gradient come from the compositing kernels

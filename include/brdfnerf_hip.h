@@ -321,7 +321,7 @@ int bn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
 #define BN_STATE_PART_OFF 512
 #define BN_ADAM_MAX_GROUPS 4
 /* in-kernel draw streams of one step */
-enum { BN_RNG_COARSE = 1, BN_RNG_GUIDED = 2, BN_RNG_GUIDED_TARGET = 3, BN_RNG_NOISE_COARSE = 4, BN_RNG_NOISE_MERGED = 5 };
+enum { BN_RNG_COARSE = 1, BN_RNG_GUIDED = 2, BN_RNG_GUIDED_TARGET = 3, BN_RNG_NOISE_COARSE = 4, BN_RNG_NOISE_MERGED = 5, BN_RNG_SUN = 6 };
 
 /* --noise_std (models/spsbrdfnerf.py:57-59: alphas = 1 - exp(-deltas * relu(sigmas + randn * noise_std)), main.py:246) with
  * in-kernel draws (ABI 6): a standard normal per (ray, sample position) from stream `rng_stream` of the state at `rng`
@@ -413,6 +413,11 @@ typedef struct {
   int32_t kind, C, ch_normal, ch_p0, ch_p1, ch_p2;
   int32_t rhoc_is_albedo, shell, cos_irradiance, usealldepth;
   float hpk_scl, f0, rgb_padding, lambda_rgb, lambda_ds, lambda_hs;
+  /* ABI 6: per-ray irradiance (nullable; element stride irr_stride) - the sun visibility of the ray's LAST sample from the
+   * sun pass (--sun_v analystic, rendering.py:244-259, models/spsbrdfnerf.py:354), a constant of the step; the cosine term
+   * (cos_irradiance) wins when both are given, as upstream (:260-266). */
+  const float *irr;
+  int64_t irr_stride;
 } bn_shade_desc;
 int bn_ray_shade_loss(const bn_shade_desc *desc, const float *acc, const float *wsum, const float *depth, const float *var,
                       const float *rays_d, int64_t rd_stride, const float *sun_d, int64_t sd_stride, const float *rgbs,

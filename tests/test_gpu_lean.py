@@ -748,6 +748,67 @@ def test_lean_step_with_normal_loss_matches_general_step(with_reg, gsam):
         brdf_nerf_amd.set_deterministic(prev)
 
 
+@pytest.mark.parametrize("name", ["rpv111_nan", "hapke_bct"])
+def test_lean_step_sun_visibility_pass_matches_general_step(name):
+    """--sun_v analystic (rendering.py:244-259; the reference runs it in the gsam_only stage) on the launch-lean step: the
+    sigma-only pass along the sun direction with in-kernel draws (stream BN_RNG_SUN), its transparency in front of the last sample as
+    the ray's irradiance in bn_ray_shade_loss (spsbrdfnerf.py:354) - against the general step fed with the streams' draws."""
+    import brdf_nerf_amd
+    from test_gpu_parity import build_model, make_args, Replay, diag
+    from brdf_nerf_amd import functions as Fn
+    from brdf_nerf_amd.trainer import FusedTrainer
+    cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16, sun_v="analystic", **_lean_cfgs()[name])
+    args = make_args(cfg, "fp32")
+    R, S, G = 96, 16, 16
+    g = torch.Generator().manual_seed(9)
+    rays = _sat_rays(R, g).to(DEV)
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    valid = (torch.rand(R, generator=g) < 0.6).float().to(DEV)
+    depths = torch.stack([0.8 + 0.4 * torch.rand(R, generator=g), torch.rand(R, generator=g)], -1).to(DEV)
+    dstd = (0.03 * torch.rand(R, generator=g)).to(DEV)
+    flags = dict(apply_brdf=True, apply_theta=True, cos_irra_on=False, gsam_only=True)
+    prev = brdf_nerf_amd.set_deterministic(True)
+    try:
+        torch.manual_seed(19)
+        ma, mb = build_model(cfg, 31, "fp32"), build_model(cfg, 31, "fp32")
+        ta = FusedTrainer(ma, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+        tb = FusedTrainer(mb, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+        ta.lean = False
+        tb.graph_after = 1
+        tb.keep_grads = True
+        worst = 0.0
+        for step in range(4):
+            tb.flat_param.copy_(ta.flat_param)
+            tb.exp_avg.copy_(ta.exp_avg)
+            tb.exp_avg_sq.copy_(ta.exp_avg_sq)
+            # the general step's order: z, the sun pass's depths and its (unused: noise_std = 0) normals, u, u_target
+            draws = [Fn.rng_uniform(tb.state, 1, R * S).view(R, S), Fn.rng_uniform(tb.state, 6, R * G).view(R, G),
+                     torch.zeros(R, G, device=DEV), Fn.rng_uniform(tb.state, 2, R * G).view(R, G), Fn.rng_uniform(tb.state, 3, R * G).view(R, G)]
+            with Replay(draws) as rp:
+                la, rgb_a = ta.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+                assert rp.draws == []
+            lb, rgb_b = tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+            la, lb = float(la), float(lb)
+            assert abs(la - lb) <= 2e-5 * abs(la) + 1e-7, (name, step, la, lb)
+            assert float((rgb_a - rgb_b).abs().max()) <= 2e-5, (name, step)
+            ga, gb = ta.flat_grad, tb.flat_grad
+            e = float((ga - gb).abs().max()) / float(ga.abs().max())
+            worst = max(worst, e)
+            assert e <= 5e-4, (name, step, e)
+        assert len(tb._graphs) >= 1, "the lean step was not captured into a HIP graph"
+        # the sun pass matters: without it the rgb differs
+        rgb_sun = rgb_b.clone()                 # (the step returns its persistent buffer)
+        mb.sun_v = "none"
+        _, rgb0 = tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+        mb.sun_v = "analystic"
+        assert float((rgb0 - rgb_sun).abs().max()) > 1e-3
+        with pytest.raises(NotImplementedError):
+            tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **dict(flags, gsam_only=False))
+        diag(f"lean step with the sun pass {name}: worst flat-gradient difference over 4 steps {worst:.2e} of the largest entry")
+    finally:
+        brdf_nerf_amd.set_deterministic(prev)
+
+
 @pytest.mark.parametrize("name", ["lambert", "rpv111_nan", "hapke_bct"])
 def test_lean_step_gsam_only_matches_general_step(name):
     """The gsam_only stage (main.py:201-203: pass 1 only places the guided samples, the step renders and back-propagates through
