@@ -50,6 +50,7 @@ class FusedTrainer:
         self.lean = True
         self.merge_passes = True        # one output array / stash / backward for both passes (False: two backward launch sets)
         self.overlap_allreduce = True   # world > 1: all-reduce the trunk's gradient while the rest of the backward still runs
+        self._row_ray = {}              # MultiBRDF lean step: ray index of every stored sample row
         self.ray_offset = 0             # index of this rank's first ray in the global batch: in-kernel draws are taken per GLOBAL ray
         self.keep_grads = False         # True: the optimiser launch leaves the step's gradient in flat_grad (tests, diagnostics)
         self.seed_hook = None           # callable(name, tensor): sees / may overwrite "z2" (guided depths) and "d_all" (the gradient rows the
@@ -149,7 +150,11 @@ class FusedTrainer:
         spec = model.spec(apply_brdf, apply_theta, self.nr_lr, self.nr_an, beta=False)   # (field.py spec(): the loss never reads beta)
         reg0 = self.reg if regularisers else {}
         # (a loss that reads per-sample channels of the merged set beyond NormalRegLoss / NormalLoss - MultiBRDF - keeps the general path)
-        per_sample0 = bool(model.MultiBRDF) and apply_brdf
+        # --MultiBRDF (one BRDF per sample, spsbrdfnerf.py:289-307,350-352) is a lean step when nothing else reads per-sample
+        # channels: no regulariser, no sun pass (its irradiance is per sample there) - see _lean_body
+        multi = bool(model.MultiBRDF) and apply_brdf
+        per_sample0 = multi and (any(abs(float(v)) > 0 for v in reg0.values()) or getattr(model, "sun_v", "none") == "analystic"
+                                 or shade_desc(model, args, spec, apply_brdf, cos_irra_on).kind == L.BN_SHADE_LAMBERT)
         # the sun-visibility pass (rendering.py:244-259) is a lean step where the reference runs it (gsam_only) and a BRDF shades the
         # ray (its rgb then reads the sun pass through ONE per-ray factor, spsbrdfnerf.py:354); per-sample irradiance of a
         # Lambertian rgb, and the sun pass's own noise draws, keep the general path
@@ -507,7 +512,58 @@ class FusedTrainer:
                 d_all = self._buf("d_all", (n_all, C))
                 d1o, d2o = d_all[:R * S].view(R, S, C), d_all[R * S:].view(R, G, C)
         loss = None
-        if lambertian:
+        if bool(model.MultiBRDF) and apply_brdf and not lambertian:
+            # One BRDF per sample: the BRDF is a pointwise function of a sample's field outputs, so it is evaluated on the rows as
+            # they are STORED (pass-1 block, guided block: the merged set is never materialised) and its padded value takes the
+            # place of the albedo in a 4-channel copy [bp_r, bp_g, bp_b, sigma]; the Lambertian tail kernel (compositing through the
+            # sort index + SNerfLoss + DepthLoss + composite backward, padding 0) runs on that copy, and autograd through the BRDF
+            # kernels turns its gradient rows into those of the field outputs.  ~20 small launches, all inside the captured graph.
+            from .rendering import _per_ray_brdf
+            rgb = self._buf("rgb", (R, 3))
+            det = L.deterministic()
+            ray_loss = self._buf("ray_loss", (R,)) if det else None
+            X = out2 if gsam_only else (out_all if merged else torch.cat([out1, out2], 0))
+            n1 = R * S                                   # rows of the first block (gsam_only: all of them, S = G here)
+            key = ("row_ray", R, S, 0 if gsam_only else G)
+            row_ray = self._row_ray.get(key)
+            if row_ray is None:
+                ar = torch.arange(R, device=rays.device)
+                row_ray = ar.repeat_interleave(S) if gsam_only else torch.cat([ar.repeat_interleave(S), ar.repeat_interleave(G)])
+                self._row_ray[key] = row_ray
+            kind = {L.BN_SHADE_RPV: "RPV", L.BN_SHADE_HAPKE: "Hapke", L.BN_SHADE_MICROFACET: "Microfacet"}[
+                shade_desc(model, args, spec, apply_brdf, cos_irra_on).kind]
+            c0 = spec.ch_normal_lr if spec.normal_lr else spec.ch_normal_an          # learned wins when both are present
+            pad = model.rgb_padding
+            sun_d = rays[:, 8:11] if args.data == "sat" else torch.ones_like(rays[:, 0:3])
+            with torch.enable_grad():
+                Xl = X.detach().requires_grad_(True)
+                heads = {name: Xl[:, h0:h0 + wdt] for (name, _, _), (h0, wdt) in zip(spec.heads[1:], spec.head_cols[1:])}
+                brdf, _ = _per_ray_brdf(model, args, kind, sun_d[row_ray], (-rays[:, 3:6])[row_ray], Xl[:, c0:c0 + 3], Xl[:, :3], heads)
+                bp = brdf * (1 + 2 * pad) - pad
+                if cos_irra_on:
+                    bp = bp * sun_d[:, 2:3].abs()[row_ray]              # upward normal: irradiance = |sun_z| (:260-264)
+                B = torch.cat([bp, Xl[:, 3:4]], 1)
+            with torch.no_grad():
+                Bd = B.detach()
+                d_B = self._buf("d_B", (X.shape[0], 4))
+                B1 = Bd[:n1].view(R, S, 4)
+                B2 = None if gsam_only else Bd[n1:].view(R, G, 4)
+                dB1 = d_B[:n1].view(R, S, 4)
+                dB2 = None if gsam_only else d_B[n1:].view(R, G, 4)
+                Fn.lambert_tail(z_all, idx, B1, B2, rgbs, 0.0, self.lambda_rgb, dB1, dB2,
+                                valid_depth if use_ds else None, depths[:, 0] if use_ds else None, depths[:, 1] if use_ds else None,
+                                depth_std if use_ds else None, self.ds_lambda if use_ds else 0.0, self.usealldepth,
+                                ray_loss=ray_loss, loss_acc=None if det else Fn.state_loss_partials(st), rgb=rgb,
+                                nonfinite=self._nonfinite if self.sanitize_grads else None, noise=nz2)
+                if det:
+                    loss = ray_loss.sum()
+            B.backward(d_B)
+            with torch.no_grad():
+                d_all.copy_(Xl.grad)
+                if self.sanitize_grads:
+                    Fn.count_nonfinite(d_all, self._nonfinite)
+                    torch.nan_to_num_(d_all, nan=0.0, posinf=0.0, neginf=0.0)
+        elif lambertian:
             rgb = self._buf("rgb", (R, 3))
             det = L.deterministic()        # the reported loss too: a fixed-order sum of the per-ray terms instead of atomics
             ray_loss = self._buf("ray_loss", (R,)) if det else None

@@ -748,6 +748,62 @@ def test_lean_step_with_normal_loss_matches_general_step(with_reg, gsam):
         brdf_nerf_amd.set_deterministic(prev)
 
 
+@pytest.mark.parametrize("name,gsam,cosi", [("rpv111_nlr", False, True), ("hapke_bct", False, False), ("microfacet", True, True),
+                                            ("rpv111_nan", True, False)])
+def test_lean_step_multibrdf_matches_general_step(name, gsam, cosi):
+    """--MultiBRDF (one BRDF per sample, models/spsbrdfnerf.py:289-307,350-352) on the launch-lean step: the BRDF evaluated on the
+    stored rows, its padded value as the colour channels of a 4-channel copy that the Lambertian tail kernel composites, autograd
+    through the BRDF kernels back to the field outputs - against the general step on the same draws; eager, then replayed."""
+    import brdf_nerf_amd
+    from test_gpu_parity import build_model, make_args, Replay, diag
+    from brdf_nerf_amd import functions as Fn
+    from brdf_nerf_amd.trainer import FusedTrainer
+    cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16, MultiBRDF=True, **_lean_cfgs()[name])
+    args = make_args(cfg, "fp32")
+    R, S, G = 96, 16, 16
+    g = torch.Generator().manual_seed(21)
+    rays = _sat_rays(R, g).to(DEV)
+    rgbs = torch.rand(R, 3, generator=g).to(DEV)
+    valid = (torch.rand(R, generator=g) < 0.6).float().to(DEV)
+    depths = torch.stack([0.8 + 0.4 * torch.rand(R, generator=g), torch.rand(R, generator=g)], -1).to(DEV)
+    dstd = (0.03 * torch.rand(R, generator=g)).to(DEV)
+    flags = dict(apply_brdf=True, apply_theta=True, cos_irra_on=cosi, gsam_only=gsam)
+    prev = brdf_nerf_amd.set_deterministic(True)
+    try:
+        torch.manual_seed(23)
+        ma, mb = build_model(cfg, 37, "fp32"), build_model(cfg, 37, "fp32")
+        ta = FusedTrainer(ma, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+        tb = FusedTrainer(mb, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+        ta.lean = False
+        tb.graph_after = 1
+        tb.keep_grads = True
+        worst = 0.0
+        for step in range(4):
+            tb.flat_param.copy_(ta.flat_param)
+            tb.exp_avg.copy_(ta.exp_avg)
+            tb.exp_avg_sq.copy_(ta.exp_avg_sq)
+            draws = [Fn.rng_uniform(tb.state, 1, R * S).view(R, S), Fn.rng_uniform(tb.state, 2, R * G).view(R, G),
+                     Fn.rng_uniform(tb.state, 3, R * G).view(R, G)]
+            with Replay(draws) as rp:
+                la, rgb_a = ta.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+                assert rp.draws == []
+            lb, rgb_b = tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+            la, lb = float(la), float(lb)
+            if not (la == la):
+                continue
+            assert abs(la - lb) <= 2e-5 * abs(la) + 1e-7, (name, step, la, lb)
+            assert float((rgb_a - rgb_b).abs().max()) <= (1e-4 if name == "microfacet" else 2e-5), (name, step)
+            ga, gb = ta.flat_grad, tb.flat_grad
+            e = float((ga - gb).abs().max()) / float(ga.abs().max())
+            worst = max(worst, e)
+            assert e <= 5e-4, (name, step, e)
+        assert len(tb._graphs) >= 1, "the lean step was not captured into a HIP graph"
+        assert tb._row_ray, "the step did not take the per-sample BRDF branch of the lean path"
+        diag(f"lean step with MultiBRDF {name} gsam_only={gsam}: worst flat-gradient difference over 4 steps {worst:.2e} of the largest entry")
+    finally:
+        brdf_nerf_amd.set_deterministic(prev)
+
+
 @pytest.mark.parametrize("name", ["rpv111_nan", "hapke_bct"])
 def test_lean_step_sun_visibility_pass_matches_general_step(name):
     """--sun_v analystic (rendering.py:244-259; the reference runs it in the gsam_only stage) on the launch-lean step: the
