@@ -203,7 +203,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
           for (int gp = 0; gp < 2; ++gp) {
             const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
             float dv[8], av[8], zb[8], db[8], yv[8];
-            dpiece_get<T>(pc, gp, dscale, dv);
+            dpiece_get<T>(pc, gp, g.act, dscale, dv);
             if constexpr (PRE) {
               const auto aq = __builtin_bit_cast(typename Elem<T>::frag, araw[mt][gp]), yq = __builtin_bit_cast(typename Elem<T>::frag, yraw[mt][gp]);
 #pragma unroll

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
           const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
           const f32x4 wa = *(const f32x4 *)(A.p.sigma_w + n0), wb = *(const f32x4 *)(A.p.sigma_w + n0 + 8);
           float dv[8];
-          dpiece_get<T>(pc, gp, dscale(g.L - 1), dv);
+          dpiece_get<T>(pc, gp, g.act, dscale(g.L - 1), dv);
           float av[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) { av[e] = wa[e]; av[4 + e] = wb[e]; }      // a'_L = w_sigma (s' is applied at the end)
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
           for (int gp = 0; gp < 2; ++gp) {
             const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
             float dv[8];
-            dpiece_get<T>(dpre[nt][mt], gp, dscale(l - 1), dv);
+            dpiece_get<T>(dpre[nt][mt], gp, g.act, dscale(l - 1), dv);
             if (keep) {
               float av[8];
 #pragma unroll

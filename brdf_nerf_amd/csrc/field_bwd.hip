@@ -193,7 +193,7 @@ __device__ __forceinline__ void bwd_head_dG(const BwdArgs &A, int p, T *ACT, con
       for (int gp = 0; gp < 2; ++gp) {
         const int n0 = pc0 + nt * 32 + 16 * gp + 4 * h;
         float dg[8];
-        dpiece_get<T>(pc, gp, 1.f, dg);
+        dpiece_get<T>(pc, gp, g.act, 1.f, dg);
         float va[4], vb[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
         for (int gp = 0; gp < 2; ++gp) {
           const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
           float dv[8], v[8];
-          dpiece_get<T>(dpre[nt][mt], gp, Elem<T>::kD8 ? dscale : 1.f, dv);
+          dpiece_get<T>(dpre[nt][mt], gp, g.act, Elem<T>::kD8 ? dscale : 1.f, dv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = acc[nt][mt][8 * gp + e];
           if constexpr (top) {  // rank-1 terms of the sigma head and the learned-normal head

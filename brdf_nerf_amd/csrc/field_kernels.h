@@ -384,9 +384,11 @@ __device__ __forceinline__ void ld8(const float *p, float (&v)[8]) {
 // ------------------------------------------------------------------ the derivative stash D_l = d act / d z  (and DG of the heads)
 // The backward chains only ever multiply by it element-wise, so it does not have to be an MFMA operand type.
 // 16-bit modes (Elem<T>::kD8): 8-bit fixed point of the UNSCALED derivative c (cos(.) of a Siren layer, 0 / 1 of a ReLU
-// layer), u = rne(127 c + 128) in [1, 255]; the consumer multiplies by the layer's w0.  Absolute error <= 1/254 of the
-// largest derivative, rms 2.3e-3 - the size of the bf16 rounding of the gradient operand it multiplies; a ReLU mask is exact
-// to 1 ulp.  Half the bytes of a 16-bit image: the forward writes 3 instead of 4 bytes per activation, the backward chains
+// layer): the high byte of the 16-bit signed-normalised value, u = (rne(32767 c) >> 8) + 128 in [0, 255]; the consumer
+// multiplies by the layer's w0.  Siren layers decode the middle of the byte's interval, (256 (u - 128) + 128) / 32767: absolute
+// error <= 1/256 of the largest derivative, rms 2.3e-3 - the size of the bf16 rounding of the gradient operand it multiplies;
+// ReLU layers decode (u - 128) / 127: the mask is exact (1 -> 127, 0 -> 0).  Half the bytes of a 16-bit image: the forward
+// writes 3 instead of 4 bytes per activation, the backward chains
 // read 1 instead of 2, and a layer's whole image is 32 registers per lane - all of it is prefetched BEFORE the layer's GEMM,
 // ahead of the stash stores riding in that GEMM (vmcnt retires in issue order: a load issued after them waits for them).
 // One piece = this lane's derivatives of one 32x32 accumulator tile (nt, mt): both 16-feature groups gp = 0, 1, i.e.
@@ -398,18 +400,25 @@ template <typename T> __host__ __device__ constexpr size_t dtile_bytes(int BM, i
 template <typename T, int MT, int NTW> __device__ __forceinline__ size_t dpiece_off(int wave, int nt, int mt, int lane) {
   return ((((size_t)(wave * NTW + nt) * MT + mt) * 64) + lane) * (Elem<T>::kD8 ? 16 : 64);
 }
-// 8 unscaled derivatives -> 8 bytes.  127 c + 128 + 1.5 * 2^23 has the rounded integer in the low mantissa bits (ulp 1);
-// the four floats' bit patterns are combined with shifts and the bias bytes removed in one add (all mod 2^32).
+// 4 unscaled derivatives -> 4 bytes: two v_cvt_pknorm_i16_f32 (saturating; NaN -> 0: a value out of range cannot carry into the
+// neighbouring bytes), one v_perm_b32 that keeps the four high bytes, one v_xor (two's complement -> offset binary, which
+// v_cvt_f32_ubyteN decodes) - 4 vector instructions where round 3's rne(127 c + 128) by fma / shift / add took 9: the packing
+// was a fifth of the forward epilogue's vector issue (profiles/r04_ablation.txt item 16).
 __device__ __forceinline__ unsigned int d8_pack4(float c0, float c1, float c2, float c3) {
-  const unsigned int b0 = __float_as_uint(fmaf(c0, 127.f, 12583040.f)), b1 = __float_as_uint(fmaf(c1, 127.f, 12583040.f)),
-                     b2 = __float_as_uint(fmaf(c2, 127.f, 12583040.f)), b3 = __float_as_uint(fmaf(c3, 127.f, 12583040.f));
-  return b0 + (b1 << 8) + (b2 << 16) + (b3 << 24) + 0x74C00000u;    // - 0x4B400000 * (1 + 2^8 + 2^16 + 2^24) mod 2^32
+  const unsigned int lo = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_i16(c0, c1)),
+                     hi = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_i16(c2, c3));
+  return __builtin_amdgcn_perm(hi, lo, 0x07050301u) ^ 0x80808080u;
 }
-__device__ __forceinline__ void d8_unpack4(unsigned int w, float k, float (&d)[4]) {     // k = scale / 127
-  d[0] = fmaf((float)(w & 0xffu), k, -128.f * k);
-  d[1] = fmaf((float)((w >> 8) & 0xffu), k, -128.f * k);
-  d[2] = fmaf((float)((w >> 16) & 0xffu), k, -128.f * k);
-  d[3] = fmaf((float)(w >> 24), k, -128.f * k);
+// d = k u + b.  Decoding constants of an activation (act: BN_ACT_SIN / BN_ACT_RELU) whose derivative is scaled by `scale`.
+__device__ __forceinline__ void d8_consts(int act, float scale, float &k, float &b) {
+  if (act == BN_ACT_SIN) { k = scale * (256.f / 32767.f); b = -127.5f * k; }
+  else { k = scale * (1.f / 127.f); b = -128.f * k; }
+}
+__device__ __forceinline__ void d8_unpack4(unsigned int w, float k, float b, float (&d)[4]) {
+  d[0] = fmaf((float)(w & 0xffu), k, b);
+  d[1] = fmaf((float)((w >> 8) & 0xffu), k, b);
+  d[2] = fmaf((float)((w >> 16) & 0xffu), k, b);
+  d[3] = fmaf((float)(w >> 24), k, b);
 }
 // Producer side: one 16-feature group (gp) at a time.  c[e] = unscaled derivative of accumulator register 8 gp + e; `scale`
 // (w0) is applied here in the fp32 mode only.  The two halves of a piece are stored together (one 16-byte store per lane).
@@ -444,13 +453,14 @@ template <typename T> __device__ __forceinline__ DPiece<T> dpiece_load(const cha
   }
   return r;
 }
-// scaled derivatives of group gp (accumulator registers 8 gp .. 8 gp + 7)
-template <typename T> __device__ __forceinline__ void dpiece_get(const DPiece<T> &pc, int gp, float scale, float (&d)[8]) {
+// scaled derivatives of group gp (accumulator registers 8 gp .. 8 gp + 7); act = the activation the image was written for
+template <typename T> __device__ __forceinline__ void dpiece_get(const DPiece<T> &pc, int gp, int act, float scale, float (&d)[8]) {
   if constexpr (Elem<T>::kD8) {
-    const float k = scale * (1.f / 127.f);
+    float k, b;
+    d8_consts(act, scale, k, b);
     float lo[4], hi[4];
-    d8_unpack4(pc.w[2 * gp], k, lo);
-    d8_unpack4(pc.w[2 * gp + 1], k, hi);
+    d8_unpack4(pc.w[2 * gp], k, b, lo);
+    d8_unpack4(pc.w[2 * gp + 1], k, b, hi);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { d[e] = lo[e]; d[4 + e] = hi[e]; }
   } else {

@@ -2204,6 +2204,27 @@ def test_c_abi_from_a_plain_host_program(tmp_path):
     assert p.returncode == 0 and "OK" in p.stdout, p.stdout
 
 
+def test_d8_derivative_stash_round_trip(tmp_path):
+    """The 8-bit derivative stash of the 16-bit modes (csrc/field_kernels.h d8_pack4 / d8_unpack4: the activation derivative the
+    backward chains of spsbrdfnerf.py:636-646 multiply by) encoded and decoded on the device: a Siren layer's cosine comes back
+    within half a step (128.5 / 32767) without bias, a ReLU mask exactly, and a NaN or out-of-range value stays inside its own
+    byte (tests/d8_roundtrip.hip)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "d8_roundtrip")
+    subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result", "-Wno-pass-failed",
+                    "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "brdf_nerf_amd", "csrc"),
+                    os.path.join(root, "tests", "d8_roundtrip.hip"), "-o", exe], check=True, timeout=600)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    for line in p.stdout.splitlines():
+        diag("d8_roundtrip: " + line)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stdout
+
+
 def test_count_nonfinite_hook():
     """Sync-free replacement of check_nan (train_utils.py:14-25): NaN and Inf counters accumulate on the device."""
     from brdf_nerf_amd import functions as Fn
