@@ -287,6 +287,36 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
   loadB(Bc, ks0);
   __builtin_amdgcn_sched_barrier(0);
   int ks = ks0;
+#ifdef BN_GEMM_AFFINE_B
+  // Whole blocks of DEPTH k-steps: the LDS fragment addresses of a block are ONE base per point tile (advanced once per block)
+  // plus compile-time offsets - the look-ahead of a range's last step reads the 16 columns behind the range (row pad / the
+  // next columns of the tile: inside the LDS allocation, never used) instead of wrapping to ks0, which made every address a
+  // select and cost a vector add per read.
+  {
+    const T *bm[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bm[mt] = bl + (size_t)mt * 32 * ldb + (size_t)ks0 * 16;
+    for (; ks + DEPTH <= kend; ks += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        frag Bn[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) Bn[mt] = lds_frag<T>(bm[mt] + (d + 1) * 16);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], A[d][nt], Bc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) Bc[mt] = Bn[mt];
+        loadA(A[d], ks + d + DEPTH);
+        side.at(d & 1);   // constant after unrolling
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bm[mt] += DEPTH * 16;
+    }
+  }
+#else
   for (; ks + DEPTH <= kend; ks += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
@@ -296,6 +326,7 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+#endif
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
     if (ks + d < kend) {

@@ -157,6 +157,32 @@ template <typename T> __device__ __forceinline__ typename Elem<T>::frag w2_frag(
   return u.b;
 }
 
+// Sum of a fragment's 8 elements added to an fp32 value: four v_dot2c_f32_{bf16,f16} against (1, 1) in the 16-bit modes (the bias
+// gradient's column sums in wgrad256).
+__device__ __forceinline__ float frag_sum8(float s, const bf16x8 &f) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  const bf16x2 one = {(__bf16)1.f, (__bf16)1.f};
+  s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), one, s, false);
+  s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), one, s, false);
+  s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), one, s, false);
+  s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), one, s, false);
+  return s;
+}
+__device__ __forceinline__ float frag_sum8(float s, const f16x8 &f) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+  const f16x2 one = {(_Float16)1.f, (_Float16)1.f};
+  s = __builtin_amdgcn_fdot2(__builtin_shufflevector(f, f, 0, 1), one, s, false);
+  s = __builtin_amdgcn_fdot2(__builtin_shufflevector(f, f, 2, 3), one, s, false);
+  s = __builtin_amdgcn_fdot2(__builtin_shufflevector(f, f, 4, 5), one, s, false);
+  s = __builtin_amdgcn_fdot2(__builtin_shufflevector(f, f, 6, 7), one, s, false);
+  return s;
+}
+__device__ __forceinline__ float frag_sum8(float s, const f32x8 &f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += f[j];
+  return s;
+}
+
 #if defined(BN_PHASE_TIMING) && defined(BN_PHASE_TIMING_WGRAD)
 BN_PH_DEFINE_READER(bn_debug_phase_read_wgrad)
 #define WG_PH_DECL BN_PH_DECL
@@ -267,12 +293,19 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-  // bias gradient = column sums of A: the waves that own output columns k0 .. k0+127 of the first k-block add up the
-  // A fragments they already hold (lane (r, h): row n = r, points 8h .. 8h+7 of the step)
-  const bool do_bias = J.bias != nullptr && k0 == 0 && wc == 0;
-  float bsum[W2_RA];
+  // bias gradient = column sums of A, from the A fragments the waves hold anyway (lane (r, h): row n = r, points 8h .. 8h+7 of
+  // the step), stored by the workgroups of the first k-block.  The two waves of a row group (wc = 0, 1) hold the same A
+  // fragments: each adds up HALF of the row group's 32-row tiles (BA of them, picked by wc with four selects per tile), by
+  // v_dot2c against (1, 1): 8 vector instructions per 16-point step and wave, no branch in the k-loop.  Rounds 1-3 and the first
+  // half of round 4: every wave added up ALL its A fragments by shifts / masks / adds, ~36 vector instructions per 8 MFMAs -
+  // 10 % of the kernel (a probe without the sums: -15 %; profiles/r04_ablation.txt item 17, where the other forms tried are:
+  // stage-loop instances with / without the sums spill inside the loop; the tiles numbered from the wave's own half - no
+  // selects - measured 3 % slower than the selects).
+  constexpr int BA = W2_RA / 2;
+  const bool do_bias = J.bias != nullptr && k0 == 0;
+  float bsum[BA];
 #pragma unroll
-  for (int a = 0; a < W2_RA; ++a) bsum[a] = 0.f;
+  for (int a = 0; a < BA; ++a) bsum[a] = 0.f;
   WG_PH_DECL
   // fragments of 16-point step i+1 are read while the MFMAs of step i run (two fragment sets; sched_barrier keeps
   // hipcc from sinking the reads below the MFMAs)
@@ -295,11 +328,12 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
       for (int a = 0; a < W2_RA; ++a)
 #pragma unroll
         for (int b = 0; b < NBV; ++b) mma32(acc[a][b], fa[cur][a], fb[cur][b]);
-      {   // every wave adds its A fragments up, only the owners of the bias columns store the sums: no branch in the k-loop
+      {   // every wave adds its half of the row group's A fragments up, the workgroups of the first k-block store the sums: no branch in the k-loop
 #pragma unroll
-        for (int a = 0; a < W2_RA; ++a)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) bsum[a] += (float)fa[cur][a][j];
+        for (int a = 0; a < BA; ++a) {
+          const u32x4 f0 = __builtin_bit_cast(u32x4, fa[cur][a]), f1 = __builtin_bit_cast(u32x4, fa[cur][BA + a]);
+          bsum[a] = frag_sum8(bsum[a], __builtin_bit_cast(frag_t, wc ? f1 : f0));
+        }
       }
       // the next stage's tile goes to the other LDS buffer one chunk pair per 16-point step, under this step's MFMAs, and
       // each register is re-filled with the stage after that at once (instead of 8 writes + 8 loads before the MFMAs
@@ -349,9 +383,9 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
             f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
   if (do_bias) {
 #pragma unroll
-    for (int a = 0; a < W2_RA; ++a) {
+    for (int a = 0; a < BA; ++a) {
       const float v = bsum[a] + __shfl_xor(bsum[a], 32);
-      if (h == 0) P[256 * 256 + wr * (W2_RA * 32) + a * 32 + r] = v;
+      if (h == 0) P[256 * 256 + wr * (W2_RA * 32) + (wc * BA + a) * 32 + r] = v;
     }
   }
   WG_PH(4)
