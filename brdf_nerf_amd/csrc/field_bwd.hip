@@ -227,7 +227,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
 #ifndef BN_BWD_PP_DEPTH
 #define BN_BWD_PP_DEPTH 6
 #endif
-  constexpr int DP = (NT == 2 && WAVES == 8 && Elem<T>::kFastMath) ? BN_BWD_PP_DEPTH : BwdDepth<T>::value;
+  constexpr int DP = (NT == 2 && WAVES == 8 && Elem<T>::kFastMath) ? (BN_BWD_PP_DEPTH | BN_GEMM_AFFINE) : BwdDepth<T>::value;
   // D_lo pieces fetched before the layer's GEMM (the rest right after its last MFMA): all of them when a piece is 16 bytes
   constexpr int NPRE = Elem<T>::kD8 ? NT : 1;
   BN_PH_DECL

@@ -228,9 +228,14 @@ __device__ __forceinline__ void pp_signal(int *flag, int lane) {
 #ifndef BN_BWD_DEPTH
 #define BN_BWD_DEPTH 2
 #endif
+// BN_GEMM_AFFINE added to a depth: the k-loop keeps ONE LDS base address per point tile and block of DEPTH k-steps (4 vector adds
+// per block instead of 4 per k-step; 4 more live registers).  Round 4, profiles/r04_ablation.txt item 18: training forward -1.4 %
+// (config 3: -3.7 %), backward chain -1.3 % (-2.7 %) - and the inference forward +38 %, the adjoint chains +19 ... 25 % (they
+// spill with it): a property of the kernel instantiation, hence carried by its depth constant.
+#define BN_GEMM_AFFINE 64
 template <typename T, bool TRAIN_FWD> struct FwdDepth { static constexpr int value = 4; };
-template <> struct FwdDepth<bf16, true> { static constexpr int value = BN_FWD_DEPTH_TRAIN; };
-template <> struct FwdDepth<f16, true> { static constexpr int value = BN_FWD_DEPTH_TRAIN; };
+template <> struct FwdDepth<bf16, true> { static constexpr int value = BN_FWD_DEPTH_TRAIN | BN_GEMM_AFFINE; };
+template <> struct FwdDepth<f16, true> { static constexpr int value = BN_FWD_DEPTH_TRAIN | BN_GEMM_AFFINE; };
 template <typename T> struct BwdDepth { static constexpr int value = Elem<T>::kFastMath ? BN_BWD_DEPTH : 4; };
 
 // LDS (B) fragments: ONE register set (`Bc = Bn` after the MFMAs; hipcc coalesces the two and issues the reads of k-step s + 1
@@ -238,10 +243,12 @@ template <typename T> struct BwdDepth { static constexpr int value = Elem<T>::kF
 // (round 4) measured slower wherever tried: the GEMM alone in a kernel 42 vs 35 cycles per MFMA with one wave
 // per SIMD and 78 vs 56 with two (profiles/r04_probe_gemm_rate.txt), the training forward +1 %, the backward chain +5 %
 // (profiles/r04_ablation.txt).
-template <typename T, int MT, int NTW, int DEPTH, typename Side>
+template <typename T, int MT, int NTW, int DEPTH_, typename Side>
 __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, int ks0, int nks, const T *bsrc,
                                            int ldb, int lane, Side &side) {
   // k-steps [ks0, ks0 + nks) of a packed matrix whose n-tiles are KS k-steps apart
+  constexpr int DEPTH = DEPTH_ & (BN_GEMM_AFFINE - 1);
+  constexpr bool AFFINE = (DEPTH_ & BN_GEMM_AFFINE) != 0;
   typedef typename Elem<T>::frag frag;
   static_assert(DEPTH % 2 == 0, "side jobs rely on an even pipeline depth");
   const int r = lane & 31, h = lane >> 5;
@@ -287,7 +294,7 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
   loadB(Bc, ks0);
   __builtin_amdgcn_sched_barrier(0);
   int ks = ks0;
-#ifdef BN_GEMM_AFFINE_B
+  if constexpr (AFFINE) {
   // Whole blocks of DEPTH k-steps: the LDS fragment addresses of a block are ONE base per point tile (advanced once per block)
   // plus compile-time offsets - the look-ahead of a range's last step reads the 16 columns behind the range (row pad / the
   // next columns of the tile: inside the LDS allocation, never used) instead of wrapping to ks0, which made every address a
@@ -316,7 +323,7 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
       for (int mt = 0; mt < MT; ++mt) bm[mt] += DEPTH * 16;
     }
   }
-#else
+  } else {
   for (; ks + DEPTH <= kend; ks += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
@@ -326,7 +333,7 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-#endif
+  }
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
     if (ks + d < kend) {
