@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-4 GPU session 47: validation of the sources with the v_cvt_pknorm D stash: PMC passes, bench lines of every BASELINE
+# round-4 GPU session 47 (run again as session 55 on the final sources: + wgrad256 bias sums by v_dot2c, affine chain GEMM): validation of the sources with the v_cvt_pknorm D stash: PMC passes, bench lines of every BASELINE
 # configuration, rocprofv3 kernel stats over bench.py
 run() {  # name, args...
   name=$1; shift
