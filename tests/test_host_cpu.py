@@ -71,6 +71,19 @@ def test_library_carries_the_hash_of_the_sources_beside_it(tmp_path, monkeypatch
     _lib.load(_lib.LIB_PATH)
 
 
+def test_device_test_programs_compile_for_gfx950(tmp_path):
+    """tests/d8_roundtrip.hip (run by the GPU suite against csrc/field_kernels.h's 8-bit derivative stash) cross-compiles here:
+    a change of the header that breaks the program shows up in the CPU suite, not first on the GPU box."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result", "-Wno-pass-failed",
+                    "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "brdf_nerf_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "d8_roundtrip.hip"), "-o", str(tmp_path / "d8_roundtrip")], check=True, timeout=600)
+
+
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     from brdf_nerf_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
