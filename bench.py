@@ -19,7 +19,8 @@ invocation (`speedup_vs_n1_ms`); `--scaling strong` makes the strong shape the h
 Prints ONE JSON line (rank 0).  Timing protocol: W warm-up steps, two steady steps for an estimate, then untimed "settling"
 steps until the chip has run STEADY-STATE steps for >= 1.5 s (DVFS settles over seconds), then EXACTLY K steps between barrier +
 synchronize pairs with no instrumentation inside, then `sustained` (200 more steps, outside `value`); the per-kernel HIP-event
-times and `launches_per_step` come from a SEPARATE eager pass after the timed one.  `roofline`
+times and `launches_per_step` come from a SEPARATE eager pass after the timed one; `box_calibration` (N = 1) = ~1 s of vendor bf16
+GEMMs after all of that: a box-speed indicator (boxes of the pool differ by up to 10 % with unchanged code).  `roofline`
 prices the kernel with the largest share of the step, as a fraction of the dense bf16/fp16 MFMA peak both by the
 reference network's algorithmic FLOPs and by the FLOPs the build executes (the linear feats layer is folded into the
 heads); `traffic` / `mfma_busy` come from the committed rocprofv3 PMC pass of the SAME kernel sources
@@ -99,6 +100,35 @@ def synthetic_batch(R, seed, device):
                  depths=torch.stack([0.8 + 0.4 * torch.rand(R, generator=g), torch.rand(R, generator=g)], -1),
                  depth_std=torch.zeros(R))                       # reference quirk 7: target_std == 0 in training
     return {k: v.to(device) for k, v in batch.items()}
+
+
+def box_calibration(dev, n=8192, seconds=1.0):
+    """How fast is THIS box?  The boxes of the pool run the same binary up to 10 % apart (round 4, DESIGN.md section 7:
+    MI355X_MICROARCH.md DVFS give-back item 5), so a bench line is read beside a workload that does not depend on this
+    repository: ~1 s of back-to-back vendor-library bf16 GEMMs (n x n x n, random operands), after everything that is timed.
+    Not part of `value`; never used by the product path."""
+    try:
+        x = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+        y = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+        for _ in range(5):
+            torch.matmul(x, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        torch.matmul(x, y)
+        torch.cuda.synchronize()
+        reps = max(10, int(seconds / max(time.perf_counter() - t0, 1e-4)))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            torch.matmul(x, y)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        return {"kind": f"torch.matmul bf16 {n}x{n}x{n} (vendor GEMM library), {reps} back-to-back calls after the bench", "ms": ms,
+                "tflops": 2.0 * n ** 3 / (ms * 1e-3) / 1e12,
+                "note": "box-speed indicator: compare bench lines of different boxes through it, not a property of this repository"}
+    except Exception as e:      # never let the indicator break the bench line
+        return {"error": repr(e)}
 
 
 def cpu_baseline(args, rays=1024, seconds_budget=30.0):
@@ -465,6 +495,8 @@ def main():
         "sustained": sustained, "strong": strong,
         "launches_per_step": sum(k["launches_per_step"] for k in kernels.values()),
     }
+    if world == 1:
+        line["box_calibration"] = box_calibration(dev)
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
     sys.stdout.flush()
