@@ -1,5 +1,6 @@
 // Shared device/host helpers for the gfx950 kernels.  CDNA4 only (wave64, MFMA 32x32).
 #pragma once
+#include "diag.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>

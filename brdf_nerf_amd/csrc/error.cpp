@@ -7,6 +7,7 @@
 #include <mutex>
 #include <utility>
 #include "brdfnerf_hip.h"
+#include "diag.h"
 
 static thread_local char g_err[512] = "";
 
@@ -27,59 +28,8 @@ extern "C" int bn_abi_version(void) { return BN_ABI_VERSION; }
 #endif
 extern "C" const char *bn_source_hash(void) { return "BN_SOURCE_HASH=" BN_SOURCE_HASH + 15; }
 
-// Every -D switch a source file of the library reacts to (variant builds pass the same defines to every file).
-extern "C" const char *bn_build_flags(void) {
-  return ""
-#ifdef BN_PHASE_TIMING
-         "BN_PHASE_TIMING "
-#endif
-#ifdef BN_PHASE_TIMING_WGRAD
-         "BN_PHASE_TIMING_WGRAD "
-#endif
-#ifdef BN_CLOCK_STAMP
-         "BN_CLOCK_STAMP "
-#endif
-#ifdef BN_CLOCK_STAMP_WGRAD
-         "BN_CLOCK_STAMP_WGRAD "
-#endif
-#ifdef BN_TIMELINE
-         "BN_TIMELINE "
-#endif
-#ifdef BN_GEMM_PRIO
-         "BN_GEMM_PRIO "
-#endif
-#ifdef BN_NO_NT_STASH
-         "BN_NO_NT_STASH "
-#endif
-#ifdef BN_NO_PINGPONG
-         "BN_NO_PINGPONG "
-#endif
-#ifdef BN_HEAD_WIDE
-         "BN_HEAD_WIDE "
-#endif
-#ifdef BN_NO_FLAT_COMPOSITE
-         "BN_NO_FLAT_COMPOSITE "
-#endif
-#ifdef BN_DPH
-         "BN_DPH "
-#endif
-#ifdef SKINNY_SPLITS
-         "SKINNY_SPLITS "
-#endif
-#ifdef BN_ABLATION_BUILD
-         "BN_ABLATION_BUILD "
-#endif
-#ifdef BN_FWD_DEPTH_TRAIN
-         "BN_FWD_DEPTH_TRAIN "
-#endif
-#ifdef BN_BWD_DEPTH
-         "BN_BWD_DEPTH "
-#endif
-#ifdef BN_PRIO_YOUNG
-         "BN_PRIO_YOUNG "
-#endif
-      ;
-}
+// Every -D switch a source file of the library reacts to is declared in diag.h (variant builds pass the same defines to every file).
+extern "C" const char *bn_build_flags(void) { return BN_BUILD_FLAGS_STRING; }
 
 static std::atomic<int> g_deterministic{0};
 int bn_deterministic() { return g_deterministic.load(std::memory_order_relaxed); }

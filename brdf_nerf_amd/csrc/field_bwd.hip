@@ -224,9 +224,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   const T *packed = (const T *)A.packed;
   // weight fragments in flight per wave: the barrier-free trunk (F = 512, 16-bit) gains 1-2 % from the forward's depth
   // (profiles/r04_ablation.txt item 7); the shapes under barriers keep the depth tuned for them in round 2
-#ifndef BN_BWD_PP_DEPTH
-#define BN_BWD_PP_DEPTH 6
-#endif
+  // (BN_BWD_PP_DEPTH = 6: diag.h)
   constexpr int DP = (NT == 2 && WAVES == 8 && Elem<T>::kFastMath) ? (BN_BWD_PP_DEPTH | BN_GEMM_AFFINE) : BwdDepth<T>::value;
   // D_lo pieces fetched before the layer's GEMM (the rest right after its last MFMA): all of them when a piece is 16 bytes
   constexpr int NPRE = Elem<T>::kD8 ? NT : 1;
@@ -447,9 +445,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
     zero_acc<MT, NT>(acc);
     T *zdst = (T *)(A.stash + A.sl.dZ[l]) + (size_t)m0 * F;
     if (!NATZ && !ride) tile_to_global<T>(ACT, LDA, zdst, F, BM, F);
-#ifndef BN_BWD_D_AT      // where the barrier-free trunk issues a layer's derivative loads (A/B switch): 0 before the GEMM, 1 between its halves, 2 behind it
-#define BN_BWD_D_AT 0
-#endif
+    // (BN_BWD_D_AT, diag.h: where the barrier-free trunk issues a layer's derivative loads: 0 before the GEMM, 1 between its halves, 2 behind it)
     if (wave_on) {
       if (!PING || BN_BWD_D_AT == 0) load_D(lo, 0, NPRE);
       const size_t off = A.pl.bwd_trunk[l] + (size_t)(ncol0 / 32) * KSF * 512;
@@ -460,13 +456,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
         if (grp == 1) pp_wait(RD + 0, 4 * (it + 1), &g_bwd_fault);    // group 0 is done with its phase 1 of this layer: the lag
         BN_PH(12)
         __builtin_amdgcn_s_setprio(1);
-        gemm_range<T, MT, NT, DP>(acc, packed + off, KSF, 0, half, ACT, LDA, lane, none);
+        gemm_range<T, MT, NT, DP | BN_PP_NKS>(acc, packed + off, KSF, 0, half, ACT, LDA, lane, none);
         BN_PH(9)
         pp_signal(RD + 0 + grp, lane);
         pp_wait(WR + 1, 4 * it, &g_bwd_fault);                        // half 1
         BN_PH(12)
         if (BN_BWD_D_AT == 1) load_D(lo, 0, NPRE);
-        gemm_range<T, MT, NT, DP>(acc, packed + off, KSF, half, half, ACT, LDA, lane, none);
+        gemm_range<T, MT, NT, DP | BN_PP_NKS>(acc, packed + off, KSF, half, half, ACT, LDA, lane, none);
         __builtin_amdgcn_s_setprio(0);
         pp_signal(RD + 2 + grp, lane);
         if (BN_BWD_D_AT == 2) load_D(lo, 0, NPRE);
@@ -683,9 +679,7 @@ extern "C" int bn_field_backward_parts(const bn_field_desc *desc, const bn_field
     for (int c = 0; c < j.nc; ++c) { j.out[c] = G->head_w2[hd] + (size_t)c * g.H2; j.bias[c] = G->head_b2[hd] ? G->head_b2[hd] + c : nullptr; }
   }
   if (s.n_jobs > 0) {
-#ifndef SKINNY_SPLITS
-#define SKINNY_SPLITS 256   // 512: 0.129 ms, 256: 0.102 ms, 128: 0.169 ms per launch (the per-block LDS + global atomics tail vs parallelism)
-#endif
+    // (SKINNY_SPLITS = 256, diag.h: 512: 0.129 ms, 256: 0.102 ms, 128: 0.169 ms per launch - the per-block tail vs parallelism)
     // small batches (strong scaling: 512 rays per GPU = 32,768 points per launch): a block walks its points in a latency-bound
     // loop, so fewer points per block is faster until the per-block tail takes over - at least 2 point tiles per split
     // (session 50, 512 rays: 32 splits 0.085 ms, 64 0.066, 128 0.060, 256 0.089 per launch)

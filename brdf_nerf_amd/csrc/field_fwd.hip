@@ -332,9 +332,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
   int *WR = (int *)RED, *RD = WR + 2;   // RD[2 * h + g]
   const int grp = wave >> 2;
   BN_TL_DECL((char *)RED + 64 + 4096)
-#ifndef BN_GEMM_PRIO      // priority of a wave while it multiplies (A/B switch; 0 = none, as in rounds 1-3)
-#define BN_GEMM_PRIO 1
-#endif
+  // (BN_GEMM_PRIO, diag.h: priority of a wave while it multiplies; 0 = none, as in rounds 1-3)
 #ifdef BN_PRIO_YOUNG      // A/B switch: static priority for the later-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
   if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -379,14 +377,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
           BN_PH(12)
           BN_TL(1)
           __builtin_amdgcn_s_setprio(BN_GEMM_PRIO);
-          gemm_range<T, MT, NT, DP>(acc, w_h, KSF, 0, half, ACT, LDA, lane, none);
+          gemm_range<T, MT, NT, DP | BN_PP_NKS>(acc, w_h, KSF, 0, half, ACT, LDA, lane, none);
           BN_PH(1)
           BN_TL(2)
           pp_signal(RD + 0 + grp, lane);
           pp_wait(WR + 1, 4 * l, &g_fwd_fault);                       // half 1
           BN_PH(13)
           BN_TL(3)
-          gemm_range<T, MT, NT, DP>(acc, w_h, KSF, half, half, ACT, LDA, lane, none);
+          gemm_range<T, MT, NT, DP | BN_PP_NKS>(acc, w_h, KSF, half, half, ACT, LDA, lane, none);
           __builtin_amdgcn_s_setprio(0);
           BN_TL(4)
           pp_signal(RD + 2 + grp, lane);

@@ -222,17 +222,21 @@ __device__ __forceinline__ void pp_signal(int *flag, int lane) {
 
 // Weight-fragment prefetch depth of the chain GEMM (k-steps in flight per wave), chosen per kernel instantiation
 // (profiles/r02_ablation.txt session 42: the training forward gains 1-1.7 % with 6, the backward / adjoint chains 1-3 % with 2).
-#ifndef BN_FWD_DEPTH_TRAIN      // A/B switches (results unchanged; reported by bn_build_flags)
-#define BN_FWD_DEPTH_TRAIN 6
-#endif
-#ifndef BN_BWD_DEPTH
-#define BN_BWD_DEPTH 2
-#endif
+// (BN_FWD_DEPTH_TRAIN = 6, BN_BWD_DEPTH = 2: diag.h)
 // BN_GEMM_AFFINE added to a depth: the k-loop keeps ONE LDS base address per point tile and block of DEPTH k-steps (4 vector adds
 // per block instead of 4 per k-step; 4 more live registers).  Round 4, profiles/r04_ablation.txt item 18: training forward -1.4 %
 // (config 3: -3.7 %), backward chain -1.3 % (-2.7 %) - and the inference forward +38 %, the adjoint chains +19 ... 25 % (they
 // spill with it): a property of the kernel instantiation, hence carried by its depth constant.
 #define BN_GEMM_AFFINE 64
+// BN_PP_NKS or-ed into a depth: the number of k-steps is a compile-time constant (bits 8 and up; the caller guarantees nks ==
+// that number) and the range is straight-line code - no clamps, no tail steps.  The barrier-free trunks' half-GEMMs (16 k-steps:
+// NT == 2 means F = 512) use it: in the looped form their tail steps copied the accumulator set (~70 v_mov_b64 per half-GEMM,
+// profiles/r04_isa_scan.txt).  Round 4 ablation item 20, adopted in round 5: training forward -3.8 %, sigma-only forward -8.6 %.
+#ifdef BN_PP_LOOP_NKS      // A/B switch (results unchanged): the looped form of rounds 1-4
+#define BN_PP_NKS 0
+#else
+#define BN_PP_NKS (16 << 8)
+#endif
 template <typename T, bool TRAIN_FWD> struct FwdDepth { static constexpr int value = 4; };
 template <> struct FwdDepth<bf16, true> { static constexpr int value = BN_FWD_DEPTH_TRAIN | BN_GEMM_AFFINE; };
 template <> struct FwdDepth<f16, true> { static constexpr int value = BN_FWD_DEPTH_TRAIN | BN_GEMM_AFFINE; };
@@ -249,6 +253,7 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
   // k-steps [ks0, ks0 + nks) of a packed matrix whose n-tiles are KS k-steps apart
   constexpr int DEPTH = DEPTH_ & (BN_GEMM_AFFINE - 1);
   constexpr bool AFFINE = (DEPTH_ & BN_GEMM_AFFINE) != 0;
+  constexpr int NKS = DEPTH_ >> 8;      // experiment: a compile-time number of k-steps (the caller guarantees nks == NKS): straight-line code, no tail
   typedef typename Elem<T>::frag frag;
   static_assert(DEPTH % 2 == 0, "side jobs rely on an even pipeline depth");
   const int r = lane & 31, h = lane >> 5;
@@ -294,6 +299,34 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
   loadB(Bc, ks0);
   __builtin_amdgcn_sched_barrier(0);
   int ks = ks0;
+  if constexpr (NKS > 0) {
+    const T *bm[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bm[mt] = bl + (size_t)mt * 32 * ldb + (size_t)ks0 * 16;
+#pragma unroll
+    for (int j = 0; j < NKS; ++j) {
+      frag Bn[MT];
+      if (j + 1 < NKS) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) Bn[mt] = lds_frag<T>(bm[mt] + (j + 1) * 16);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], A[j % DEPTH][nt], Bc[mt]);
+      if (j + 1 < NKS) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) Bc[mt] = Bn[mt];
+      }
+      if (j + DEPTH < NKS) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) A[j % DEPTH][nt] = gld_frag<T>(wl + ((size_t)nt * KS + ks0 + j + DEPTH) * 512);
+      }
+      side.at(j & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
   if constexpr (AFFINE) {
   // Whole blocks of DEPTH k-steps: the LDS fragment addresses of a block are ONE base per point tile (advanced once per block)
   // plus compile-time offsets - the look-ahead of a range's last step reads the 16 columns behind the range (row pad / the
