@@ -79,7 +79,9 @@ class FoldDesc(C.Structure):          # bn_fold_desc
                 ("d_wf", fptr), ("d_bf", fptr)]
 
 
+BN_ABI_VERSION = 7
 BN_STATE_BYTES, BN_STATE_LOSS_OFF, BN_STATE_LOSS_SLOTS, BN_STATE_POW_OFF, BN_STATE_PART_OFF = 1024, 64, 64, 320, 512
+BN_STATE_NOISE_OFF = 40
 BN_RNG_COARSE, BN_RNG_GUIDED, BN_RNG_GUIDED_TARGET, BN_RNG_NOISE_COARSE, BN_RNG_NOISE_MERGED, BN_RNG_SUN = 1, 2, 3, 4, 5, 6
 BN_BWD_CHAIN, BN_BWD_WGRAD_TRUNK, BN_BWD_WGRAD_HEADS, BN_BWD_SKINNY, BN_BWD_ALL = 1, 2, 4, 8, 15
 
@@ -189,7 +191,7 @@ def load(path, baseline=False):
             continue
         fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if not baseline and L.bn_abi_version() != 6:
+    if not baseline and L.bn_abi_version() != BN_ABI_VERSION:
         raise LibraryMissing(f"{path}: ABI version mismatch; rebuild")
     if not baseline and os.environ.get("BRDFNERF_ALLOW_STALE_LIB", "0") in ("", "0"):
         # a library older than the sources beside it must not pass for them (tests, bench and profiles all run through here)

@@ -20,6 +20,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 void bn_set_error(const char *fmt, ...);
+// Sticky device fault words of the barrier-free trunks (field_fwd.hip / field_bwd.hip; bn_device_faults): device addresses on the
+// current device, and the host's asynchronous view of them (bit 0 forward, bit 1 backward; refreshed every 64th forward launch
+// outside stream captures).  bn_adam_multi reads both words: a step whose kernels lost a hand-over does not update the parameters.
+const unsigned int *bn_fwd_fault_ptr();
+const unsigned int *bn_bwd_fault_ptr();
+int bn_field_fault_seen();
 // Raise a kernel's dynamic-LDS limit to `lds` bytes on the CURRENT device (cached per (device, kernel); thread-safe).
 int bn_configure_lds(const void *kernel, size_t lds, const char *what);
 

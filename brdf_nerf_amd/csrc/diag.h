@@ -23,6 +23,7 @@
 //     BN_NO_FLAT_COMPOSITE   the per-(sample, channel) scalar compositing path everywhere
 //     BN_DPH=<n>             pre-activation gradients kept per point for the heads (default 3 * BN_MAX_HEADS)
 //     SKINNY_SPLITS=<n>      point splits of skinny_wgrad_kernel (default 256)
+//     BN_W2_BLOCKS=<n>       wgrad256: tiles x point splits per round of the 256 CUs (default 256)
 //     BN_WGRAD_BIAS_INLINE   round 4's wgrad256: bias column sums computed by every workgroup (round 5: only where they are stored)
 //   kind P (timing probe, RESULTS WRONG - never ship):
 //     BN_PROBE_NO_A, BN_PROBE_NO_B   chain GEMM without its weight / LDS fragment traffic (profiles/probe_gemm_rate.py)
@@ -31,7 +32,6 @@
 //     BN_ABLATION_BUILD              marker set by profiles/ scripts that patch sources for an ablation
 #pragma once
 
-#define BN_DIAG_CAT_(a, b) a b
 #ifdef BN_PHASE_TIMING
 #define BN_F_PHASE_TIMING "BN_PHASE_TIMING "
 #else
@@ -133,6 +133,12 @@
 #define BN_F_SKINNY_SPLITS ""
 #define SKINNY_SPLITS 256   // 512: 0.129 ms, 256: 0.102 ms, 128: 0.169 ms per launch (round 2)
 #endif
+#ifdef BN_W2_BLOCKS
+#define BN_F_W2_BLOCKS "BN_W2_BLOCKS "
+#else
+#define BN_F_W2_BLOCKS ""
+#define BN_W2_BLOCKS 256
+#endif
 #ifdef BN_WGRAD_BIAS_INLINE
 #define BN_F_WGRAD_BIAS_INLINE "BN_WGRAD_BIAS_INLINE "
 #else
@@ -170,4 +176,4 @@
   BN_F_PHASE_TIMING BN_F_PHASE_TIMING_WGRAD BN_F_CLOCK_STAMP BN_F_CLOCK_STAMP_WGRAD BN_F_TIMELINE BN_F_GEMM_PRIO          \
   BN_F_PRIO_YOUNG BN_F_NO_NT_STASH BN_F_NO_PINGPONG BN_F_BWD_NO_PINGPONG BN_F_PP_LOOP_NKS BN_F_FWD_DEPTH_TRAIN            \
   BN_F_BWD_DEPTH BN_F_BWD_PP_DEPTH BN_F_BWD_D_AT BN_F_HEAD_WIDE BN_F_NO_FLAT_COMPOSITE BN_F_DPH BN_F_SKINNY_SPLITS        \
-  BN_F_WGRAD_BIAS_INLINE BN_F_PROBE_NO_A BN_F_PROBE_NO_B BN_F_PROBE_NO_D BN_F_PROBE_NO_RIDE BN_F_ABLATION_BUILD
+  BN_F_W2_BLOCKS BN_F_WGRAD_BIAS_INLINE BN_F_PROBE_NO_A BN_F_PROBE_NO_B BN_F_PROBE_NO_D BN_F_PROBE_NO_RIDE BN_F_ABLATION_BUILD

@@ -178,16 +178,37 @@ struct StashLayout {
   int64_t Mpad;
 };
 
-// Bytes of the weight-gradient slab workspace for a point set of Mpad rows: the launchers' largest grids (field_wgrad.hip
-// bn_launch_wgrad: <= 1024 workgroups of 256 x 256 tiles in the 16-bit modes, <= 2048 of 128 x 128 in fp32, splits of >= 512 / 256
-// points), bounded by the job list a model can have, and the skinny jobs' [job][split] slabs.
+// Point splits of one weight-gradient launch over `tiles` output tiles and Mpad points - THE place both the launcher
+// (field_wgrad.hip bn_launch_wgrad) and the stash sizing below take them from (two formulas that could drift).
+//   16-bit modes (256 x 256 tiles, one 144 KB workgroup per CU): one round of the 256 CUs up to 327,680 points, two beyond (both
+//   passes of a 4096-ray step in one call: 524,288 points).  With the fp32 atomics of rounds 1-3 four rounds were fastest; with
+//   slabs every split costs a 257 KB slab written and read once more: 1020 -> 510 workgroups took the launch from 2.372 to
+//   2.344 ms and its reduce from 0.089 to 0.059 ms (profiles/r04_ab_slab_lambert.txt).  At least 512 points per workgroup.
+//   fp32 parity mode (128 x 128 tiles): a grid of ~2048 workgroups, at least 256 points each.
+// (BN_W2_BLOCKS = 256, diag.h: tiles x point splits per round of the 256 CUs)
+static inline int64_t bn_wgrad_splits(bool half, int64_t tiles, int64_t Mpad, int64_t *m_per_block) {
+  const int64_t stage = half ? 64 : 32;          // W2_BK / WG_BK: points per LDS stage
+  const int64_t min_mpb = half ? 512 : 256;
+  int64_t n_split = (half ? (Mpad <= 327680 ? BN_W2_BLOCKS : 2 * BN_W2_BLOCKS) : 2048) / (tiles > 0 ? tiles : 1);
+  if (n_split < 1) n_split = 1;
+  int64_t mpb = ceil_div64(ceil_div64(Mpad, n_split), stage) * stage;
+  if (mpb < min_mpb) mpb = min_mpb;
+  if (m_per_block) *m_per_block = mpb;
+  return ceil_div64(Mpad, mpb);                  // <= the first n_split: tiles x splits <= max(tiles, the grid bound above)
+}
+// Bytes of the weight-gradient slab workspace for a point set of Mpad rows: tiles x splits of the largest job list a model can
+// have ((2 L + 12) matrices of ceil(F / tile)^2 tiles each: trunk + analytic-normal jobs + heads), and the skinny jobs'
+// [job][split] slabs.  bn_launch_wgrad checks its actual product against this (BN_REQUIRE: an error, never an overrun).
 static inline size_t bn_wgpart_bytes(const FieldGeom &g, int64_t Mpad, size_t esz) {
   const bool half = esz != 4;
   const int64_t tl = half ? 256 : 128, ft = (g.F + tl - 1) / tl;
   const int64_t tiles_bound = (2 * g.L + 12) * ft * ft;
-  const int64_t by_grid = (half ? 1024 : 2048) + 2 * tiles_bound + 8;
-  const int64_t by_points = tiles_bound * ceil_div64(Mpad, half ? 512 : 256);
-  const int64_t slabs = by_grid < by_points ? by_grid : by_points;
+  // tiles x splits is largest either for the full job list or where the split count peaks (few tiles): both are bounded by
+  // max(tiles, grid bound), and by tiles x the split count of a ONE-tile launch
+  const int64_t grid_bound = half ? 2 * BN_W2_BLOCKS : 2048;
+  int64_t slabs = tiles_bound > grid_bound ? tiles_bound : grid_bound;
+  const int64_t by_points = tiles_bound * bn_wgrad_splits(half, 1, Mpad, nullptr);
+  if (by_points < slabs) slabs = by_points;
   const size_t wg = (size_t)slabs * (size_t)(tl * tl + tl) * 4;
   int64_t sk_splits = ceil_div64(Mpad, g.BM);
   if (sk_splits > 256) sk_splits = 256;

@@ -20,6 +20,12 @@ unsigned int bn_bwd_fault_read(hipStream_t) {
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_bwd_fault), sizeof(unsigned int), 0, hipMemcpyDeviceToHost) != hipSuccess) return 0x80000000u;
   return v;
 }
+// device address of the word on the current device (the forward's launch wrapper mirrors it to the host beside its own, and
+// bn_adam_multi reads both: a faulted step skips its update)
+const unsigned int *bn_bwd_fault_ptr() {
+  void *p = nullptr;
+  return hipGetSymbolAddress(&p, HIP_SYMBOL(g_bwd_fault)) == hipSuccess ? (const unsigned int *)p : nullptr;
+}
 
 BN_PH_DEFINE_READER(bn_debug_phase_read_bwd)
 BN_CLK_DEFINE(bn_debug_clock_read_bwd)
@@ -522,6 +528,11 @@ extern "C" int bn_field_backward_parts(const bn_field_desc *desc, const bn_field
                                        const bn_field_grads *G, int32_t parts, void *stream) {
   BwdArgs a;
   if (int e = bn_make_geom(desc, &a.g)) return e;
+  if (const int f = bn_field_fault_seen()) {
+    bn_set_error("field_backward: an earlier %s launch lost an LDS hand-over (pp_wait timed out): its results are invalid",
+                 (f & 1) ? "forward" : "backward");
+    return BN_ELAUNCH;
+  }
   a.an = desc->normal_an ? 1 : 0;
   BN_REQUIRE(pts && pts->n_points > 0 && packed && out && d_out && stash && G, "field_backward: null argument");
   BN_REQUIRE(parts > 0 && (parts & ~BN_BWD_ALL) == 0, "field_backward: parts=%d", parts);

@@ -25,8 +25,12 @@ struct FwdArgs {
 
 // sticky fault word of the forward kernels (lost LDS hand-over in the barrier-free trunk, field_kernels.h pp_wait)
 __device__ unsigned int g_fwd_fault;
-static unsigned int *g_fwd_fault_host = nullptr;     // pinned mirror, refreshed asynchronously every 64th launch
+static unsigned int *g_fault_host = nullptr;         // pinned mirror of [forward word, backward word], refreshed asynchronously every 64th launch
 static unsigned int g_fwd_launches = 0;
+const unsigned int *bn_fwd_fault_ptr() {
+  void *p = nullptr;
+  return hipGetSymbolAddress(&p, HIP_SYMBOL(g_fwd_fault)) == hipSuccess ? (const unsigned int *)p : nullptr;
+}
 
 BN_PH_DEFINE_READER(bn_debug_phase_read_fwd)
 BN_CLK_DEFINE(bn_debug_clock_read_fwd)
@@ -864,17 +868,21 @@ template <typename T, int MT, int NT, int WAVES, bool KEEP, bool DIR> static int
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
   if (cap == hipStreamCaptureStatusNone && (g_fwd_launches++ & 63u) == 0u) {
-    if (!g_fwd_fault_host && hipHostMalloc((void **)&g_fwd_fault_host, sizeof(unsigned int), hipHostMallocDefault) == hipSuccess)
-      *g_fwd_fault_host = 0u;
-    if (g_fwd_fault_host) (void)hipMemcpyFromSymbolAsync(g_fwd_fault_host, HIP_SYMBOL(g_fwd_fault), sizeof(unsigned int), 0, hipMemcpyDeviceToHost, st);
+    if (!g_fault_host && hipHostMalloc((void **)&g_fault_host, 2 * sizeof(unsigned int), hipHostMallocDefault) == hipSuccess)
+      g_fault_host[0] = g_fault_host[1] = 0u;
+    if (g_fault_host) {
+      (void)hipMemcpyFromSymbolAsync(g_fault_host, HIP_SYMBOL(g_fwd_fault), sizeof(unsigned int), 0, hipMemcpyDeviceToHost, st);
+      // the backward trunk's word rides along (every step launches a forward): both fail the next bn_field_* call
+      if (const unsigned int *b = bn_bwd_fault_ptr()) (void)hipMemcpyAsync(g_fault_host + 1, b, sizeof(unsigned int), hipMemcpyDeviceToHost, st);
+    }
   }
   return 0;
 }
 
-// 0: no fault seen so far (asynchronous view: what the last mirrored copy showed)
-int bn_fwd_fault_seen() { return g_fwd_fault_host && *g_fwd_fault_host != 0u; }
+// 0: no fault seen so far (asynchronous view: what the last mirrored copy showed); bit 0 forward trunk, bit 1 backward trunk
+int bn_field_fault_seen() { return g_fault_host ? (g_fault_host[0] != 0u ? 1 : 0) | (g_fault_host[1] != 0u ? 2 : 0) : 0; }
 
-unsigned int bn_bwd_fault_read(hipStream_t st);   // field_bwd.hip: 1 = a deterministic-mode turn wait timed out
+unsigned int bn_bwd_fault_read(hipStream_t st);   // field_bwd.hip: non-zero = a hand-over of the barrier-free backward trunk was lost
 
 extern "C" int bn_device_faults(unsigned int *faults, void *stream) {
   BN_REQUIRE(faults, "device_faults: null argument");
@@ -885,7 +893,7 @@ extern "C" int bn_device_faults(unsigned int *faults, void *stream) {
   }
   const unsigned int b = bn_bwd_fault_read((hipStream_t)stream);
   if (b & 0x80000000u) { bn_set_error("device_faults: cannot read the backward fault word"); return BN_ELAUNCH; }
-  *faults = (*faults != 0u ? 1u : 0u) | (b ? 2u : 0u);      // bit 0: forward hand-over lost; bit 1: deterministic turn timed out
+  *faults = (*faults != 0u ? 1u : 0u) | (b ? 2u : 0u);      // bit 0: forward trunk hand-over lost; bit 1: backward trunk hand-over lost
   return 0;
 }
 
@@ -893,8 +901,9 @@ int bn_field_forward_impl(const bn_field_desc *desc, const bn_field_params *para
                           const bn_points *pts, float *out, void *stash, int sigma_only, void *stream) {
   FwdArgs a;
   if (int e = bn_make_geom(desc, &a.g)) return e;
-  if (bn_fwd_fault_seen()) {
-    bn_set_error("field_forward: an earlier forward launch lost an LDS hand-over (pp_wait timed out): its results are invalid");
+  if (const int f = bn_field_fault_seen()) {
+    bn_set_error("field_forward: an earlier %s launch lost an LDS hand-over (pp_wait timed out): its results are invalid",
+                 (f & 1) ? "forward" : "backward");
     return BN_ELAUNCH;
   }
   // desc->normal_an only reserves 3 output channels here; bn_field_normals() fills them from the stash

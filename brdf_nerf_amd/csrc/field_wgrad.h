@@ -67,5 +67,5 @@ struct SkinnyArgs {
 int bn_launch_wgrad(WgradArgs &wv, bool bf, bool f16m, int64_t Mpad, float *part, size_t part_bytes, hipStream_t st);
 // Launch the skinny (<= 4 rows) jobs of `sv` with `m_per_block` points per split, and their reduce.
 int bn_launch_skinny(SkinnyArgs &sv, bool bf, bool f16m, int64_t Mpad, int64_t m_per_block, float *part, size_t part_bytes, hipStream_t st);
-// (bn_device_faults bit 1; always 0 since round 4)
+// (bn_device_faults bit 1: a lost hand-over of the barrier-free backward trunk; rounds 1-3 reported their turn-taking mode there)
 unsigned int bn_bwd_fault_read(hipStream_t st);

@@ -708,18 +708,9 @@ int bn_launch_wgrad(WgradArgs &wv, bool bf, bool f16m, int64_t Mpad, float *part
     for (int j = 0; j < wv.n_jobs; ++j)
       wv.tile0[j + 1] = wv.tile0[j] + ((wv.job[j].N + 255) / 256) * ((wv.job[j].K + 255) / 256);
     const int tiles = wv.tile0[wv.n_jobs];
-#ifndef W2_BLOCKS
-#define W2_BLOCKS 256   // tiles x point splits per round of the 256 CUs (one 144 KB workgroup per CU)
-#endif
-    // One round of workgroups up to 327,680 points, two beyond (both passes of a 4096-ray step in one call: 524,288 points).
-    // With the fp32 atomics of rounds 1-3 four rounds were fastest for that launch (half the points per workgroup: a shorter
-    // atomic tail); with slabs every split costs a 257 KB slab written and read once more: 1020 -> 510 workgroups took the
-    // launch from 2.372 to 2.344 ms and its reduce from 0.089 to 0.059 ms (profiles/r04_ab_slab_lambert.txt).
-    int64_t n_split = (Mpad <= 327680 ? W2_BLOCKS : 2 * W2_BLOCKS) / tiles;
-    if (n_split < 1) n_split = 1;
-    int64_t mpb2 = ceil_div64(ceil_div64(Mpad, n_split), W2_BK) * W2_BK;
-    if (mpb2 < 512) mpb2 = 512;
-    n_split = ceil_div64(Mpad, mpb2);
+    static_assert(W2_BK == 64, "bn_wgrad_splits (field.h) rounds the points per workgroup to W2_BK");
+    int64_t mpb2 = 0;
+    const int64_t n_split = bn_wgrad_splits(true, tiles, Mpad, &mpb2);      // (shared with the stash sizing: field.h)
     wv.m_per_block = (int)mpb2;
     wv.n_split = (int)n_split;
     BN_REQUIRE((size_t)tiles * n_split * WG_SLAB256 * sizeof(float) <= part_bytes, "wgrad: %d tiles x %d splits do not fit the slab workspace (%zu bytes)",
@@ -744,12 +735,10 @@ int bn_launch_wgrad(WgradArgs &wv, bool bf, bool f16m, int64_t Mpad, float *part
   for (int j = 0; j < wv.n_jobs; ++j)
     wv.tile0[j + 1] = wv.tile0[j] + ((wv.job[j].N + 127) / 128) * ((wv.job[j].K + 127) / 128);
   const int tiles = wv.tile0[wv.n_jobs];
-  int64_t splits = 2048 / (tiles > 0 ? tiles : 1);
-  if (splits < 1) splits = 1;
-  int64_t mpb = ceil_div64(ceil_div64(Mpad, splits), WG_BK) * WG_BK;
-  if (mpb < 256) mpb = 256;
+  static_assert(WG_BK == 32, "bn_wgrad_splits (field.h) rounds the points per workgroup to WG_BK");
+  int64_t mpb = 0;
+  wv.n_split = (int)bn_wgrad_splits(false, tiles, Mpad, &mpb);
   wv.m_per_block = (int)mpb;
-  wv.n_split = (int)ceil_div64(Mpad, mpb);
   BN_REQUIRE((size_t)tiles * wv.n_split * WG_SLAB128 * sizeof(float) <= part_bytes, "wgrad: %d tiles x %d splits do not fit the slab workspace (%zu bytes)",
              tiles, wv.n_split, part_bytes);
   dim3 grid((unsigned)tiles, (unsigned)wv.n_split);

@@ -59,6 +59,7 @@ struct AdamMultiArgs {
   float b1, b2, eps, wd, gscale;
   int zero_grad;
   char *state;
+  const unsigned int *fault[2];   // the trunks' sticky fault words (nullable): set -> this step's gradient is invalid, no update
 };
 __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMultiArgs A) {
   float *lr_p = (float *)(A.state + 16);
@@ -66,6 +67,10 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMultiArgs A) 
   int *steps = (int *)(A.state + 24);
   double *pw1 = (double *)(A.state + BN_STATE_POW_OFF), *pw2 = pw1 + BN_ADAM_MAX_GROUPS;     // beta^step per group, kept in double
   const float lr = *lr_p;
+  // a lost LDS hand-over in a trunk kernel of this (or an earlier) step: the gradient is invalid - parameters and moments stay as
+  // they are (the host learns of it from the mirrored words / bn_device_faults; inside a replayed graph nothing else would stop
+  // the training from walking on: ADVICE r4)
+  const bool faulted = (A.fault[0] && *A.fault[0] != 0u) || (A.fault[1] && *A.fault[1] != 0u);
   for (int gi = 0; gi < A.n_groups; ++gi) {
     if (!A.active[gi]) continue;
     // bias corrections in double, like torch.optim.Adam (1 - beta2^step loses half its digits in fp32 early on); the powers are
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMultiArgs A) 
         const float denom = sqrtf(vv[e]) / bc2_sqrt + A.eps;
         pp[e] -= (lr / bc1) * (mm[e] / denom);
       }
-      *(f32x4 *)(A.p + i) = pp; *(f32x4 *)(A.m + i) = mm; *(f32x4 *)(A.v + i) = vv;
+      if (!faulted) { *(f32x4 *)(A.p + i) = pp; *(f32x4 *)(A.m + i) = mm; *(f32x4 *)(A.v + i) = vv; }
       if (A.zero_grad) *(f32x4 *)(A.g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
@@ -126,6 +131,7 @@ extern "C" int bn_adam_multi(float *param, float *grad, float *exp_avg, float *e
     if (active[i] && hi[i] - lo[i] > most) most = hi[i] - lo[i];
   }
   a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay; a.gscale = grad_scale; a.zero_grad = zero_grad; a.state = (char *)state;
+  a.fault[0] = bn_fwd_fault_ptr(); a.fault[1] = bn_bwd_fault_ptr();
   // (every workgroup ends on one atomic to the same word, ~12 ns each back to back: 512 of them, not 2048)
   int64_t blocks = ceil_div64(ceil_div64(most, 4), 256);
   blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);

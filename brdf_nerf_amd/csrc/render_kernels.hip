@@ -66,8 +66,12 @@ struct NoiseArgs {
   unsigned int stream;
   int64_t ray_offset;
 };
+// (noise_std < 0, ABI 7: the value lives in the step state the draws come from - f32 at BN_STATE_NOISE_OFF - so a step whose
+// noise decays every step (main.py:246) keeps ONE launch signature and stays inside its captured graph)
 __device__ __forceinline__ float noised(const NoiseArgs &N, float sg, int64_t ray, int S, int s) {
-  return N.rng ? sg + philox_normal(N.rng, N.stream, (unsigned long long)((ray + N.ray_offset) * S + s)) * N.noise_std : sg;
+  if (!N.rng) return sg;
+  const float sd = N.noise_std < 0.f ? ((const float *)N.rng)[BN_STATE_NOISE_OFF / 4] : N.noise_std;
+  return sg + philox_normal(N.rng, N.stream, (unsigned long long)((ray + N.ray_offset) * S + s)) * sd;
 }
 static NoiseArgs make_noise(const bn_noise *n) {
   NoiseArgs a = {nullptr, 0.f, 0u, 0};

@@ -498,6 +498,11 @@ def state_views(state):
     return state[1], f[4], i[6:10], f[L.BN_STATE_LOSS_OFF // 4:L.BN_STATE_LOSS_OFF // 4 + L.BN_STATE_LOSS_SLOTS]
 
 
+def set_state_noise(state, noise_std):
+    """--noise_std of the running step into the device step state (read by the compositing kernels when bn_noise.noise_std < 0)."""
+    state.view(torch.float32)[L.BN_STATE_NOISE_OFF // 4].fill_(float(noise_std))
+
+
 def state_loss_partials(state):
     """The 64 partial sums bn_lambert_tail adds the running step's loss terms to (bn_adam_multi folds them into the ring)."""
     return state.view(torch.float32)[L.BN_STATE_PART_OFF // 4:L.BN_STATE_PART_OFF // 4 + L.BN_STATE_LOSS_SLOTS]
@@ -530,12 +535,13 @@ def rng_normal(state, stream_id, n):
     return x
 
 
-def noise_arg(state, noise_std, stream_id, ray_offset=0):
-    """bn_noise: --noise_std with in-kernel draws (stream `stream_id` of the step state); None when noise_std == 0."""
+def noise_arg(state, noise_std, stream_id, ray_offset=0, from_state=False):
+    """bn_noise: --noise_std with in-kernel draws (stream `stream_id` of the step state); None when noise_std == 0.
+    from_state: the kernels read the value from the step state (set_state_noise) instead of the launch arguments."""
     if not noise_std:
         return None
     n = L.Noise()
-    n.rng, n.noise_std, n.rng_stream, n.ray_offset = state.data_ptr(), float(noise_std), int(stream_id), int(ray_offset)
+    n.rng, n.noise_std, n.rng_stream, n.ray_offset = state.data_ptr(), -1.0 if from_state else float(noise_std), int(stream_id), int(ray_offset)
     n._keep = state
     return n
 

@@ -43,7 +43,9 @@ class FusedTrainer:
         self.nr_lr = model.normal in ("analystic_learned", "learned")
         self.nr_an = model.normal in ("analystic_learned", "analystic")
         self._flatten()
-        self._bufs = {}
+        self._bufs = OrderedDict()      # (name, shape, dtype) -> scratch tensor, see _buf
+        self._touched = None            # list collecting the scratch a step body uses while it is being captured
+        self.max_buf_variants = 3
         # Launch-lean step (round 3; own draws only): in-kernel draws, pass-1 compositing fused with the resampling, the merged
         # sample set composited through its sort index, one-launch Lambertian tail, fold / unfold kernels, one Adam launch for
         # all groups - and, for a step whose inputs keep their addresses, replayed from a captured HIP graph.
@@ -51,6 +53,7 @@ class FusedTrainer:
         self.merge_passes = True        # one output array / stash / backward for both passes (False: two backward launch sets)
         self.overlap_allreduce = True   # world > 1: all-reduce the trunk's gradient while the rest of the backward still runs
         self._row_ray = {}              # MultiBRDF lean step: ray index of every stored sample row
+        self._kind_cache = {}
         self.ray_offset = 0             # index of this rank's first ray in the global batch: in-kernel draws are taken per GLOBAL ray
         self.keep_grads = False         # True: the optimiser launch leaves the step's gradient in flat_grad (tests, diagnostics)
         self.seed_hook = None           # callable(name, tensor): sees / may overwrite "z2" (guided depths) and "d_all" (the gradient rows the
@@ -61,7 +64,7 @@ class FusedTrainer:
         self._graphs, self._sig_seen, self._nf_dev, self._no_graph = OrderedDict(), OrderedDict(), {}, set()
         self._graph_cap_warned = False
         self.state = Fn.new_step_state(self.flat_param.device, torch.initial_seed(), lr)
-        self._rng_step, self._state_lr, self._grads_clean = 0, float(lr), True
+        self._rng_step, self._state_lr, self._grads_clean, self._state_noise = 0, float(lr), True, 0.0
         self._state_adam = [0, 0, 0, 0]
         # sanitize_grads bookkeeping: NaN / Inf elements of d(loss)/d(per-sample outputs) zeroed so far, counted on the
         # device (bn_count_nonfinite, no host round trip); read it with dropped_grad_elems()
@@ -132,10 +135,23 @@ class FusedTrainer:
         return sum(self.dropped_grad_elems())
 
     def _buf(self, key, shape, dtype=torch.float32):
-        b = self._bufs.get(key)
-        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
+        """Scratch buffer `key` of this shape and dtype.  A captured step bakes the ADDRESSES of its scratch into the graph, so
+        a buffer is never dropped because a step of another shape (the short last batch of an epoch, raytable.py) asked for the
+        same name: buffers are kept per (name, shape, dtype), and a capture pins every buffer its body touched (`_touched`,
+        stored in the graph entry).  At most `max_buf_variants` shapes per name stay in the table (least recently used first
+        out); a variant a live graph still references survives its eviction from the table through that reference."""
+        k = (key, tuple(shape), dtype)
+        b = self._bufs.get(k)
+        if b is None:
             b = torch.empty(shape, dtype=dtype, device=self.flat_param.device)
-            self._bufs[key] = b
+            same = [q for q in self._bufs if q[0] == key]
+            for q in same[:max(0, len(same) + 1 - self.max_buf_variants)]:
+                del self._bufs[q]
+            self._bufs[k] = b
+        else:
+            self._bufs.move_to_end(k)
+        if self._touched is not None:
+            self._touched.append(b)
         return b
 
     # ------------------------------------------------------------------ one step
@@ -153,14 +169,14 @@ class FusedTrainer:
         # --MultiBRDF (one BRDF per sample, spsbrdfnerf.py:289-307,350-352) is a lean step when nothing else reads per-sample
         # channels: no regulariser, no sun pass (its irradiance is per sample there) - see _lean_body
         multi = bool(model.MultiBRDF) and apply_brdf
+        kind = self._shade_kind(spec, apply_brdf, cos_irra_on)
         per_sample0 = multi and (any(abs(float(v)) > 0 for v in reg0.values()) or getattr(model, "sun_v", "none") == "analystic"
-                                 or shade_desc(model, args, spec, apply_brdf, cos_irra_on).kind == L.BN_SHADE_LAMBERT)
+                                 or kind == L.BN_SHADE_LAMBERT)
         # the sun-visibility pass (rendering.py:244-259) is a lean step where the reference runs it (gsam_only) and a BRDF shades the
         # ray (its rgb then reads the sun pass through ONE per-ray factor, spsbrdfnerf.py:354); per-sample irradiance of a
         # Lambertian rgb, and the sun pass's own noise draws, keep the general path
         sun_on = getattr(model, "sun_v", "none") == "analystic" and apply_brdf
-        sun_lean = (sun_on and gsam_only and args.noise_std == 0 and args.data == "sat"
-                    and shade_desc(model, args, spec, apply_brdf, cos_irra_on).kind != L.BN_SHADE_LAMBERT)
+        sun_lean = (sun_on and gsam_only and args.noise_std == 0 and args.data == "sat" and kind != L.BN_SHADE_LAMBERT)
         if (self.lean and not self.strict_rng and self.reuse_coarse and not per_sample0
                 and (not sun_on or sun_lean)
                 and rays.dtype == torch.float32 and rays.is_contiguous() and rays.shape[1] >= 8 and S + G <= 512):
@@ -322,6 +338,25 @@ class FusedTrainer:
         return loss.detach(), res["rgb"].detach()
 
     # ------------------------------------------------------------------ launch-lean step
+    def _row_ray_for(self, R, S, G, dev):
+        """MultiBRDF lean step: ray index of every stored sample row ([R S] pass-1 rows, then [R G] guided rows).  Always made
+        OUTSIDE a graph capture (a tensor first allocated inside one would live in that graph's private pool)."""
+        key = (R, S, G)
+        t = self._row_ray.get(key)
+        if t is None:
+            ar = torch.arange(R, device=dev)
+            t = ar.repeat_interleave(S) if G == 0 else torch.cat([ar.repeat_interleave(S), ar.repeat_interleave(G)])
+            self._row_ray[key] = t
+        return t
+
+    def _shade_kind(self, spec, apply_brdf, cos_irra_on):
+        """BN_SHADE_* kind of the ray-level shading for this head set (cached: step() asks on every call)."""
+        key = (spec.key(), bool(apply_brdf), bool(cos_irra_on))
+        k = self._kind_cache.get(key)
+        if k is None:
+            k = self._kind_cache[key] = shade_desc(self.model, self.args, spec, apply_brdf, cos_irra_on).kind
+        return k
+
     def _near_far(self, rays, near_far):
         if near_far is None:
             return rays[0, 6:8]
@@ -338,10 +373,21 @@ class FusedTrainer:
         if float(self.lr) != self._state_lr:
             lr_v.fill_(float(self.lr))
             self._state_lr = float(self.lr)
+        # --noise_std decays after EVERY step (schedule.py:66, as main.py:246): the kernels read it from the device state, so the
+        # launch signature only knows noise on / off (a value in the launch arguments kept such steps eager)
+        nz = self._noise_f32()
+        if nz != self._state_noise:
+            Fn.set_state_noise(self.state, nz)
+            self._state_noise = nz
         want = [self.adam_steps[g] for g, _, _ in self.groups] + [0] * (4 - len(self.groups))
         if want != self._state_adam:
             Fn.set_adam_steps(self.state, want, self.betas)
             self._state_adam = list(want)
+
+    def _noise_f32(self):
+        """--noise_std as the kernels see it (float32): a Python float that underflows float32 is OFF."""
+        import numpy as np
+        return float(np.float32(self.args.noise_std))
 
     def _step_lean(self, spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, apply_theta, cos_irra_on, depth_loss_on,
                    near_far, regularisers, gsam_only=False):
@@ -371,6 +417,9 @@ class FusedTrainer:
         active = [on[g] for g, _, _ in self.groups]
         self._sync_state(on)
         slot = self._rng_step % 64
+        if bool(model.MultiBRDF) and apply_brdf and not lambertian:
+            S_, G_ = args.n_samples, args.guided_samples
+            self._row_ray_for(rays.shape[0], G_ if gsam_only else S_, 0 if gsam_only else G_, rays.device)
         body = lambda: self._lean_body(spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, cos_irra_on, use_ds, nf, reg,
                                        lambertian, active, gsam_only)
         res = None
@@ -380,7 +429,7 @@ class FusedTrainer:
                    nf.data_ptr(), use_ds, tuple(active), float(self.ds_lambda), float(self.lambda_rgb), bool(self.usealldepth),
                    L.deterministic(), int(self.ray_offset), bool(self.keep_grads), bool(self.merge_passes), bool(apply_brdf),
                    bool(cos_irra_on), float(reg.get("hs", 0)), bool(self.sanitize_grads), float(reg.get("nr_an", 0)),
-                   float(reg.get("nr_lr", 0)), bool(gsam_only), float(args.noise_std), float(reg.get("nr_spv", 0)))
+                   float(reg.get("nr_lr", 0)), bool(gsam_only), self._noise_f32() != 0.0, float(reg.get("nr_spv", 0)))
             ent = self._graphs.get(sig)
             if ent is not None:
                 self._graphs.move_to_end(sig)
@@ -400,10 +449,12 @@ class FusedTrainer:
                                           f"least recently used graph is dropped (inputs whose addresses change every step defeat the replay: "
                                           f"keep batches in fixed buffers, e.g. RayTable.next_batch(out=...))")
                             self._graph_cap_warned = True
-                    # keep the inputs alive with the graph: their addresses are baked into it
-                    keep = (rays, rgbs, valid_depth, depths, depth_std, nf)
+                    # keep the inputs AND the scratch alive with the graph: their addresses are baked into it (a step of
+                    # another shape must not free what this graph writes on replay: ADVICE r4)
+                    keep = [rays, rgbs, valid_depth, depths, depth_std, nf]
                     g = torch.cuda.CUDAGraph()
                     torch.cuda.synchronize()
+                    self._touched = []
                     try:
                         with torch.cuda.graph(g):
                             out = body()
@@ -412,9 +463,12 @@ class FusedTrainer:
                         warnings.warn(f"brdf_nerf_amd: HIP graph capture of the training step failed ({type(e).__name__}: {e}); "
                                       f"this step signature runs eagerly")
                         self._no_graph.add(sig)
+                        self._touched = None
                         torch.cuda.synchronize()
                     else:
-                        self._graphs[sig] = (g, out, keep)
+                        keep += self._touched
+                        self._touched = None
+                        self._graphs[sig] = (g, out, tuple(keep))
                         g.replay()            # the capture itself does not execute: this is the step
                         res = out
         if res is None:
@@ -447,11 +501,11 @@ class FusedTrainer:
             merged = self.merge_passes and (R * S) % tile == 0 and not gsam_only
             n_all = R * (S + G)
             has_t = valid_depth is not None
-            # --noise_std (models/spsbrdfnerf.py:57-59, decayed per epoch by main.py:246): in-kernel normal draws, one stream for
+            # --noise_std (models/spsbrdfnerf.py:57-59, multiplied by 0.9 after every step, main.py:246): in-kernel normal draws, one stream for
             # the pass-1 compositing and one for the final compositing of the merged set (the general step draws randn(R, S) and
             # randn(R, S + G) at the same two places)
-            nz1 = Fn.noise_arg(st, args.noise_std, L.BN_RNG_NOISE_COARSE, self.ray_offset)
-            nz2 = Fn.noise_arg(st, args.noise_std, L.BN_RNG_NOISE_MERGED, self.ray_offset)
+            nz1 = Fn.noise_arg(st, self._noise_f32(), L.BN_RNG_NOISE_COARSE, self.ray_offset, from_state=True)
+            nz2 = Fn.noise_arg(st, self._noise_f32(), L.BN_RNG_NOISE_MERGED, self.ray_offset, from_state=True)
             bufs = {"z2": self._buf("z2", (R, G)), "z_all": self._buf("z_all", (R, S + G)),
                     "idx": self._buf("idx", (R, S + G), torch.int64)}
             if gsam_only:
@@ -524,14 +578,9 @@ class FusedTrainer:
             ray_loss = self._buf("ray_loss", (R,)) if det else None
             X = out2 if gsam_only else (out_all if merged else torch.cat([out1, out2], 0))
             n1 = R * S                                   # rows of the first block (gsam_only: all of them, S = G here)
-            key = ("row_ray", R, S, 0 if gsam_only else G)
-            row_ray = self._row_ray.get(key)
-            if row_ray is None:
-                ar = torch.arange(R, device=rays.device)
-                row_ray = ar.repeat_interleave(S) if gsam_only else torch.cat([ar.repeat_interleave(S), ar.repeat_interleave(G)])
-                self._row_ray[key] = row_ray
+            row_ray = self._row_ray_for(R, S, 0 if gsam_only else G, rays.device)     # (made before the capture decision, _step_lean)
             kind = {L.BN_SHADE_RPV: "RPV", L.BN_SHADE_HAPKE: "Hapke", L.BN_SHADE_MICROFACET: "Microfacet"}[
-                shade_desc(model, args, spec, apply_brdf, cos_irra_on).kind]
+                self._shade_kind(spec, apply_brdf, cos_irra_on)]
             c0 = spec.ch_normal_lr if spec.normal_lr else spec.ch_normal_an          # learned wins when both are present
             pad = model.rgb_padding
             sun_d = rays[:, 8:11] if args.data == "sat" else torch.ones_like(rays[:, 0:3])

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BN_ABI_VERSION 6
+#define BN_ABI_VERSION 7
 #define BN_MAX_LAYERS 12
 #define BN_MAX_HEADS 6 /* rgb (+ beta) + up to 3 BRDF heads evaluated together, two per pass */
 
@@ -310,11 +310,13 @@ int bn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg
  *   [16] f32 lr            learning rate read by bn_adam_multi
  *   [20] u32 done          internal (completion ticket of bn_adam_multi)
  *   [24] i32 adam_step[4]  optimiser step count per parameter group (torch.optim.Adam keeps one per parameter)
+ *   [40] f32 noise_std     --noise_std of the running step, read by the compositing kernels when bn_noise.noise_std < 0 (ABI 7)
  *   [64] f32 loss_ring[64] loss of step t at slot t % 64 (written by bn_adam_multi from the partial sums)
  *   [320] f64 beta1_pow[4], [352] f64 beta2_pow[4]   beta^adam_step per group (1.0 at step 0): the bias corrections
  *   [512] f32 loss_part[64] partial sums of the running step's loss (bn_lambert_tail adds ray r's term to slot r % 64;
  *                           bn_adam_multi folds them into the ring and clears them) */
 #define BN_STATE_BYTES 1024
+#define BN_STATE_NOISE_OFF 40
 #define BN_STATE_LOSS_OFF 64
 #define BN_STATE_LOSS_SLOTS 64
 #define BN_STATE_POW_OFF 320
@@ -327,7 +329,10 @@ enum { BN_RNG_COARSE = 1, BN_RNG_GUIDED = 2, BN_RNG_GUIDED_TARGET = 3, BN_RNG_NO
  * in-kernel draws (ABI 6): a standard normal per (ray, sample position) from stream `rng_stream` of the state at `rng`
  * (Box-Muller on a Philox pair), element (ray_offset + r) * S + s of the stream, S = the sample count of the compositing it
  * perturbs (pass 1: the S coarse samples; the final compositing: the depth-sorted S + G set, position = sorted position).
- * NULL, or noise_std == 0: no noise.  The forward and the backward of a step name the same stream and see the same draws. */
+ * NULL, or noise_std == 0: no noise.  noise_std < 0 (ABI 7): the kernels read the value from the step state at `rng` (f32 at byte
+ * BN_STATE_NOISE_OFF): the reference multiplies noise_std by 0.9 after EVERY step (main.py:246), and a value baked into the launch
+ * arguments would give every step a new signature - no graph replay while the noise decays.  The forward and the backward of a
+ * step name the same stream and see the same draws. */
 typedef struct {
   const unsigned long long *rng;
   float noise_std;
@@ -480,9 +485,11 @@ int bn_count_nonfinite(const float *x, int64_t n, unsigned long long *counts, vo
 
 /* Device-side fault word of the fused kernels (bit 0: a wave of the barrier-free forward trunk gave up waiting for an LDS
  * hand-over - never in a correct run; the affected launch's results are invalid; bit 1: the same for the barrier-free trunk of
- * the backward chain (round 4; ABI 3-4 reported their turn-taking deterministic mode there).  The library mirrors bit 0 to the
- * host asynchronously and fails the NEXT bn_field_* call with BN_ELAUNCH once it is set; this call synchronises `stream`
- * and reads it directly. */
+ * the backward chain (round 4; ABI 3-4 reported their turn-taking deterministic mode there).  The library mirrors both bits to
+ * the host asynchronously (every 64th forward launch outside a stream capture) and fails the NEXT bn_field_forward /
+ * bn_field_backward call with BN_ELAUNCH once one is set; bn_adam_multi reads both words on the device and leaves parameters and
+ * moments untouched while one is set (ABI 7: a replayed graph cannot train on an invalid gradient); this call synchronises
+ * `stream` and reads them directly. */
 int bn_device_faults(unsigned int *faults, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

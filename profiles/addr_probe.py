@@ -46,12 +46,13 @@ def main():
             if not key.startswith("stash") or _shift == 0:
                 return _plain(key, shape, dtype)
             n = int(shape[0])
-            b = _tr._bufs.get(key)
-            if b is None or b.numel() != n:
+            k = (key, (n,), dtype)              # FusedTrainer._bufs is keyed by (name, shape, dtype)
+            b = _tr._bufs.get(k)
+            if b is None:
                 big = torch.empty(n + MAX_SHIFT, dtype=torch.uint8, device=dev)
                 keep.append(big)
                 b = big[_shift:_shift + n]
-                _tr._bufs[key] = b
+                _tr._bufs[k] = b
             return b
 
         tr._buf = shifted
@@ -74,7 +75,7 @@ def main():
     keys = ["field_fwd_full", "field_bwd_chain", "wgrad", "skinny_wgrad", "field_adjoint", "field_adjoint_bwd"]
     print(f"config {config} rays {n_rays}: ms per launch, median (min) over {rounds} alternating rounds; stash address of each trainer")
     for name, tr in variants.items():
-        st = [(k, v.data_ptr(), v.numel()) for k, v in tr._bufs.items() if k.startswith("stash")]
+        st = [(k[0], v.data_ptr(), v.numel()) for k, v in tr._bufs.items() if k[0].startswith("stash")]
         addr = " ".join(f"{k}@0x{p:x} (+{p % (2 << 20)} mod 2MiB, {n / 2**30:.2f} GiB)" for k, p, n in st)
         row = " ".join(f"{k} {statistics.median(times[name][k]):.4f} ({min(times[name][k]):.4f})" for k in keys if k in times[name])
         print(f"{name:>20}: {row} | {addr}")

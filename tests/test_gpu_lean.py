@@ -1014,3 +1014,76 @@ def test_lean_step_mixes_with_the_general_path():
     assert tr.adam_steps["base"] == len(seq)
     assert Fn.state_views(tr.state)[2].tolist()[0] == len(seq) or tr._state_adam[0] == len(seq)
     assert int(Fn.state_views(tr.state)[0]) == seq.count(False)
+
+
+@pytest.mark.parametrize("name", ["lambert", "rpv111_nan"])
+def test_graph_replay_survives_batches_of_another_shape(name):
+    """a captured step bakes the addresses of the trainer's scratch into its graph.  An epoch ends in a SHORT
+    batch (raytable.py); the full batches of the next epoch replay the graph captured before it.  The short step must not free
+    (or re-use) what the graph writes: full, short, full batches with use_graph give the parameters of the eager run, bit for bit
+    (deterministic gradients; the draws are keyed by (seed, step))."""
+    from test_gpu_parity import build_model, make_args
+    from brdf_nerf_amd.trainer import FusedTrainer
+    cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16, **_lean_cfgs()[name])
+    brdf = name != "lambert"
+    flags = dict(apply_brdf=brdf, apply_theta=brdf, cos_irra_on=brdf)
+    args = make_args(cfg)
+    g = torch.Generator().manual_seed(11)
+    R, Rs = 64, 24
+    rays, rgbs = _sat_rays(R, g).to(DEV), torch.rand(R, 3, generator=g).to(DEV)
+    rays_s, rgbs_s = rays[:Rs].contiguous(), rgbs[:Rs].contiguous()          # own storage: other addresses, another shape
+    seq = ["full"] * 6 + ["short"] * 2 + ["full"] * 3 + ["short"] + ["full"] * 2
+
+    def run(graph):
+        torch.manual_seed(3)
+        tr = FusedTrainer(build_model(cfg, 4), args, lr=5e-4, strict_rng=False)
+        tr.use_graph, tr.graph_after = graph, 2
+        held = []
+        for i, kind in enumerate(seq):
+            a, b = (rays, rgbs) if kind == "full" else (rays_s, rgbs_s)
+            loss, _ = tr.step(a, b, near_far=(0.0, 2.0), **flags)
+            assert np.isfinite(float(loss)), (i, kind)
+            if kind == "short":
+                # what a caching allocator hands out next is what the short step's re-allocation would have freed: occupy it
+                held.append(torch.full((1 << 20,), float("nan"), device=DEV))
+        return tr.flat_param.clone(), len(tr._graphs)
+
+    p_eager, _ = run(False)
+    p_graph, n_graphs = run(True)
+    assert n_graphs >= 2, n_graphs                                           # the full AND the short signature were captured
+    assert torch.equal(p_eager, p_graph), float((p_eager - p_graph).abs().max())
+
+
+def test_decaying_noise_std_keeps_the_step_on_its_graph():
+    """--noise_std is multiplied by 0.9 after every step (main.py:246, schedule.py).  The kernels read it from the
+    device step state (ABI 7: bn_noise.noise_std < 0), so the step keeps ONE signature while the noise decays - it is captured
+    once and replayed - and the replayed steps equal the eager ones bit for bit."""
+    from test_gpu_parity import build_model, make_args
+    from brdf_nerf_amd.trainer import FusedTrainer
+    cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16)
+    g = torch.Generator().manual_seed(5)
+    R = 48
+    rays, rgbs = _sat_rays(R, g).to(DEV), torch.rand(R, 3, generator=g).to(DEV)
+
+    def run(graph):
+        args = make_args(cfg)
+        args.noise_std = 1.0
+        torch.manual_seed(2)
+        tr = FusedTrainer(build_model(cfg, 4), args, lr=5e-4, strict_rng=False)
+        tr.use_graph, tr.graph_after = graph, 2
+        for _ in range(10):
+            tr.step(rays, rgbs, near_far=(0.0, 2.0))
+            args.noise_std *= 0.9
+        return tr.flat_param.clone(), len(tr._graphs), len(tr._sig_seen)
+
+    p_eager, _, _ = run(False)
+    p_graph, n_graphs, n_sigs = run(True)
+    assert n_graphs == 1 and n_sigs == 1, (n_graphs, n_sigs)
+    assert torch.equal(p_eager, p_graph), float((p_eager - p_graph).abs().max())
+    # and the noise acts: the same run without it ends elsewhere
+    args0 = make_args(cfg)
+    torch.manual_seed(2)
+    tr0 = FusedTrainer(build_model(cfg, 4), args0, lr=5e-4, strict_rng=False)
+    for _ in range(10):
+        tr0.step(rays, rgbs, near_far=(0.0, 2.0))
+    assert not torch.equal(tr0.flat_param, p_graph)

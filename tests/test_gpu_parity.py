@@ -131,7 +131,7 @@ def compare_render(res, g, tag, ray_tol=(1e-4, 2e-5), other_tol=(1e-3, 2e-4)):
 # ------------------------------------------------------------------------------------------------ C ABI smoke
 def test_library_loads_on_gpu():
     from brdf_nerf_amd import _lib
-    assert _lib.lib().bn_abi_version() == 6
+    assert _lib.lib().bn_abi_version() == _lib.BN_ABI_VERSION == 7
 
 
 def test_device_fault_word_stays_clear():

@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(bn_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
     L = _lib.lib()                       # dlopen; resolves every symbol or raises
-    assert L.bn_abi_version() == 6
+    assert L.bn_abi_version() == _lib.BN_ABI_VERSION == 7
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
