@@ -19,12 +19,13 @@ invocation (`speedup_vs_n1_ms`); `--scaling strong` makes the strong shape the h
 Prints ONE JSON line (rank 0).  Timing protocol: W warm-up steps, two steady steps for an estimate, then untimed "settling"
 steps until the chip has run STEADY-STATE steps for >= 1.5 s (DVFS settles over seconds), then EXACTLY K steps between barrier +
 synchronize pairs with no instrumentation inside, then `sustained` (200 more steps, outside `value`); the per-kernel HIP-event
-times and `launches_per_step` come from a SEPARATE eager pass after the timed one; `box_calibration` (N = 1) = ~1 s of vendor bf16
-GEMMs after all of that: a box-speed indicator (boxes of the pool differ by up to 10 % with unchanged code).  `roofline`
+times and `launches_per_step` come from a SEPARATE eager pass after the timed one; `box_calibration_before` / `box_calibration`
+(N = 1) = ~1 s of vendor bf16 GEMMs before the warm-up steps and after all of that: a box-speed indicator (boxes of the pool differ
+by up to 10 % with unchanged code).  `roofline`
 prices the kernel with the largest share of the step, as a fraction of the dense bf16/fp16 MFMA peak both by the
 reference network's algorithmic FLOPs and by the FLOPs the build executes (the linear feats layer is folded into the
 heads); `traffic` / `mfma_busy` come from the committed rocprofv3 PMC pass of the SAME kernel sources
-(profiles/r04_pmc.json, keyed by a hash of csrc/; `traffic_live` false says so), null when the sources have changed since.  `cpu_baseline` times the
+(profiles/r05_pmc.json, keyed by a hash of csrc/; `traffic_live` false says so), null when the sources have changed since.  `cpu_baseline` times the
 CPU oracle (a port of the reference's PyTorch path) on a bounded sample of the same workload.
 """
 import argparse
@@ -102,7 +103,7 @@ def synthetic_batch(R, seed, device):
     return {k: v.to(device) for k, v in batch.items()}
 
 
-def box_calibration(dev, n=8192, seconds=1.0):
+def box_calibration(dev, n=8192, seconds=1.0, when="after the bench"):
     """How fast is THIS box?  The boxes of the pool run the same binary up to 10 % apart (round 4, DESIGN.md section 7:
     MI355X_MICROARCH.md DVFS give-back item 5), so a bench line is read beside a workload that does not depend on this
     repository: ~1 s of back-to-back vendor-library bf16 GEMMs (n x n x n, random operands), after everything that is timed.
@@ -124,17 +125,20 @@ def box_calibration(dev, n=8192, seconds=1.0):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        return {"kind": f"torch.matmul bf16 {n}x{n}x{n} (vendor GEMM library), {reps} back-to-back calls after the bench", "ms": ms,
+        return {"kind": f"torch.matmul bf16 {n}x{n}x{n} (vendor GEMM library), {reps} back-to-back calls {when}", "ms": ms,
                 "tflops": 2.0 * n ** 3 / (ms * 1e-3) / 1e12,
                 "note": "box-speed indicator: compare bench lines of different boxes through it, not a property of this repository"}
     except Exception as e:      # never let the indicator break the bench line
         return {"error": repr(e)}
 
 
-def cpu_baseline(args, rays=1024, seconds_budget=30.0):
+def cpu_baseline(args, rays=512, seconds_budget=30.0):
     """Time the CPU oracle (port of the reference's PyTorch path) on a bounded sample: same network, same S/G, `rays` rays
     per step.  profiles/r02_cpu_cross_timing.txt holds the oracle-vs-imported-reference timing of the same step taken in
-    the build container: the stand-in is within a few per cent of the reference itself."""
+    the build container: the stand-in is within a few per cent of the reference itself.
+    Bounded (round 4's sweep spent ~150 s in a 256-thread leg): 8 / 16 / min(allowed, 64) threads, each leg
+    one warm-up step (itself timed, and taken as the leg's result when it alone exceeds the leg's budget) and at most two steps
+    inside seconds_budget / 3."""
     from oracle.config import FieldConfig
     from oracle import render as ORD, losses as OL
     allowed = os.cpu_count() or 1
@@ -156,35 +160,34 @@ def cpu_baseline(args, rays=1024, seconds_budget=30.0):
         loss.backward()
         opt.step()
 
-    # Thread sweep (round 3 reported 181 rays/s on 16 threads of the GPU box against 232 on the 8 threads of
-    # the build container): the step is timed with 8 threads, with 16 and with every core the process may use; `value` is the
-    # best of them, `cores` the threads it used, `sweep` keeps all three.
-    sweep = {}
-    for th in sorted({min(8, allowed), min(16, allowed), allowed}):
+    leg = seconds_budget / 3
+    sweep, t_all = {}, time.perf_counter()
+    for th in sorted({min(8, allowed), min(16, allowed), min(64, allowed)}):
         torch.set_num_threads(th)
-        step()                                                   # warm-up (allocator, thread pool)
         t0 = time.perf_counter()
-        n = 0
-        while True:
+        step()                                                   # warm-up (allocator, thread pool)
+        warm = time.perf_counter() - t0
+        if warm > leg:                                           # a leg this slow is not the best one: its warm-up step is its sample
+            sweep[th] = (rays / warm, 1, True)
+            continue
+        t0, n = time.perf_counter(), 0
+        while n < 2 and (n == 0 or (time.perf_counter() - t0) * (n + 1) / n + warm < leg):
             step()
             n += 1
-            if time.perf_counter() - t0 > seconds_budget / 3 * 0.6 or n >= 3:
-                break
-        sweep[th] = (rays * n / (time.perf_counter() - t0), n)
+        sweep[th] = (rays * n / (time.perf_counter() - t0), n, False)
     cores = max(sweep, key=lambda k: sweep[k][0])
-    n = sweep[cores][1]
-    dt = rays * n / sweep[cores][0]
+    rate, n, warm_only = sweep[cores]
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
             cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.lower().startswith("model name")), "unknown")
     except OSError:
         pass
-    return dict(value=rays * n / dt, unit="rays/s", cores=cores, kind="port", cpu_model=cpu_model, threads=cores,
+    return dict(value=rate, unit="rays/s", cores=cores, kind="port", cpu_model=cpu_model, threads=cores,
                 host_logical_cpus=os.cpu_count(), allowed_cpus=allowed,
-                sweep={str(k): round(v[0], 1) for k, v in sweep.items()},
-                sample=f"{n} training steps of {rays} rays x {args.n_samples}+{args.guided_samples} samples (same network, fp32, "
-                       f"torch CPU oracle, {cores} threads) after 1 warm-up step",
+                sweep={str(k): round(v[0], 1) for k, v in sweep.items()}, seconds=round(time.perf_counter() - t_all, 1),
+                sample=f"{n} training step(s) of {rays} rays x {args.n_samples}+{args.guided_samples} samples (same network, fp32, "
+                       f"torch CPU oracle, {cores} threads)" + (" = the leg's first step" if warm_only else " after 1 warm-up step"),
                 cross_timing="profiles/r02_cpu_cross_timing.txt (oracle vs the imported reference, build container)")
 
 
@@ -194,10 +197,13 @@ from brdf_nerf_amd.build import source_hash  # noqa: E402  (key of the committed
 def pmc_record(config, dtype):
     """Per-kernel counters of the committed rocprofv3 PMC passes (profiles/pmc_collect.sh -> profiles/r03_pmc.json), or
     ({}, reason) when there is none for this workload or the kernel sources have changed since it was taken."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc.json")
-    if not os.path.exists(path):
+    # the newest committed record whose key matches the sources wins (one per round: profiles/r05_pmc.json, profiles/history/...)
+    cands = [os.path.join(ROOT, "profiles", "r05_pmc.json"), os.path.join(ROOT, "profiles", "history", "r04_pmc.json")]
+    cands = [c for c in cands if os.path.exists(c)]
+    if not cands:
         return {}, "no PMC pass committed"
-    rec = json.load(open(path))
+    recs = [json.load(open(c)) for c in cands]
+    rec = next((r for r in recs if r.get("source_hash") == source_hash()), recs[0])
     if rec.get("source_hash") != source_hash():
         return {}, f"PMC pass is of other kernel sources ({rec.get('source_hash')}): re-run profiles/pmc_collect.sh"
     runs = rec.get("workloads", {})
@@ -361,6 +367,8 @@ def main():
         dt_, out = timed(fn, steps)
         return dt_, out, n_settle
 
+    # box-speed indicator BEFORE anything is timed (and again after everything, below): both are printed
+    calib_before = box_calibration(dev, when="before the warm-up steps") if world == 1 else None
     dt, (loss, _), settle = settle_then_time(run, a.warmup, a.steps)
     # ---- sustained: a longer run after the timed region, outside `value` (does the step hold its time?)
     sustained = None
@@ -458,6 +466,10 @@ def main():
     flops_ref = sum(fpp[False][n] * pts[n] for n in fpp[False])
     step_s = dt / a.steps
     rays_step = world * rays_gpu
+    # SURVEY.md section 8(d), per train ray of the reference-default pipeline: S sigma-only forwards + (S + G) x 3 x (full forward
+    # [+ the analytic-normal adjoint]): 2.002 GFLOP (Lambertian), 3.761 GFLOP (RPV111 + analytic normals, fused accounting)
+    per_ray_ref = a.samples * fpp[False]["field_fwd_sigma"] + (a.samples + a.guided) * 3 * (
+        fpp[False]["field_fwd_full"] + fpp[False].get("field_adjoint", 0))
     line = {
         "metric": METRIC, "value": rays_step * a.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
@@ -469,6 +481,11 @@ def main():
                    "backend": (backend if world > 1 else None), "settle_steps": settle},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
                      "frac": mfma[dom]["tflops"] / peak, "frac_algorithmic": mfma[dom]["tflops"] / peak,
+                     # the OTHER accounting, never to be confused with the kernel fraction: rays/s x SURVEY section 8(d)'s FLOP per
+                     # train ray of the REFERENCE pipeline (pass 1 sigma-only + pass 2 on all S + G samples, x 3 for the backward:
+                     # 2.002 GFLOP per Lambertian ray) / peak - the build evaluates every sample once, so it executes less
+                     "frac_per_ray_accounting": per_ray_ref * rays_step / step_s / 1e12 / peak,
+                     "flop_per_ray_reference_accounting": per_ray_ref,
                      "achieved_executed": mfma[dom]["tflops_executed"], "frac_executed": mfma[dom]["tflops_executed"] / peak,
                      "mfma_busy": dpm.get("mfma_busy"), "traffic": dpm.get("hbm_bytes"),
                      "traffic_unit": "bytes/launch", "traffic_live": False, "traffic_source": pmc_note,
@@ -496,7 +513,8 @@ def main():
         "launches_per_step": sum(k["launches_per_step"] for k in kernels.values()),
     }
     if world == 1:
-        line["box_calibration"] = box_calibration(dev)
+        line["box_calibration"] = box_calibration(dev, when="after everything that is timed")
+        line["box_calibration_before"] = calib_before
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
     sys.stdout.flush()

@@ -15,6 +15,8 @@
 //     BN_NO_NT_STASH         plain instead of non-temporal stash stores / loads
 //     BN_NO_PINGPONG, BN_BWD_NO_PINGPONG        the trunks under workgroup barriers (rounds 1-3) instead of LDS hand-overs
 //     BN_PP_LOOP_NKS         the trunks' half-GEMMs as loops with tail steps (rounds 1-4) instead of straight-line code
+//     BN_PP_SPLIT            the trunks' layer GEMM as two half-GEMMs with a weight prologue each (rounds 1-4) instead of one stream
+//     BN_NO_BUFW             the trunks' weight fragments by global loads with vector addresses (rounds 1-4) instead of buffer loads
 //     BN_FWD_DEPTH_TRAIN=<n> weight-fragment prefetch depth of the training forward (default 6)
 //     BN_BWD_DEPTH=<n>       ... of the backward / adjoint chains under barriers (default 2)
 //     BN_BWD_PP_DEPTH=<n>    ... of the barrier-free backward trunk (default 6)
@@ -87,6 +89,16 @@
 #define BN_F_PP_LOOP_NKS "BN_PP_LOOP_NKS "
 #else
 #define BN_F_PP_LOOP_NKS ""
+#endif
+#ifdef BN_PP_SPLIT
+#define BN_F_PP_SPLIT "BN_PP_SPLIT "
+#else
+#define BN_F_PP_SPLIT ""
+#endif
+#ifdef BN_NO_BUFW
+#define BN_F_NO_BUFW "BN_NO_BUFW "
+#else
+#define BN_F_NO_BUFW ""
 #endif
 #ifdef BN_FWD_DEPTH_TRAIN
 #define BN_F_FWD_DEPTH_TRAIN "BN_FWD_DEPTH_TRAIN "
@@ -174,6 +186,6 @@
 // the same defines to every file
 #define BN_BUILD_FLAGS_STRING                                                                                              \
   BN_F_PHASE_TIMING BN_F_PHASE_TIMING_WGRAD BN_F_CLOCK_STAMP BN_F_CLOCK_STAMP_WGRAD BN_F_TIMELINE BN_F_GEMM_PRIO          \
-  BN_F_PRIO_YOUNG BN_F_NO_NT_STASH BN_F_NO_PINGPONG BN_F_BWD_NO_PINGPONG BN_F_PP_LOOP_NKS BN_F_FWD_DEPTH_TRAIN            \
+  BN_F_PRIO_YOUNG BN_F_NO_NT_STASH BN_F_NO_PINGPONG BN_F_BWD_NO_PINGPONG BN_F_PP_LOOP_NKS BN_F_PP_SPLIT BN_F_NO_BUFW BN_F_FWD_DEPTH_TRAIN            \
   BN_F_BWD_DEPTH BN_F_BWD_PP_DEPTH BN_F_BWD_D_AT BN_F_HEAD_WIDE BN_F_NO_FLAT_COMPOSITE BN_F_DPH BN_F_SKINNY_SPLITS        \
   BN_F_W2_BLOCKS BN_F_WGRAD_BIAS_INLINE BN_F_PROBE_NO_A BN_F_PROBE_NO_B BN_F_PROBE_NO_D BN_F_PROBE_NO_RIDE BN_F_ABLATION_BUILD

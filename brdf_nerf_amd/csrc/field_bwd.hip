@@ -462,6 +462,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
         if (grp == 1) pp_wait(RD + 0, 4 * (it + 1), &g_bwd_fault);    // group 0 is done with its phase 1 of this layer: the lag
         BN_PH(12)
         __builtin_amdgcn_s_setprio(1);
+#ifdef BN_PP_SPLIT      // A/B switch (results unchanged): two half-GEMMs, each with its own weight prologue (round 4)
         gemm_range<T, MT, NT, DP | BN_PP_NKS>(acc, packed + off, KSF, 0, half, ACT, LDA, lane, none);
         BN_PH(9)
         pp_signal(RD + 0 + grp, lane);
@@ -469,6 +470,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
         BN_PH(12)
         if (BN_BWD_D_AT == 1) load_D(lo, 0, NPRE);
         gemm_range<T, MT, NT, DP | BN_PP_NKS>(acc, packed + off, KSF, half, half, ACT, LDA, lane, none);
+#else
+        if constexpr (sizeof(T) == 2) {        // (PING implies a 16-bit mode)
+          (void)half; (void)none;
+          gemm_trunk<T, MT, NT, (DP & (BN_GEMM_AFFINE - 1)), 32, 16>(acc, packed + off, KSF, ACT, LDA, lane, [&]() {
+            pp_signal(RD + 0 + grp, lane);
+            pp_wait(WR + 1, 4 * it, &g_bwd_fault);                    // half 1
+            if (BN_BWD_D_AT == 1) load_D(lo, 0, NPRE);
+          });
+        }
+#endif
         __builtin_amdgcn_s_setprio(0);
         pp_signal(RD + 2 + grp, lane);
         if (BN_BWD_D_AT == 2) load_D(lo, 0, NPRE);

@@ -381,6 +381,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
           BN_PH(12)
           BN_TL(1)
           __builtin_amdgcn_s_setprio(BN_GEMM_PRIO);
+#ifdef BN_PP_SPLIT      // A/B switch (results unchanged): two half-GEMMs, each with its own weight prologue (rounds 1-4)
           gemm_range<T, MT, NT, DP | BN_PP_NKS>(acc, w_h, KSF, 0, half, ACT, LDA, lane, none);
           BN_PH(1)
           BN_TL(2)
@@ -389,6 +390,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
           BN_PH(13)
           BN_TL(3)
           gemm_range<T, MT, NT, DP | BN_PP_NKS>(acc, w_h, KSF, half, half, ACT, LDA, lane, none);
+#else
+          if constexpr (sizeof(T) == 2) {      // (PING implies a 16-bit mode; the fp32 instantiation never gets here)
+            (void)half; (void)none;
+            gemm_trunk<T, MT, NT, (DP & (BN_GEMM_AFFINE - 1)), 32, 16>(acc, w_h, KSF, ACT, LDA, lane, [&]() {
+              BN_TL(2)
+              pp_signal(RD + 0 + grp, lane);
+              pp_wait(WR + 1, 4 * l, &g_fwd_fault);                   // half 1
+              BN_TL(3)
+            });
+          }
+#endif
           __builtin_amdgcn_s_setprio(0);
           BN_TL(4)
           pp_signal(RD + 2 + grp, lane);

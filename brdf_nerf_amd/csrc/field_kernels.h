@@ -374,6 +374,72 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
       side.at(d & 1);
     }
 }
+// The barrier-free trunks' GEMM over a WHOLE layer (NT == 2 means F = 512: NKS = 32 k-steps) as one straight-line weight stream
+// (round 5).  `mid()` runs between k-steps MID - 1 and MID: the hand-over of the two column halves (signal "done reading half
+// 0", wait for half 1) - the weight-fragment ring keeps running through it (rounds 1-4: two half-GEMMs, each with its own
+// prologue of DEPTH exposed L2 round trips behind the hand-over wait), only the LDS look-ahead read of step MID waits for it.
+// The weight fragments are BUFFER loads: descriptor = the wave's packed block (wave-uniform), one lane-offset register for the
+// whole kernel, everything else in the scalar offset - the global-load form spent two 64-bit vector adds per k-step on its
+// addresses and, unrolled, spilled scalar registers to vector lanes (v_readlane: 26 + 42 per layer in the ISA of the looped /
+// half-GEMM forms).  Loads are the compiler's builtin (counted in its vmcnt bookkeeping), not inline asm:
+// the store-data hazard of stash_store_buf is a store's.
+template <typename T, int MT, int NTW, int DEPTH, int NKS, int MID, typename Mid>
+__device__ __forceinline__ void gemm_trunk(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb, int lane,
+                                           Mid &&mid) {
+  typedef typename Elem<T>::frag frag;
+  static_assert(sizeof(frag) == 16, "16-bit modes only: one 16-byte fragment piece per lane");
+  static_assert(MID > 0 && MID < NKS && DEPTH <= MID, "the ring must not wrap inside the prologue");
+  const int r = lane & 31, h = lane >> 5;
+  const T *bm[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) bm[mt] = bsrc + (size_t)(r + 32 * mt) * ldb + 8 * h;
+  const auto rs = stash_rsrc(wp);
+  const int voff = lane * 16;
+  auto ldA = [&](int nt, int ks) {
+#ifdef BN_NO_BUFW      // A/B switch (results unchanged): global loads with 64-bit vector addresses, as in rounds 1-4
+    return gld_frag<T>(wp + (size_t)lane * 8 + ((size_t)nt * KS + ks) * 512);
+#else
+    return __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (nt * KS + ks) * (512 * (int)sizeof(T)), 0));
+#endif
+  };
+  frag A[DEPTH][NTW], Bc[MT];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) A[d][nt] = ldA(nt, d);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) Bc[mt] = lds_frag<T>(bm[mt]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < NKS; ++j) {
+    const bool ahead = j + 1 < NKS && j + 1 != MID;      // (compile-time after unrolling)
+    frag Bn[MT];
+    if (ahead) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) Bn[mt] = lds_frag<T>(bm[mt] + (j + 1) * 16);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) mma32(acc[nt][mt], A[j % DEPTH][nt], Bc[mt]);
+    if (ahead) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) Bc[mt] = Bn[mt];
+    }
+    if (j + DEPTH < NKS) {
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) A[j % DEPTH][nt] = ldA(nt, j + DEPTH);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (j + 1 == MID) {
+      mid();
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) Bc[mt] = lds_frag<T>(bm[mt] + MID * 16);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 template <typename T, int MT, int NTW, int DEPTH, typename Side>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb,
                                          int lane, Side &side) {

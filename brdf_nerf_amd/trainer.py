@@ -56,8 +56,9 @@ class FusedTrainer:
         self._kind_cache = {}
         self.ray_offset = 0             # index of this rank's first ray in the global batch: in-kernel draws are taken per GLOBAL ray
         self.keep_grads = False         # True: the optimiser launch leaves the step's gradient in flat_grad (tests, diagnostics)
-        self.seed_hook = None           # callable(name, tensor): sees / may overwrite "z2" (guided depths) and "d_all" (the gradient rows the
-                                        # field backward starts from) of a launch-lean step (tests; such steps are not captured)
+        self.seed_hook = None           # callable(name, tensor): sees / may overwrite "z2" (guided depths), "out_all" (the per-sample field
+                                        # outputs of both passes, merged step) and "d_all" (the gradient rows the field backward starts
+                                        # from) of a launch-lean step (tests, profiles/diag_c5_rows.py; such steps are not captured)
         self.use_graph = True
         self.graph_after = 3            # eager steps with an unchanged signature before the step is captured
         self.max_graphs = 16            # captured steps kept (least recently used evicted; each owns a private memory pool)
@@ -558,6 +559,8 @@ class FusedTrainer:
                     self.seed_hook("z2", z2)
                 if merged:
                     Fn.field_forward_raw(spec, named, packed, out_all, stash_all, rays=rays, z=z2, point_offset=R * S, total_points=n_all)
+                    if self.seed_hook is not None:   # (and the per-sample field outputs [R S + R G][C] of both passes: diagnostics)
+                        self.seed_hook("out_all", out_all)
                 else:
                     out2 = self._buf("out2", (R * G, C))
                     stash2 = self._buf("stash2", (Fn.field_stash_bytes(spec, R * G),), torch.uint8)

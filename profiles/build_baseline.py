@@ -21,6 +21,8 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         subprocess.check_call(f"git -C {ROOT} archive {commit} brdf_nerf_amd/csrc brdf_nerf_amd/build.py include | tar -x -C {td}", shell=True)
         shutil.copy(os.path.join(ROOT, "brdf_nerf_amd", "csrc", "error.cpp"), os.path.join(td, "brdf_nerf_amd", "csrc", "error.cpp"))
+        if not os.path.exists(os.path.join(td, "brdf_nerf_amd", "csrc", "diag.h")):     # (round 5: error.cpp takes bn_build_flags from diag.h)
+            shutil.copy(os.path.join(ROOT, "brdf_nerf_amd", "csrc", "diag.h"), os.path.join(td, "brdf_nerf_amd", "csrc", "diag.h"))
         old_hdr = open(os.path.join(td, "include", "brdfnerf_hip.h")).read()
         if "bn_build_flags" not in old_hdr:     # declare what the new error.cpp defines, keep the old structs
             old_hdr = old_hdr.replace("const char *bn_last_error(void);", "const char *bn_last_error(void);\nconst char *bn_build_flags(void);")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 PMC passes (one counter group per pass, --kernel-trace only) over a few training steps of the bench workloads,
-# summarised per kernel into gpurun_out/r04_pmc.json, which bench.py reads (copy it to profiles/r04_pmc.json) for
+# summarised per kernel into gpurun_out/r05_pmc.json, which bench.py reads (copy it to profiles/r05_pmc.json) for
 # roofline.traffic / roofline.mfma_busy.  The record carries a hash of csrc/: bench.py ignores it once the kernels change.
 #   gpurun -- 'bash profiles/pmc_collect.sh [workload ...]'     workload = <config>_<dtype>, default: lambert_bf16 rpv_nan_bf16
 cd /tmp && export TMPDIR=/tmp
@@ -18,4 +18,4 @@ for wl in $WL; do
     echo "pass $i of $wl done" >> $R/gpurun_out/pmc_collect.progress
   done
 done
-python3 $R/profiles/pmc_parse.py /tmp $R/gpurun_out/r04_pmc.json $WL
+python3 $R/profiles/pmc_parse.py /tmp $R/gpurun_out/r05_pmc.json $WL
