@@ -27,6 +27,9 @@
 //     SKINNY_SPLITS=<n>      point splits of skinny_wgrad_kernel (default 256)
 //     BN_W2_BLOCKS=<n>       wgrad256: tiles x point splits per round of the 256 CUs (default 256)
 //     BN_WGRAD_BIAS_INLINE   round 4's wgrad256: bias column sums computed by every workgroup (round 5: only where they are stored)
+//   kind D (numerical diagnostic, results CHANGED on purpose):
+//     BN_DIAG_D8_IN_F32      the fp32 mode sends its activation derivatives through the 16-bit modes' 8-bit codec (Siren layers):
+//                            what the 8-bit D stash alone does to the analytic normals (profiles/diag_c5_rows.py --d8lib=...)
 //   kind P (timing probe, RESULTS WRONG - never ship):
 //     BN_PROBE_NO_A, BN_PROBE_NO_B   chain GEMM without its weight / LDS fragment traffic (profiles/probe_gemm_rate.py)
 //     BN_PROBE_NO_D                  backward chain without its derivative loads
@@ -156,6 +159,11 @@
 #else
 #define BN_F_WGRAD_BIAS_INLINE ""
 #endif
+#ifdef BN_DIAG_D8_IN_F32
+#define BN_F_DIAG_D8_IN_F32 "BN_DIAG_D8_IN_F32 "
+#else
+#define BN_F_DIAG_D8_IN_F32 ""
+#endif
 #ifdef BN_PROBE_NO_A
 #define BN_F_PROBE_NO_A "BN_PROBE_NO_A "
 #else
@@ -188,4 +196,4 @@
   BN_F_PHASE_TIMING BN_F_PHASE_TIMING_WGRAD BN_F_CLOCK_STAMP BN_F_CLOCK_STAMP_WGRAD BN_F_TIMELINE BN_F_GEMM_PRIO          \
   BN_F_PRIO_YOUNG BN_F_NO_NT_STASH BN_F_NO_PINGPONG BN_F_BWD_NO_PINGPONG BN_F_PP_LOOP_NKS BN_F_PP_SPLIT BN_F_NO_BUFW BN_F_FWD_DEPTH_TRAIN            \
   BN_F_BWD_DEPTH BN_F_BWD_PP_DEPTH BN_F_BWD_D_AT BN_F_HEAD_WIDE BN_F_NO_FLAT_COMPOSITE BN_F_DPH BN_F_SKINNY_SPLITS        \
-  BN_F_W2_BLOCKS BN_F_WGRAD_BIAS_INLINE BN_F_PROBE_NO_A BN_F_PROBE_NO_B BN_F_PROBE_NO_D BN_F_PROBE_NO_RIDE BN_F_ABLATION_BUILD
+  BN_F_W2_BLOCKS BN_F_WGRAD_BIAS_INLINE BN_F_DIAG_D8_IN_F32 BN_F_PROBE_NO_A BN_F_PROBE_NO_B BN_F_PROBE_NO_D BN_F_PROBE_NO_RIDE BN_F_ABLATION_BUILD

@@ -567,8 +567,16 @@ template <typename T> __device__ __forceinline__ DHalf<T> dhalf_make(const float
     r.w[0] = d8_pack4(c[0], c[1], c[2], c[3]);
     r.w[1] = d8_pack4(c[4], c[5], c[6], c[7]);
   } else {
+#ifdef BN_DIAG_D8_IN_F32      // diagnostic (profiles/diag_c5_rows.py --d8lib): the fp32 mode with its derivatives sent through the 8-bit codec
+    float q[8];
+    d8_unpack4(d8_pack4(c[0], c[1], c[2], c[3]), 256.f / 32767.f, -127.5f * (256.f / 32767.f), *(float (*)[4])&q[0]);
+    d8_unpack4(d8_pack4(c[4], c[5], c[6], c[7]), 256.f / 32767.f, -127.5f * (256.f / 32767.f), *(float (*)[4])&q[4]);
+    r.v[0] = f32x4{q[0] * scale, q[1] * scale, q[2] * scale, q[3] * scale};
+    r.v[1] = f32x4{q[4] * scale, q[5] * scale, q[6] * scale, q[7] * scale};
+#else
     r.v[0] = f32x4{c[0] * scale, c[1] * scale, c[2] * scale, c[3] * scale};
     r.v[1] = f32x4{c[4] * scale, c[5] * scale, c[6] * scale, c[7] * scale};
+#endif
   }
   return r;
 }

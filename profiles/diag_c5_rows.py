@@ -12,7 +12,10 @@ the guided depths of the fp32 run are handed to the 16-bit run) and compares, st
 then swaps ONE channel group of the fp32 run's per-sample outputs for the 16-bit run's and reports what that alone does to the
 gradient rows: the quantity that carries the divergence.
 
-    python profiles/diag_c5_rows.py [--name=c5_microfacet_fp16] [--pre=150]
+    python profiles/diag_c5_rows.py [--name=c5_microfacet_fp16] [--pre=150] [--d8lib=brdf_nerf_amd/build/BN_DIAG_D8_IN_F32/libbrdfnerf_hip.so]
+
+--d8lib: a library built with -DBN_DIAG_D8_IN_F32 (the fp32 mode with its activation derivatives sent through the 8-bit codec of the
+16-bit modes): one more run, fp32 arithmetic + 8-bit D, which separates the 8-bit derivative stash from the 16-bit activations.
 """
 import os
 import sys
@@ -98,7 +101,18 @@ def main():
     low = run(dtype, {"z2": lambda d: d.copy_(z2_ref)})
     w16 = run("fp32", {"z2": lambda d: d.copy_(z2_ref)}, round_w=True)
     print(f"whole flat gradient cosine vs fp32: {dtype} {cos(low['grad'], ref['grad']):.5f}, fp32 on {dtype}-rounded weights (referee) {cos(w16['grad'], ref['grad']):.5f}")
-    for tag, other in ((dtype, low), ("referee", w16)):
+    others = [(dtype, low), ("referee", w16)]
+    if "d8lib" in opt:
+        from brdf_nerf_amd import _lib as L
+        hv = L.load(os.path.abspath(opt["d8lib"]))
+        assert b"BN_DIAG_D8_IN_F32" in hv.bn_build_flags(), hv.bn_build_flags()
+        hv.bn_set_deterministic(1)
+        h0 = L.use(hv)
+        d8 = run("fp32", {"z2": lambda d: d.copy_(z2_ref)})
+        L.use(h0)
+        print(f"whole flat gradient cosine vs fp32: fp32 arithmetic with the 8-bit D codec {cos(d8['grad'], ref['grad']):.5f}")
+        others.append(("fp32 + 8-bit D", d8))
+    for tag, other in others:
         print(f"--- {tag} vs fp32, same points")
         oa, ob = other["seen"]["out_all"].view(-1, C), ref["seen"]["out_all"].view(-1, C)
         for g, (a, b) in groups.items():
