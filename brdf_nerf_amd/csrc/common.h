@@ -62,7 +62,15 @@ int bn_deterministic();
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t bn_esize(int dtype) { return dtype == BN_F32 ? 4 : 2; }
 static inline bool bn_half(int dtype) { return dtype != BN_F32; }   // 16-bit throughput modes (bf16, fp16)
-static inline size_t bn_dsize(int dtype) { return dtype == BN_F32 ? 4 : 1; }   // bytes per element of the D_l / DG stashes (Elem<T>::kD8)
+// bytes per element of the D_l / DG stashes (field_kernels.h, "the derivative stash"): fp32 in the parity mode, fp16 in the fp16 mode of
+// a model with analytic normals (round 5), 8-bit fixed point otherwise
+static inline size_t bn_dsize(int dtype, int normal_an) { return dtype == BN_F32 ? 4 : ((dtype == BN_F16 && normal_an) ? 2 : 1); }
+struct DK8 {};
+struct DK16 {};
+struct DK32 {};
+template <typename T, bool D16> struct DKind { typedef DK8 type; };
+template <bool D16> struct DKind<float, D16> { typedef DK32 type; };
+template <> struct DKind<_Float16, true> { typedef DK16 type; };
 
 // ---------------------------------------------------------------- MFMA element traits
 // A "fragment" is 8 consecutive k-elements of one row (A) / column (B) held by lane (r = lane&31,
@@ -78,8 +86,7 @@ template <> struct Elem<bf16> {
   // the forward epilogue's registers: no row-major copy riding in the next GEMM.  The weight-gradient kernel stages native
   // chunks (field_bwd.hip, w2_body<.., BNAT>); the fp32 parity mode keeps the row-major stash.
   static constexpr bool kNativeY = true;
-  // D_l = d act / d z is stashed as 8-bit fixed point (field_kernels.h, DTile): half the bytes of a 16-bit image
-  static constexpr bool kD8 = true;
+  // (D_l = d act / d z is stashed as 8-bit fixed point, DKind<T, D16> below / field_kernels.h: half the bytes of a 16-bit image)
   static constexpr int kBM = 128;   // points per workgroup tile
   static constexpr int kPad = 8;    // LDS row pad (elements) = 16 B
   static constexpr int kU = 2;      // k-steps per prefetch block
@@ -93,7 +100,6 @@ template <> struct Elem<f16> {
   typedef f16x4 vec4;
   typedef bf16 wide;
   static constexpr bool kNativeY = true;
-  static constexpr bool kD8 = true;
   static constexpr int kBM = 128;
   static constexpr int kPad = 8;
   static constexpr int kU = 2;
@@ -104,7 +110,6 @@ template <> struct Elem<float> {
   typedef f32x4 vec4;
   typedef float wide;
   static constexpr bool kNativeY = false;
-  static constexpr bool kD8 = false;    // parity mode: D_l kept in fp32
   static constexpr int kBM = 64;
   static constexpr int kPad = 4;
   static constexpr int kU = 2;

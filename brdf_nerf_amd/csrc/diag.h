@@ -16,6 +16,7 @@
 //     BN_NO_PINGPONG, BN_BWD_NO_PINGPONG        the trunks under workgroup barriers (rounds 1-3) instead of LDS hand-overs
 //     BN_PP_LOOP_NKS         the trunks' half-GEMMs as loops with tail steps (rounds 1-4) instead of straight-line code
 //     BN_PP_SPLIT            the trunks' layer GEMM as two half-GEMMs with a weight prologue each (rounds 1-4) instead of one stream
+//     BN_NO_FIXED_FULL       head passes / sigma head / the backward's top layer in the looped form (round 4) instead of straight-line
 //     BN_NO_BUFW             the trunks' weight fragments by global loads with vector addresses (rounds 1-4) instead of buffer loads
 //     BN_FWD_DEPTH_TRAIN=<n> weight-fragment prefetch depth of the training forward (default 6)
 //     BN_BWD_DEPTH=<n>       ... of the backward / adjoint chains under barriers (default 2)
@@ -97,6 +98,11 @@
 #define BN_F_PP_SPLIT "BN_PP_SPLIT "
 #else
 #define BN_F_PP_SPLIT ""
+#endif
+#ifdef BN_NO_FIXED_FULL
+#define BN_F_NO_FIXED_FULL "BN_NO_FIXED_FULL "
+#else
+#define BN_F_NO_FIXED_FULL ""
 #endif
 #ifdef BN_NO_BUFW
 #define BN_F_NO_BUFW "BN_NO_BUFW "
@@ -194,6 +200,6 @@
 // the same defines to every file
 #define BN_BUILD_FLAGS_STRING                                                                                              \
   BN_F_PHASE_TIMING BN_F_PHASE_TIMING_WGRAD BN_F_CLOCK_STAMP BN_F_CLOCK_STAMP_WGRAD BN_F_TIMELINE BN_F_GEMM_PRIO          \
-  BN_F_PRIO_YOUNG BN_F_NO_NT_STASH BN_F_NO_PINGPONG BN_F_BWD_NO_PINGPONG BN_F_PP_LOOP_NKS BN_F_PP_SPLIT BN_F_NO_BUFW BN_F_FWD_DEPTH_TRAIN            \
+  BN_F_PRIO_YOUNG BN_F_NO_NT_STASH BN_F_NO_PINGPONG BN_F_BWD_NO_PINGPONG BN_F_PP_LOOP_NKS BN_F_PP_SPLIT BN_F_NO_FIXED_FULL BN_F_NO_BUFW BN_F_FWD_DEPTH_TRAIN            \
   BN_F_BWD_DEPTH BN_F_BWD_PP_DEPTH BN_F_BWD_D_AT BN_F_HEAD_WIDE BN_F_NO_FLAT_COMPOSITE BN_F_DPH BN_F_SKINNY_SPLITS        \
   BN_F_W2_BLOCKS BN_F_WGRAD_BIAS_INLINE BN_F_DIAG_D8_IN_F32 BN_F_PROBE_NO_A BN_F_PROBE_NO_B BN_F_PROBE_NO_D BN_F_PROBE_NO_RIDE BN_F_ABLATION_BUILD

@@ -21,6 +21,7 @@ struct FieldGeom {
   int KP;       // P rounded up to 64 (60 -> 64, 3 -> 64): k-extent of the PE operand (4 MFMA k-steps)
   int NT;       // 32-column tiles per wave in the F-wide phases
   int BM, waves; // points per workgroup tile, waves per workgroup (tile configuration, bn_tile_config)
+  int dsz;       // bytes per element of the derivative stashes D_l / DG: 4 (fp32), 2 (fp16 + analytic normals), 1 (common.h bn_dsize)
   int H2;       // head hidden width F/2
   int n_heads, n_pass;
   int pass_heads[BN_MAX_PASS];  // heads evaluated in pass p (2 or 1)
@@ -57,6 +58,7 @@ static inline int bn_make_geom(const bn_field_desc *d, FieldGeom *g) {
   g->P = d->pe_freqs > 0 ? 6 * d->pe_freqs : 3;
   g->KP = (g->P + 63) / 64 * 64;
   bn_tile_config(d->dtype, &g->BM, &g->waves);
+  g->dsz = (int)bn_dsize(d->dtype, d->normal_an);
   {
     const int per = (d->feat + 32 * g->waves - 1) / (32 * g->waves);   // 32-column tiles each wave must cover
     g->NT = per <= 1 ? 1 : (per <= 2 ? 2 : 4);
@@ -217,7 +219,7 @@ static inline size_t bn_wgpart_bytes(const FieldGeom &g, int64_t Mpad, size_t es
 }
 
 static inline void bn_make_stash_layout(const FieldGeom &g, int64_t n_points, int BM, size_t esz, StashLayout *s) {
-  const size_t dsz = esz == 4 ? 4 : 1;   // Elem<T>::kD8: one byte per derivative in the 16-bit modes
+  const size_t dsz = (size_t)g.dsz;      // DK32 / DK16 / DK8 (field_kernels.h): 4, 2 or 1 byte per derivative
   int64_t Mpad = ceil_div64(n_points, BM) * BM;
   s->Mpad = Mpad;
   size_t off = 0;
@@ -269,7 +271,7 @@ static inline void bn_stash_layout_at(const FieldGeom &g, const bn_points *pts, 
   bn_make_stash_layout(g, total, BM, esz, s);
   const size_t off = (size_t)pts->point_offset;
   if (off == 0) return;
-  const size_t dsz = esz == 4 ? 4 : 1, F = (size_t)g.F;
+  const size_t dsz = (size_t)g.dsz, F = (size_t)g.F;
   s->sraw += off * 4; s->nraw += off * 16; s->dpre_trunk += off * 16; s->dpre_head += off * BN_DPH * 4;
   s->pe += off * g.KP * esz;
   if (g.KD > 0) s->dirpe += off * g.KD * esz;

@@ -32,8 +32,9 @@ struct AdjBwdArgs {
                        // max |zbar_l| (true scale) for the primal chain's; else nullptr
 };
 
-template <typename T, int MT, int NT, int WAVES>
+template <typename T, int MT, int NT, int WAVES, bool D16>
 __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBwdArgs A) {
+  typedef typename DKind<T, D16>::type DK;     // kind of the derivative stash (field_kernels.h)
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
   constexpr int PADE = Elem<T>::kPad;
@@ -109,22 +110,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
   // 16-bit modes (round 4): the layer's derivative bytes leave HBM before its GEMM (32 registers, as in the primal backward
   // chain), and its a_{l+1} / y_l pieces in batches of ADJ_GRP point tiles - one exposed latency per batch instead of one per
   // piece (the loads used to sit beside their uses inside the epilogue loops).
-  constexpr bool PRE = Elem<T>::kD8;
+  constexpr bool PRE = std::is_same<DK, DK8>::value;     // (DK16: 64 registers for a layer - fetched per piece, like the fp32 mode's)
 #ifndef ADJ_GRP
 #define ADJ_GRP 2      // point tiles per batch of a_{l+1} / y_l loads (4 = a whole n-tile: 212 B of scratch per lane)
 #endif
-  DPiece<T> dpre[PRE ? NT : 1][PRE ? MT : 1];
+  DPiece<DK> dpre[PRE ? NT : 1][PRE ? MT : 1];
   for (int l = 0; l < g.L; ++l) {
     zero_acc<MT, NT>(acc);
     T *adst = (T *)(A.stash + A.sl.adj_abar[l]) + (size_t)m0 * F;   // abar_l, l >= 1
     if (!ride && l > 0) tile_to_global<T>(ACT, LDA, adst, F, BM, F);
     if constexpr (PRE) {
       if (wave_on) {
-        const char *Dp = A.stash + A.sl.D[l] + (size_t)tile * dtile_bytes<T>(BM, F);
+        const char *Dp = A.stash + A.sl.D[l] + (size_t)tile * dtile_bytes<DK>(BM, F);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) dpre[nt][mt] = dpiece_load<T>(Dp + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
+          for (int mt = 0; mt < MT; ++mt) dpre[nt][mt] = dpiece_load<DK>(Dp + dpiece_off<DK, MT, NT>(wave, nt, mt, lane));
       }
     }
     if (wave_on) {
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       const float unscale = A.prescaled ? 6.283185307179586f / w0 : 1.f;
       const float e2 = g.act == BN_ACT_SIN ? -w0 * w0 : 0.f;      // dD/dz = -w0^2 sin(w0 z) = -w0^2 y (0 for ReLU)
       const float dscale = (g.act == BN_ACT_SIN) ? w0 : 1.f;      // the 16-bit modes stash the unscaled derivative (DTile)
-      const char *Ds = A.stash + A.sl.D[l] + (size_t)tile * dtile_bytes<T>(BM, F);
+      const char *Ds = A.stash + A.sl.D[l] + (size_t)tile * dtile_bytes<DK>(BM, F);
       const T *As = (const T *)(A.stash + A.sl.adj_a[l]) + (size_t)tile * BM * F;
       const T *Yn = (const T *)(A.stash + A.sl.Y[l]) + (size_t)tile * BM * F;        // native-order y_l (16-bit modes)
       typename Elem<T>::wide *Zs = (typename Elem<T>::wide *)(A.stash + A.sl.adj_zbar[l]) + (size_t)tile * BM * F;
@@ -196,14 +197,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
             }
           }
           const int m = mt * 32 + r;
-          DPiece<T> pc;
+          DPiece<DK> pc;
           if constexpr (PRE) pc = dpre[nt][mt];
-          else pc = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
+          else pc = dpiece_load<DK>(Ds + dpiece_off<DK, MT, NT>(wave, nt, mt, lane));
 #pragma unroll
           for (int gp = 0; gp < 2; ++gp) {
             const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
             float dv[8], av[8], zb[8], db[8], yv[8];
-            dpiece_get<T>(pc, gp, g.act, dscale, dv);
+            dpiece_get<DK>(pc, gp, g.act, dscale, dv);
             if constexpr (PRE) {
               const auto aq = __builtin_bit_cast(typename Elem<T>::frag, araw[mt][gp]), yq = __builtin_bit_cast(typename Elem<T>::frag, yraw[mt][gp]);
 #pragma unroll
@@ -270,14 +271,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
   }
 }
 
-template <typename T, int MT, int NT, int WAVES> static int launch_adjbwd(const AdjBwdArgs &a, int64_t tiles, hipStream_t st) {
+template <typename T, int MT, int NT, int WAVES, bool D16> static int launch_adjbwd_k(const AdjBwdArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = ((size_t)BM * (a.g.F + Elem<T>::kPad) + (size_t)BM * (a.g.KP + Elem<T>::kPad)) * sizeof(T);
-  if (int e = bn_configure_lds((const void *)field_adjbwd_kernel<T, MT, NT, WAVES>, lds, "field_adjbwd")) return e;
+  if (int e = bn_configure_lds((const void *)field_adjbwd_kernel<T, MT, NT, WAVES, D16>, lds, "field_adjbwd")) return e;
   BnProfScope prof_(BN_K_ADJBWD, st);
-  field_adjbwd_kernel<T, MT, NT, WAVES><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
+  field_adjbwd_kernel<T, MT, NT, WAVES, D16><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_adjbwd");
   return 0;
+}
+template <typename T, int MT, int NT, int WAVES> static int launch_adjbwd(const AdjBwdArgs &a, int64_t tiles, hipStream_t st) {
+  if constexpr (std::is_same<T, f16>::value) {
+    if (a.g.dsz == 2) return launch_adjbwd_k<T, MT, NT, WAVES, true>(a, tiles, st);     // fp16 derivative stash (analytic normals)
+  }
+  return launch_adjbwd_k<T, MT, NT, WAVES, false>(a, tiles, st);
 }
 
 // called by bn_field_backward() before the primal backward chain when desc->normal_an is set

@@ -26,9 +26,10 @@ struct AdjArgs {
   int keep;         // 1: training - also stash delta_l (row-major), a_{l+1} (native), sigmoid(s_raw), grad_x
 };
 
-template <typename T, int MT, int NT, int WAVES, bool KEEP>
+template <typename T, int MT, int NT, int WAVES, bool KEEP, bool D16>
 __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjArgs A) {
   typedef typename Elem<T>::vec4 vec4;
+  typedef typename DKind<T, D16>::type DK;     // kind of the derivative stash (field_kernels.h)
   constexpr int BM = MT * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const FieldGeom &g = A.g;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
   const bool wave_on = ncol0 < F;
   const float *sraw = (const float *)(A.stash + A.sl.sraw);
   constexpr int DP = BwdDepth<T>::value;
-  constexpr int NPRE = Elem<T>::kD8 ? NT : 1;    // D pieces fetched ahead of the layer's GEMM (field_bwd.hip)
+  constexpr int NPRE = std::is_same<DK, DK8>::value ? NT : 1;    // D pieces fetched ahead of the layer's GEMM (field_bwd.hip)
   auto dscale = [&](int lo) { return (g.act == BN_ACT_SIN && lo == 0) ? 30.f : 1.f; };   // w0 of layer lo (16-bit modes: unscaled stash)
 
   for (int i = tid; i < BM * P; i += WAVES * 64) GP[i] = 0.f;
@@ -52,19 +53,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
 
   // delta_{L-1} = (sigmoid(s_raw) w_sigma) (.) D_{L-1}
   if (wave_on) {
-    const char *Ds = A.stash + A.sl.D[g.L - 1] + (size_t)tile * dtile_bytes<T>(BM, F);
+    const char *Ds = A.stash + A.sl.D[g.L - 1] + (size_t)tile * dtile_bytes<DK>(BM, F);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const DPiece<T> pc = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
+        const DPiece<DK> pc = dpiece_load<DK>(Ds + dpiece_off<DK, MT, NT>(wave, nt, mt, lane));
         const int m = mt * 32 + r;
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
           const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
           const f32x4 wa = *(const f32x4 *)(A.p.sigma_w + n0), wb = *(const f32x4 *)(A.p.sigma_w + n0 + 8);
           float dv[8];
-          dpiece_get<T>(pc, gp, g.act, dscale(g.L - 1), dv);
+          dpiece_get<DK>(pc, gp, g.act, dscale(g.L - 1), dv);
           float av[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) { av[e] = wa[e]; av[4 + e] = wb[e]; }      // a'_L = w_sigma (s' is applied at the end)
@@ -104,13 +105,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
     if (l == 0) break;
     zero_acc<MT, NT>(acc);
     // D_{l-1} in accumulator order (DTile pieces), fetched ahead of the GEMM and of the stash stores riding in it
-    const char *Ds = A.stash + A.sl.D[l - 1] + (size_t)tile * dtile_bytes<T>(BM, F);
-    DPiece<T> dpre[NT][MT];
+    const char *Ds = A.stash + A.sl.D[l - 1] + (size_t)tile * dtile_bytes<DK>(BM, F);
+    DPiece<DK> dpre[NT][MT];
     if (wave_on) {
 #pragma unroll
       for (int nt = 0; nt < NPRE; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) dpre[nt][mt] = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
+        for (int mt = 0; mt < MT; ++mt) dpre[nt][mt] = dpiece_load<DK>(Ds + dpiece_off<DK, MT, NT>(wave, nt, mt, lane));
       const T *w_t = packed + A.pl.bwd_trunk[l] + (size_t)(ncol0 / 32) * KSF * 512;
       if (keep && ride) {
         TileCopyExact<T> dcopy(ACT, LDA, ddst, F, F, tid, WAVES * 64);
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
 #pragma unroll
       for (int nt = NPRE; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) dpre[nt][mt] = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
+        for (int mt = 0; mt < MT; ++mt) dpre[nt][mt] = dpiece_load<DK>(Ds + dpiece_off<DK, MT, NT>(wave, nt, mt, lane));
     }
     __syncthreads();
     if (wave_on) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
           for (int gp = 0; gp < 2; ++gp) {
             const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
             float dv[8];
-            dpiece_get<T>(dpre[nt][mt], gp, g.act, dscale(l - 1), dv);
+            dpiece_get<DK>(dpre[nt][mt], gp, g.act, dscale(l - 1), dv);
             if (keep) {
               float av[8];
 #pragma unroll
@@ -190,16 +191,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
   }
 }
 
-template <typename T, int MT, int NT, int WAVES, bool KEEP> static int launch_adj_k(const AdjArgs &a, int64_t tiles, hipStream_t st);
+template <typename T, int MT, int NT, int WAVES, bool KEEP, bool D16> static int launch_adj_k(const AdjArgs &a, int64_t tiles, hipStream_t st);
 template <typename T, int MT, int NT, int WAVES> static int launch_adj(const AdjArgs &a, int64_t tiles, hipStream_t st) {
-  return a.keep ? launch_adj_k<T, MT, NT, WAVES, true>(a, tiles, st) : launch_adj_k<T, MT, NT, WAVES, false>(a, tiles, st);
+  if constexpr (std::is_same<T, f16>::value) {      // fp16 mode: the derivative stash of a model with analytic normals is fp16 (DK16)
+    if (a.g.dsz == 2)
+      return a.keep ? launch_adj_k<T, MT, NT, WAVES, true, true>(a, tiles, st) : launch_adj_k<T, MT, NT, WAVES, false, true>(a, tiles, st);
+  }
+  return a.keep ? launch_adj_k<T, MT, NT, WAVES, true, false>(a, tiles, st) : launch_adj_k<T, MT, NT, WAVES, false, false>(a, tiles, st);
 }
-template <typename T, int MT, int NT, int WAVES, bool KEEP> static int launch_adj_k(const AdjArgs &a, int64_t tiles, hipStream_t st) {
+template <typename T, int MT, int NT, int WAVES, bool KEEP, bool D16> static int launch_adj_k(const AdjArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = (size_t)BM * (a.g.F + Elem<T>::kPad) * sizeof(T) + (size_t)BM * a.g.P * sizeof(float);
-  if (int e = bn_configure_lds((const void *)field_adjoint_kernel<T, MT, NT, WAVES, KEEP>, lds, "field_normals")) return e;
+  if (int e = bn_configure_lds((const void *)field_adjoint_kernel<T, MT, NT, WAVES, KEEP, D16>, lds, "field_normals")) return e;
   BnProfScope prof_(BN_K_ADJOINT, st);
-  field_adjoint_kernel<T, MT, NT, WAVES, KEEP><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
+  field_adjoint_kernel<T, MT, NT, WAVES, KEEP, D16><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_normals");
   return 0;
 }

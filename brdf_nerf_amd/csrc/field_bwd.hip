@@ -164,8 +164,9 @@ __global__ __launch_bounds__(256) void head_xin_grad_kernel(const T *__restrict_
   }
 }
 
-template <typename T, int MT, int NTW>
+template <typename T, int MT, int NTW, bool D16>
 __device__ __forceinline__ void bwd_head_dG(const BwdArgs &A, int p, T *ACT, const float *DPH, int64_t /*m0*/, int64_t tile) {
+  typedef typename DKind<T, D16>::type DK;     // kind of the derivative stash (field_kernels.h)
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
   const FieldGeom &g = A.g;
@@ -177,7 +178,7 @@ __device__ __forceinline__ void bwd_head_dG(const BwdArgs &A, int p, T *ACT, con
   const int hl = pc0 / g.H2, hd = 2 * p + hl;
   const int nout = A.d.head_out[hd];
   const float *w2 = A.p.head_w2[hd];
-  const char *DGs = A.stash + A.sl.DG[p] + (size_t)tile * dtile_bytes<T>(BM, F);
+  const char *DGs = A.stash + A.sl.DG[p] + (size_t)tile * dtile_bytes<DK>(BM, F);
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     f32x4 wa[2][3], wb[2][3];
@@ -194,12 +195,12 @@ __device__ __forceinline__ void bwd_head_dG(const BwdArgs &A, int p, T *ACT, con
     for (int mt = 0; mt < MT; ++mt) {
       const int m = mt * 32 + r;
       const float d0 = DPH[m * BN_DPH + hd * 3 + 0], d1 = DPH[m * BN_DPH + hd * 3 + 1], d2 = DPH[m * BN_DPH + hd * 3 + 2];
-      const DPiece<T> pc = dpiece_load<T>(DGs + dpiece_off<T, MT, NTW>(wave, nt, mt, lane));
+      const DPiece<DK> pc = dpiece_load<DK>(DGs + dpiece_off<DK, MT, NTW>(wave, nt, mt, lane));
 #pragma unroll
       for (int gp = 0; gp < 2; ++gp) {
         const int n0 = pc0 + nt * 32 + 16 * gp + 4 * h;
         float dg[8];
-        dpiece_get<T>(pc, gp, g.act, 1.f, dg);
+        dpiece_get<DK>(pc, gp, g.act, 1.f, dg);
         float va[4], vb[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -213,8 +214,9 @@ __device__ __forceinline__ void bwd_head_dG(const BwdArgs &A, int p, T *ACT, con
   }
 }
 
-template <typename T, int MT, int NT, int WAVES>
+template <typename T, int MT, int NT, int WAVES, bool D16>
 __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs A) {
+  typedef typename DKind<T, D16>::type DK;     // kind of the derivative stash (field_kernels.h)
   typedef typename Elem<T>::vec4 vec4;
   constexpr int BM = MT * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
   // (BN_BWD_PP_DEPTH = 6: diag.h)
   constexpr int DP = (NT == 2 && WAVES == 8 && Elem<T>::kFastMath) ? (BN_BWD_PP_DEPTH | BN_GEMM_AFFINE) : BwdDepth<T>::value;
   // D_lo pieces fetched before the layer's GEMM (the rest right after its last MFMA): all of them when a piece is 16 bytes
-  constexpr int NPRE = Elem<T>::kD8 ? NT : 1;
+  constexpr int NPRE = std::is_same<DK, DK8>::value ? NT : 1;
   BN_PH_DECL
   BN_CLK_BEGIN
 
@@ -269,8 +271,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
 
   // ---------------------------------------------------------------- heads: dG -> LDS, dFeats += W1^T dG
   for (int p = 0; p < g.n_pass; ++p) {
-    if (g.pass_heads[p] == 2) bwd_head_dG<T, MT, NT>(A, p, ACT, DPH, m0, tile);
-    else bwd_head_dG<T, MT, BN_SINGLE_HEAD_NTW(NT)>(A, p, ACT, DPH, m0, tile);
+    if (g.pass_heads[p] == 2) bwd_head_dG<T, MT, NT, D16>(A, p, ACT, DPH, m0, tile);
+    else bwd_head_dG<T, MT, BN_SINGLE_HEAD_NTW(NT), D16>(A, p, ACT, DPH, m0, tile);
     BN_PH(1)
     __syncthreads();
     BN_PH(2)
@@ -321,21 +323,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
 #endif
   const int grp = wave >> 2;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  DPiece<T> dpre[NT][MT];
+  DPiece<DK> dpre[NT][MT];
   // D_lo = d act / d z of layer lo, read back in accumulator order (DTile pieces).  The loads are issued BEFORE the layer's
   // GEMM - in flight while the MFMAs run - so the epilogue does not sit on HBM latency (fp32 mode: only n-tile 0 fits there,
   // the others follow the last MFMA).
   auto load_D = [&](int lo, int nt0, int nt1) {
-    const char *Ds = A.stash + A.sl.D[lo] + (size_t)tile * dtile_bytes<T>(BM, F);
+    const char *Ds = A.stash + A.sl.D[lo] + (size_t)tile * dtile_bytes<DK>(BM, F);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         if (nt < nt0 || nt >= nt1) continue;
 #ifdef BN_PROBE_NO_D          // timing probe only (results wrong): no derivative loads
-        if constexpr (Elem<T>::kD8) { dpre[nt][mt].w = u32x4{0x80808080u + (unsigned)lane, 0x90909090u, 0xa0a0a0a0u, 0xb0b0b0b0u}; continue; }
+        if constexpr (std::is_same<DK, DK8>::value) { dpre[nt][mt].w = u32x4{0x80808080u + (unsigned)lane, 0x90909090u, 0xa0a0a0a0u, 0xb0b0b0b0u}; continue; }
 #endif
-        dpre[nt][mt] = dpiece_load<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane));
+        dpre[nt][mt] = dpiece_load<DK>(Ds + dpiece_off<DK, MT, NT>(wave, nt, mt, lane));
       }
   };
   // epilogue of the layer that produces dZ_lo: (+ the top layer's rank-1 terms) x D_lo (+ zbar_lo), -> LDS tile and stash
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
         for (int gp = 0; gp < 2; ++gp) {
           const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
           float dv[8], v[8];
-          dpiece_get<T>(dpre[nt][mt], gp, g.act, Elem<T>::kD8 ? dscale : 1.f, dv);
+          dpiece_get<DK>(dpre[nt][mt], gp, g.act, dscale, dv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = acc[nt][mt][8 * gp + e];
           if constexpr (top) {  // rank-1 terms of the sigma head and the learned-normal head
@@ -518,14 +520,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_bwd_kernel(const BwdArgs 
 }
 
 // ------------------------------------------------------------------------------------------ weight gradients
-template <typename T, int MT, int NT, int WAVES> static int launch_bwd(const BwdArgs &a, int64_t tiles, hipStream_t st) {
+template <typename T, int MT, int NT, int WAVES, bool D16> static int launch_bwd_k(const BwdArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = (size_t)BM * (a.g.F + Elem<T>::kPad) * sizeof(T) + (size_t)BM * (BN_DPH + 4) * sizeof(float) + 64;
-  if (int e = bn_configure_lds((const void *)field_bwd_kernel<T, MT, NT, WAVES>, lds, "field_bwd")) return e;
+  if (int e = bn_configure_lds((const void *)field_bwd_kernel<T, MT, NT, WAVES, D16>, lds, "field_bwd")) return e;
   BnProfScope prof_(BN_K_BWD_CHAIN, st);
-  field_bwd_kernel<T, MT, NT, WAVES><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
+  field_bwd_kernel<T, MT, NT, WAVES, D16><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
   BN_LAUNCH_CHECK("field_bwd");
   return 0;
+}
+template <typename T, int MT, int NT, int WAVES> static int launch_bwd(const BwdArgs &a, int64_t tiles, hipStream_t st) {
+  if constexpr (std::is_same<T, f16>::value) {
+    if (a.g.dsz == 2) return launch_bwd_k<T, MT, NT, WAVES, true>(a, tiles, st);     // fp16 + analytic normals: fp16 derivative stash
+  }
+  return launch_bwd_k<T, MT, NT, WAVES, false>(a, tiles, st);
 }
 
 extern "C" int bn_field_backward(const bn_field_desc *desc, const bn_field_params *params, const void *packed,

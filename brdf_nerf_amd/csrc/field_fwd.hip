@@ -96,7 +96,7 @@ __device__ __forceinline__ void fill_dir_row(const FwdArgs &A, int64_t gm, T *ro
 // The pass's first-layer biases and second-layer weights are staged in LDS (PRM, the positional-encoding buffer,
 // free by now) ahead of the GEMM: the epilogue then reads them without queueing behind its own stash stores.
 // The hidden activations G are stashed in accumulator order like DG (one coalesced 16-byte store per lane).
-template <typename T, int MT, int NTW, int WAVES, bool KEEP, bool DIR>
+template <typename T, int MT, int NTW, int WAVES, bool KEEP, bool DIR, bool HOT, bool D16>
 __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT, float *PRM, float *RED, int64_t m0, int64_t tile
 #ifdef BN_PHASE_TIMING
                                           , unsigned long long (&ph_)[BN_PH_N], unsigned long long &pt_
@@ -105,6 +105,7 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
   constexpr int BM = MT * 32;
   constexpr bool FAST = Elem<T>::kFastMath;
   constexpr int DP = FwdDepth<T, KEEP>::value;
+  typedef typename DKind<T, D16>::type DK;     // kind of the derivative stash (field_kernels.h)
   const FieldGeom &g = A.g;
   const int F = g.F, LDA = F + Elem<T>::kPad, KSF = F / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -133,7 +134,7 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
   }
   f32x16 acc[NTW][MT];
   zero_acc<MT, NTW>(acc);
-  if (on) gemm_seg<T, MT, NTW, DP>(acc, (const T *)A.packed + A.pl.fwd_head[p] + (size_t)(pc0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
+  if (on) gemm_full<T, MT, NTW, DP, HOT>(acc, (const T *)A.packed + A.pl.fwd_head[p] + (size_t)(pc0 / 32) * KSF * 512, KSF, ACT, LDA, lane);
   BN_PH(9)
   __syncthreads();   // PRM (and the direction tile) filled
   if constexpr (DIR) {
@@ -145,7 +146,7 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
   }
   if (on) {
     T *Gs = keep ? (T *)(A.stash + A.sl.G[p]) + (size_t)tile * BM * F : nullptr;
-    char *DGs = keep ? A.stash + A.sl.DG[p] + (size_t)tile * dtile_bytes<T>(BM, F) : nullptr;
+    char *DGs = keep ? A.stash + A.sl.DG[p] + (size_t)tile * dtile_bytes<DK>(BM, F) : nullptr;
     float part[MT][3];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) part[mt][0] = part[mt][1] = part[mt][2] = 0.f;
@@ -153,7 +154,7 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
       constexpr int ACTK = decltype(act_tag)::value;
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        DHalf<T> dh0[MT];     // derivative bytes of group gp = 0, stored with those of gp = 1 (one 16-byte piece per lane)
+        DHalf<DK> dh0[MT];     // derivative bytes of group gp = 0, stored with those of gp = 1 (one 16-byte piece per lane)
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
           const int n0 = pc0 + nt * 32 + 16 * gp + 4 * h;   // column in the pass of the first run (second: +8)
@@ -178,8 +179,8 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
             for (int e = 0; e < 8; ++e) y[e] = (float)yq[e];
             if (keep) {
               st_frag(Gs + native_off8<MT, NTW>(wave, nt, mt, gp, lane), yq);
-              if (gp == 0) dh0[mt] = dhalf_make<T>(dd, 1.f);
-              else dpiece_store<T>(DGs + dpiece_off<T, MT, NTW>(wave, nt, mt, lane), dh0[mt], dhalf_make<T>(dd, 1.f));
+              if (gp == 0) dh0[mt] = dhalf_make<DK>(dd, 1.f);
+              else dpiece_store<DK>(DGs + dpiece_off<DK, MT, NTW>(wave, nt, mt, lane), dh0[mt], dhalf_make<DK>(dd, 1.f));
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c)
@@ -240,9 +241,10 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
 #else
 #define BN_PH_ARGS
 #endif
-template <typename T, int MT, int NT, int WAVES, bool KEEP, bool DIR>
+template <typename T, int MT, int NT, int WAVES, bool KEEP, bool DIR, bool D16>
 __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs A) {
   typedef typename Elem<T>::vec4 vec4;
+  typedef typename DKind<T, D16>::type DK;     // kind of the derivative stash (field_kernels.h)
   constexpr int BM = MT * 32;
   constexpr int PADE = Elem<T>::kPad;
   constexpr bool FAST = Elem<T>::kFastMath;
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
       // Two-pass epilogue of the anti-phase trunk (see above); the accumulators hold z = W x + b.  Stash stores go through
       // buffer instructions: one lane-offset register, everything else in scalar registers.
       const auto Yr = stash_rsrc(keep ? A.stash + A.sl.Y[l] + (size_t)tile * BM * F * sizeof(T) : nullptr);
-      const auto Dr = stash_rsrc(keep ? A.stash + A.sl.D[l] + (size_t)tile * dtile_bytes<T>(BM, F) : nullptr);
+      const auto Dr = stash_rsrc(keep ? A.stash + A.sl.D[l] + (size_t)tile * dtile_bytes<DK>(BM, F) : nullptr);
       const int voff = lane * 16;
       auto passes = [&](auto act_tag) {
         typedef typename Elem<T>::frag frag;
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
         BN_TL(5)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          DHalf<T> dh0[MT];     // derivative bytes of group gp = 0, stored with those of gp = 1 (one 16-byte piece per lane)
+          DHalf<DK> dh0[MT];     // derivative bytes of group gp = 0, stored with those of gp = 1 (one 16-byte piece per lane)
 #pragma unroll
           for (int gp = 0; gp < 2; ++gp) {
             const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
@@ -465,11 +467,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
               *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = __builtin_shufflevector(yq, yq, 4, 5, 6, 7);
               if (keep) {
                 stash_store_buf(Yr, voff, ((((wave_u * NT + nt) * MT + mt) * 2 + gp) * 1024), yq);
-                if (gp == 0) dh0[mt] = dhalf_make<T>(c, dsc);
-                else {
-                  const DHalf<T> h1 = dhalf_make<T>(c, dsc);
-                  stash_store_buf(Dr, voff, ((wave_u * NT + nt) * MT + mt) * 1024, u32x4{dh0[mt].w[0], dh0[mt].w[1], h1.w[0], h1.w[1]});
-                }
+                if (gp == 0) dh0[mt] = dhalf_make<DK>(c, dsc);
+                else dpiece_store_buf<DK>(Dr, voff, (wave_u * NT + nt) * MT + mt, dh0[mt], dhalf_make<DK>(c, dsc));
               }
             }
           }
@@ -485,14 +484,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
     __syncthreads();  // every wave has finished reading ACT (in-place update below)
     BN_PH(2)
     if (wave_on) {
-      char *Ds = keep ? A.stash + A.sl.D[l] + (size_t)tile * dtile_bytes<T>(BM, F) : nullptr;
+      char *Ds = keep ? A.stash + A.sl.D[l] + (size_t)tile * dtile_bytes<DK>(BM, F) : nullptr;
       T *Ys = keep ? (T *)(A.stash + A.sl.Y[l]) + (size_t)tile * BM * F : nullptr;   // native order (16-bit modes)
       auto epilogue = [&](auto act_tag) {
         constexpr int ACTK = decltype(act_tag)::value;
         const float dsc = ACTK == BN_ACT_SIN ? w0 : 1.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          DHalf<T> dh0[MT];     // derivative bytes of group gp = 0, stored with those of gp = 1 (one 16-byte piece per lane)
+          DHalf<DK> dh0[MT];     // derivative bytes of group gp = 0, stored with those of gp = 1 (one 16-byte piece per lane)
 #pragma unroll
           for (int gp = 0; gp < 2; ++gp) {
             const int n0 = ncol0 + nt * 32 + 16 * gp + 4 * h;
@@ -516,8 +515,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
                 *(vec4 *)(ACT + (size_t)m * LDA + n0 + 8) = to_vec4(T(), y[4], y[5], y[6], y[7]);
               }
               if (keep) {
-                if (gp == 0) dh0[mt] = dhalf_make<T>(dd, dsc);
-                else dpiece_store<T>(Ds + dpiece_off<T, MT, NT>(wave, nt, mt, lane), dh0[mt], dhalf_make<T>(dd, dsc));
+                if (gp == 0) dh0[mt] = dhalf_make<DK>(dd, dsc);
+                else dpiece_store<DK>(Ds + dpiece_off<DK, MT, NT>(wave, nt, mt, lane), dh0[mt], dhalf_make<DK>(dd, dsc));
               }
             }
           }
@@ -554,8 +553,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
     zero_acc<MT, 1>(nacc);
     if (kon) {
       NoSide none;
-      gemm_range<T, MT, 1, DP>(sacc, packed + A.pl.fwd_sigma, KSF, ks0, nks, ACT, LDA, lane, none);
-      if (nlr) gemm_range<T, MT, 1, DP>(nacc, packed + A.pl.fwd_nlr, KSF, ks0, nks, ACT, LDA, lane, none);
+#if !defined(BN_NO_FIXED_FULL) && !defined(BN_NO_FIXED_SIGMA)
+      if constexpr (NT == 2 && WAVES == 8) {       // F = 512: four k-steps per wave, straight-line
+        (void)none; (void)nks;
+        gemm_fixed<T, MT, 1, 4, 4, 0>(sacc, packed + A.pl.fwd_sigma, KSF, ks0, ACT, LDA, lane, NoMid());
+        if (nlr) gemm_fixed<T, MT, 1, 4, 4, 0>(nacc, packed + A.pl.fwd_nlr, KSF, ks0, ACT, LDA, lane, NoMid());
+      } else
+#endif
+      {
+        gemm_range<T, MT, 1, DP>(sacc, packed + A.pl.fwd_sigma, KSF, ks0, nks, ACT, LDA, lane, none);
+        if (nlr) gemm_range<T, MT, 1, DP>(nacc, packed + A.pl.fwd_nlr, KSF, ks0, nks, ACT, LDA, lane, none);
+      }
     }
     if (h == 0) {                                      // accumulator rows 0..3 live in registers 0..3 of lanes 0-31
 #pragma unroll
@@ -687,8 +695,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_fwd_kernel(const FwdArgs 
 
   // ---------------------------------------------------------------- two-layer sigmoid heads, up to 2 per pass
   for (int p = 0; p < g.n_pass; ++p) {
-    if (g.pass_heads[p] == 2) head_pass<T, MT, NT, WAVES, KEEP, DIR>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
-    else head_pass<T, MT, BN_SINGLE_HEAD_NTW(NT), WAVES, KEEP, DIR>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
+    if (g.pass_heads[p] == 2) head_pass<T, MT, NT, WAVES, KEEP, DIR, NT == 2, D16>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
+    else head_pass<T, MT, BN_SINGLE_HEAD_NTW(NT), WAVES, KEEP, DIR, NT == 2, D16>(A, p, ACT, (float *)PE, RED, m0, tile BN_PH_ARGS);
   }
   BN_PH_FLUSH
   BN_CLK_END
@@ -859,20 +867,28 @@ extern "C" int bn_pack_field(const bn_field_desc *desc, const bn_field_params *P
   return 0;
 }
 
-template <typename T, int MT, int NT, int WAVES, bool KEEP, bool DIR> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st);
+template <typename T, int MT, int NT, int WAVES, bool KEEP, bool DIR, bool D16> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st);
 template <typename T, int MT, int NT, int WAVES> static int launch_fwd(const FwdArgs &a, int64_t tiles, hipStream_t st) {
+  // fp16 mode of a model with analytic normals: the derivative stash in fp16 (DK16, FieldGeom.dsz == 2); only a stash-writing
+  // forward has a derivative stash at all
+  if constexpr (std::is_same<T, f16>::value) {
+    if (a.g.dsz == 2 && a.stash) {
+      if (a.g.KD > 0 && !a.sigma_only) return launch_fwd_k<T, MT, NT, WAVES, true, true, true>(a, tiles, st);
+      return launch_fwd_k<T, MT, NT, WAVES, true, false, true>(a, tiles, st);
+    }
+  }
   if (a.g.KD > 0 && !a.sigma_only)      // --input_viewdir / --beta: the variant with the extra-input segment in pass 0
-    return a.stash ? launch_fwd_k<T, MT, NT, WAVES, true, true>(a, tiles, st) : launch_fwd_k<T, MT, NT, WAVES, false, true>(a, tiles, st);
-  return a.stash ? launch_fwd_k<T, MT, NT, WAVES, true, false>(a, tiles, st) : launch_fwd_k<T, MT, NT, WAVES, false, false>(a, tiles, st);
+    return a.stash ? launch_fwd_k<T, MT, NT, WAVES, true, true, false>(a, tiles, st) : launch_fwd_k<T, MT, NT, WAVES, false, true, false>(a, tiles, st);
+  return a.stash ? launch_fwd_k<T, MT, NT, WAVES, true, false, false>(a, tiles, st) : launch_fwd_k<T, MT, NT, WAVES, false, false, false>(a, tiles, st);
 }
-template <typename T, int MT, int NT, int WAVES, bool KEEP, bool DIR> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st) {
+template <typename T, int MT, int NT, int WAVES, bool KEEP, bool DIR, bool D16> static int launch_fwd_k(const FwdArgs &a, int64_t tiles, hipStream_t st) {
   constexpr int BM = MT * 32;
   const size_t lds = ((size_t)BM * (a.g.F + Elem<T>::kPad) + (size_t)BM * (a.g.KP + Elem<T>::kPad)) * sizeof(T) +
                      (size_t)WAVES * 3 * BM * sizeof(float);
-  if (int e = bn_configure_lds((const void *)field_fwd_kernel<T, MT, NT, WAVES, KEEP, DIR>, lds, "field_fwd")) return e;
+  if (int e = bn_configure_lds((const void *)field_fwd_kernel<T, MT, NT, WAVES, KEEP, DIR, D16>, lds, "field_fwd")) return e;
   {
     BnProfScope prof_(a.sigma_only ? BN_K_FWD_SIGMA : BN_K_FWD_FULL, st);
-    field_fwd_kernel<T, MT, NT, WAVES, KEEP, DIR><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
+    field_fwd_kernel<T, MT, NT, WAVES, KEEP, DIR, D16><<<dim3((unsigned)tiles), WAVES * 64, lds, st>>>(a);
     BN_LAUNCH_CHECK("field_fwd");
   }
   // mirror the device fault word to the host now and then: asynchronous, no synchronisation on the hot path

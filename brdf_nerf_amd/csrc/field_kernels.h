@@ -374,32 +374,40 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
       side.at(d & 1);
     }
 }
-// The barrier-free trunks' GEMM over a WHOLE layer (NT == 2 means F = 512: NKS = 32 k-steps) as one straight-line weight stream
-// (round 5).  `mid()` runs between k-steps MID - 1 and MID: the hand-over of the two column halves (signal "done reading half
-// 0", wait for half 1) - the weight-fragment ring keeps running through it (rounds 1-4: two half-GEMMs, each with its own
-// prologue of DEPTH exposed L2 round trips behind the hand-over wait), only the LDS look-ahead read of step MID waits for it.
+// GEMM over a COMPILE-TIME number of k-steps as one straight-line weight stream (round 5): k-steps [ks0, ks0 + NKS) of a packed
+// matrix whose n-tiles are KS k-steps apart.  NT == 2 means F = 512, so the full-width products of the hot instantiations have 32
+// k-steps, their k-split sigma head 4 per wave.  No clamps, no tail steps (the looped form's tails copied the accumulator set:
+// ~70 v_mov_b64 each, profiles/r04_isa_scan.txt).
 // The weight fragments are BUFFER loads: descriptor = the wave's packed block (wave-uniform), one lane-offset register for the
 // whole kernel, everything else in the scalar offset - the global-load form spent two 64-bit vector adds per k-step on its
-// addresses and, unrolled, spilled scalar registers to vector lanes (v_readlane: 26 + 42 per layer in the ISA of the looped /
-// half-GEMM forms).  Loads are the compiler's builtin (counted in its vmcnt bookkeeping), not inline asm:
-// the store-data hazard of stash_store_buf is a store's.
+// addresses and, unrolled, spilled scalar registers to vector lanes (26 + 42 v_readlane per layer in the ISA of the half-GEMM
+// form).  Loads are the compiler's builtin (counted in its vmcnt bookkeeping), not inline asm: the
+// store-data hazard of stash_store_buf is a store's.
+// MID > 0: `mid()` runs between k-steps MID - 1 and MID - the hand-over of the barrier-free trunks' two column halves (signal
+// "done reading half 0", wait for half 1).  The weight ring keeps running through it (rounds 1-4: two half-GEMMs, each with its
+// own prologue of DEPTH exposed L2 round trips behind the hand-over wait); only the LDS look-ahead read of step MID waits.
+// Session 1 of round 5 (profiles/r05_ab_trunk_stream_lambert.txt): training forward 1.062 -> 1.020 ms, backward chain 2.240 ->
+// 2.051 ms, sigma-only forward 1.573 -> 1.530 ms against the half-GEMM form with global loads.
+struct NoMid {
+  __device__ __forceinline__ void operator()() const {}
+};
 template <typename T, int MT, int NTW, int DEPTH, int NKS, int MID, typename Mid>
-__device__ __forceinline__ void gemm_trunk(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb, int lane,
-                                           Mid &&mid) {
+__device__ __forceinline__ void gemm_fixed(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, int ks0, const T *bsrc, int ldb,
+                                           int lane, Mid &&mid) {
   typedef typename Elem<T>::frag frag;
   static_assert(sizeof(frag) == 16, "16-bit modes only: one 16-byte fragment piece per lane");
-  static_assert(MID > 0 && MID < NKS && DEPTH <= MID, "the ring must not wrap inside the prologue");
+  static_assert(MID >= 0 && MID < NKS && DEPTH <= NKS && (MID == 0 || DEPTH <= MID), "the ring must not wrap inside the prologue");
   const int r = lane & 31, h = lane >> 5;
   const T *bm[MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) bm[mt] = bsrc + (size_t)(r + 32 * mt) * ldb + 8 * h;
+  for (int mt = 0; mt < MT; ++mt) bm[mt] = bsrc + (size_t)(r + 32 * mt) * ldb + 8 * h + (size_t)ks0 * 16;
   const auto rs = stash_rsrc(wp);
   const int voff = lane * 16;
   auto ldA = [&](int nt, int ks) {
 #ifdef BN_NO_BUFW      // A/B switch (results unchanged): global loads with 64-bit vector addresses, as in rounds 1-4
-    return gld_frag<T>(wp + (size_t)lane * 8 + ((size_t)nt * KS + ks) * 512);
+    return gld_frag<T>(wp + (size_t)lane * 8 + ((size_t)nt * KS + ks0 + ks) * 512);
 #else
-    return __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (nt * KS + ks) * (512 * (int)sizeof(T)), 0));
+    return __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (nt * KS + ks0 + ks) * (512 * (int)sizeof(T)), 0));
 #endif
   };
   frag A[DEPTH][NTW], Bc[MT];
@@ -412,7 +420,7 @@ __device__ __forceinline__ void gemm_trunk(f32x16 (&acc)[NTW][MT], const T *__re
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < NKS; ++j) {
-    const bool ahead = j + 1 < NKS && j + 1 != MID;      // (compile-time after unrolling)
+    const bool ahead = j + 1 < NKS && (MID == 0 || j + 1 != MID);      // (compile-time after unrolling)
     frag Bn[MT];
     if (ahead) {
 #pragma unroll
@@ -431,7 +439,7 @@ __device__ __forceinline__ void gemm_trunk(f32x16 (&acc)[NTW][MT], const T *__re
       for (int nt = 0; nt < NTW; ++nt) A[j % DEPTH][nt] = ldA(nt, j + DEPTH);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (j + 1 == MID) {
+    if (MID > 0 && j + 1 == MID) {
       mid();
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) Bc[mt] = lds_frag<T>(bm[mt] + MID * 16);
@@ -439,7 +447,12 @@ __device__ __forceinline__ void gemm_trunk(f32x16 (&acc)[NTW][MT], const T *__re
     }
   }
 }
-
+// the barrier-free trunks' layer GEMM: 32 k-steps, hand-over behind the 16th
+template <typename T, int MT, int NTW, int DEPTH, int NKS, int MID, typename Mid>
+__device__ __forceinline__ void gemm_trunk(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb, int lane,
+                                           Mid &&mid) {
+  gemm_fixed<T, MT, NTW, DEPTH, NKS, MID>(acc, wp, KS, 0, bsrc, ldb, lane, mid);
+}
 template <typename T, int MT, int NTW, int DEPTH, typename Side>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb,
                                          int lane, Side &side) {
@@ -450,6 +463,21 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NTW][MT], const T *__rest
                                          int lane) {
   NoSide none;
   gemm_range<T, MT, NTW, DEPTH, NoSide>(acc, wp, KS, 0, KS, bsrc, ldb, lane, none);
+}
+
+// A full-width product under barriers (head passes, the backward's top layer).  HOT = the F = 512 instantiation of a 16-bit mode
+// (NT == 2): its k-step counts are 32 (F / 16) or 16 (a single head's 256 hidden columns) - straight-line streams; every other
+// shape keeps the looped form.
+template <typename T, int MT, int NTW, int DP, bool HOT>
+__device__ __forceinline__ void gemm_full(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb, int lane) {
+#ifndef BN_NO_FIXED_FULL      // A/B switch (results unchanged): the looped form everywhere outside the trunks (round 4)
+  if constexpr (HOT && sizeof(T) == 2) {
+    constexpr int D = (DP & (BN_GEMM_AFFINE - 1)) < 2 ? 2 : (DP & (BN_GEMM_AFFINE - 1));
+    if (KS == 32) { gemm_fixed<T, MT, NTW, D, 32, 0>(acc, wp, KS, 0, bsrc, ldb, lane, NoMid()); return; }
+    if (KS == 16) { gemm_fixed<T, MT, NTW, D, 16, 0>(acc, wp, KS, 0, bsrc, ldb, lane, NoMid()); return; }
+  }
+#endif
+  gemm_seg<T, MT, NTW, DP>(acc, wp, KS, bsrc, ldb, lane);
 }
 
 template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NTW][MT]) {
@@ -519,8 +547,9 @@ __device__ __forceinline__ void ld8(const float *p, float (&v)[8]) {
 }
 
 // ------------------------------------------------------------------ the derivative stash D_l = d act / d z  (and DG of the heads)
-// The backward chains only ever multiply by it element-wise, so it does not have to be an MFMA operand type.
-// 16-bit modes (Elem<T>::kD8): 8-bit fixed point of the UNSCALED derivative c (cos(.) of a Siren layer, 0 / 1 of a ReLU
+// The backward chains only ever multiply by it element-wise, so it does not have to be an MFMA operand type.  Three kinds
+// (common.h DKind<T, D16>):
+// DK8 (16-bit modes, default): 8-bit fixed point of the UNSCALED derivative c (cos(.) of a Siren layer, 0 / 1 of a ReLU
 // layer): the high byte of the 16-bit signed-normalised value, u = (rne(32767 c) >> 8) + 128 in [0, 255]; the consumer
 // multiplies by the layer's w0.  Siren layers decode the middle of the byte's interval, (256 (u - 128) + 128) / 32767: absolute
 // error <= 1/256 of the largest derivative, rms 2.3e-3 - the size of the bf16 rounding of the gradient operand it multiplies;
@@ -530,12 +559,22 @@ __device__ __forceinline__ void ld8(const float *p, float (&v)[8]) {
 // ahead of the stash stores riding in that GEMM (vmcnt retires in issue order: a load issued after them waits for them).
 // One piece = this lane's derivatives of one 32x32 accumulator tile (nt, mt): both 16-feature groups gp = 0, 1, i.e.
 // accumulator registers 0..15, 16 bytes per lane, one coalesced 1 KB access per wave instruction.
-// fp32 parity mode: the scaled derivative in fp32, 64 bytes per lane and tile.
-template <typename T> struct DPiece { u32x4 w; };
-template <> struct DPiece<float> { f32x4 v[4]; };
-template <typename T> __host__ __device__ constexpr size_t dtile_bytes(int BM, int F) { return (size_t)BM * F * (Elem<T>::kD8 ? 1 : sizeof(T)); }
-template <typename T, int MT, int NTW> __device__ __forceinline__ size_t dpiece_off(int wave, int nt, int mt, int lane) {
-  return ((((size_t)(wave * NTW + nt) * MT + mt) * 64) + lane) * (Elem<T>::kD8 ? 16 : 64);
+// DK16 (round 5; fp16 mode of a model with ANALYTIC NORMALS, FieldGeom.dsz == 2): the unscaled derivative in fp16 (|c| <= 1:
+// absolute error <= 2.4e-4), 32 bytes per lane and tile as two 1 KB wave instructions (one per 16-feature group).  The adjoint
+// chain of the analytic normal multiplies by D_l in every layer; with the 8-bit image the normals of a trained field sit a
+// median 0.4 degrees from the fp32 mode's (fp32 arithmetic + 8-bit D alone: 0.38 degrees) and the GGX / Hapke derivatives
+// w.r.t. the normal turn that into a whole-gradient cosine of 0.08 (microfacet) / 0.87 (Hapke + theta) where fp32 arithmetic on
+// fp16-rounded weights keeps 0.998 (profiles/r05_ablation.txt item 4).  The fp16 mode is BASELINE config 5's mode: it pays the
+// byte.  bf16 keeps DK8: its referee (bf16-rounded weights) is as far from fp32 as the 8-bit image makes it.
+// DK32 (fp32 parity mode): the scaled derivative in fp32, 64 bytes per lane and tile.
+template <typename DK> struct DPiece { u32x4 w; };
+template <> struct DPiece<DK16> { u32x4 w[2]; };
+template <> struct DPiece<DK32> { f32x4 v[4]; };
+template <typename DK> __host__ __device__ constexpr size_t dk_bytes() { return std::is_same<DK, DK32>::value ? 4 : (std::is_same<DK, DK16>::value ? 2 : 1); }
+template <typename DK> __host__ __device__ constexpr size_t dtile_bytes(int BM, int F) { return (size_t)BM * F * dk_bytes<DK>(); }
+// byte offset of the lane's piece (DK16: of its first half; the second one is 1 KB behind it)
+template <typename DK, int MT, int NTW> __device__ __forceinline__ size_t dpiece_off(int wave, int nt, int mt, int lane) {
+  return ((size_t)(wave * NTW + nt) * MT + mt) * (1024 * dk_bytes<DK>()) + (size_t)lane * (std::is_same<DK, DK32>::value ? 64 : 16);
 }
 // 4 unscaled derivatives -> 4 bytes: two v_cvt_pknorm_i16_f32 (saturating; NaN -> 0: a value out of range cannot carry into the
 // neighbouring bytes), one v_perm_b32 that keeps the four high bytes, one v_xor (two's complement -> offset binary, which
@@ -558,14 +597,18 @@ __device__ __forceinline__ void d8_unpack4(unsigned int w, float k, float b, flo
   d[3] = fmaf((float)(w >> 24), k, b);
 }
 // Producer side: one 16-feature group (gp) at a time.  c[e] = unscaled derivative of accumulator register 8 gp + e; `scale`
-// (w0) is applied here in the fp32 mode only.  The two halves of a piece are stored together (one 16-byte store per lane).
-template <typename T> struct DHalf { unsigned int w[2]; };
-template <> struct DHalf<float> { f32x4 v[2]; };
-template <typename T> __device__ __forceinline__ DHalf<T> dhalf_make(const float (&c)[8], float scale) {
-  DHalf<T> r;
-  if constexpr (Elem<T>::kD8) {
+// (w0) is applied here in the fp32 mode only.  DK8: the two halves of a piece are stored together (one 16-byte store per lane).
+template <typename DK> struct DHalf { unsigned int w[2]; };
+template <> struct DHalf<DK16> { u32x4 w; };
+template <> struct DHalf<DK32> { f32x4 v[2]; };
+template <typename DK> __device__ __forceinline__ DHalf<DK> dhalf_make(const float (&c)[8], float scale) {
+  DHalf<DK> r;
+  if constexpr (std::is_same<DK, DK8>::value) {
     r.w[0] = d8_pack4(c[0], c[1], c[2], c[3]);
     r.w[1] = d8_pack4(c[4], c[5], c[6], c[7]);
+  } else if constexpr (std::is_same<DK, DK16>::value) {
+    const f32x8 f = {c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]};
+    r.w = __builtin_bit_cast(u32x4, __builtin_convertvector(f, f16x8));
   } else {
 #ifdef BN_DIAG_D8_IN_F32      // diagnostic (profiles/diag_c5_rows.py --d8lib): the fp32 mode with its derivatives sent through the 8-bit codec
     float q[8];
@@ -580,27 +623,44 @@ template <typename T> __device__ __forceinline__ DHalf<T> dhalf_make(const float
   }
   return r;
 }
-template <typename T> __device__ __forceinline__ void dpiece_store(char *p, const DHalf<T> &h0, const DHalf<T> &h1) {
-  if constexpr (Elem<T>::kD8) {
+template <typename DK> __device__ __forceinline__ void dpiece_store(char *p, const DHalf<DK> &h0, const DHalf<DK> &h1) {
+  if constexpr (std::is_same<DK, DK8>::value) {
     stash_store((u32x4 *)p, u32x4{h0.w[0], h0.w[1], h1.w[0], h1.w[1]});
+  } else if constexpr (std::is_same<DK, DK16>::value) {
+    stash_store((u32x4 *)p, h0.w);
+    stash_store((u32x4 *)(p + 1024), h1.w);
   } else {
     stash_store((f32x4 *)p, h0.v[0]); stash_store((f32x4 *)p + 1, h0.v[1]);
     stash_store((f32x4 *)p + 2, h1.v[0]); stash_store((f32x4 *)p + 3, h1.v[1]);
   }
 }
-template <typename T> __device__ __forceinline__ DPiece<T> dpiece_load(const char *p) {
-  DPiece<T> r;
-  if constexpr (Elem<T>::kD8) {
+// the same through buffer stores (the barrier-free forward trunk): `idx` = the piece's number (wave NT + nt) MT + mt, a scalar
+template <typename DK, typename R> __device__ __forceinline__ void dpiece_store_buf(R rsrc, int voff, int idx, const DHalf<DK> &h0, const DHalf<DK> &h1) {
+  static_assert(!std::is_same<DK, DK32>::value, "16-bit modes only");
+  if constexpr (std::is_same<DK, DK8>::value) {
+    stash_store_buf(rsrc, voff, idx * 1024, u32x4{h0.w[0], h0.w[1], h1.w[0], h1.w[1]});
+  } else {
+    stash_store_buf(rsrc, voff, idx * 2048, h0.w);
+    stash_store_buf(rsrc, voff, idx * 2048 + 1024, h1.w);
+  }
+}
+template <typename DK> __device__ __forceinline__ DPiece<DK> dpiece_load(const char *p) {
+  DPiece<DK> r;
+  if constexpr (std::is_same<DK, DK8>::value) {
     r.w = stash_load((const u32x4 *)p);
+  } else if constexpr (std::is_same<DK, DK16>::value) {
+    r.w[0] = stash_load((const u32x4 *)p);
+    r.w[1] = stash_load((const u32x4 *)(p + 1024));
   } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) r.v[q] = stash_load((const f32x4 *)p + q);
   }
   return r;
 }
-// scaled derivatives of group gp (accumulator registers 8 gp .. 8 gp + 7); act = the activation the image was written for
-template <typename T> __device__ __forceinline__ void dpiece_get(const DPiece<T> &pc, int gp, int act, float scale, float (&d)[8]) {
-  if constexpr (Elem<T>::kD8) {
+// scaled derivatives of group gp (accumulator registers 8 gp .. 8 gp + 7); act = the activation the image was written for;
+// `scale` = the layer's w0 for the unscaled kinds (DK8, DK16), ignored by DK32 (scaled when it was written)
+template <typename DK> __device__ __forceinline__ void dpiece_get(const DPiece<DK> &pc, int gp, int act, float scale, float (&d)[8]) {
+  if constexpr (std::is_same<DK, DK8>::value) {
     float k, b;
     d8_consts(act, scale, k, b);
     float lo[4], hi[4];
@@ -608,6 +668,10 @@ template <typename T> __device__ __forceinline__ void dpiece_get(const DPiece<T>
     d8_unpack4(pc.w[2 * gp + 1], k, b, hi);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { d[e] = lo[e]; d[4 + e] = hi[e]; }
+  } else if constexpr (std::is_same<DK, DK16>::value) {
+    const f16x8 v = __builtin_bit_cast(f16x8, pc.w[gp]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = (float)v[e] * scale;
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { d[e] = pc.v[2 * gp][e]; d[4 + e] = pc.v[2 * gp + 1][e]; }
