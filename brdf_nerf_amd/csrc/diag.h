@@ -17,6 +17,7 @@
 //     BN_PP_LOOP_NKS         the trunks' half-GEMMs as loops with tail steps (rounds 1-4) instead of straight-line code
 //     BN_PP_SPLIT            the trunks' layer GEMM as two half-GEMMs with a weight prologue each (rounds 1-4) instead of one stream
 //     BN_NO_FIXED_FULL       head passes / sigma head / the backward's top layer in the looped form (round 4) instead of straight-line
+//     BN_ADJ_LOOP            the adjoint chain's trunk product in the looped form (round 4) instead of a straight-line buffer-load stream
 //     BN_NO_BUFW             the trunks' weight fragments by global loads with vector addresses (rounds 1-4) instead of buffer loads
 //     BN_FWD_DEPTH_TRAIN=<n> weight-fragment prefetch depth of the training forward (default 6)
 //     BN_BWD_DEPTH=<n>       ... of the backward / adjoint chains under barriers (default 2)
@@ -27,7 +28,6 @@
 //     BN_DPH=<n>             pre-activation gradients kept per point for the heads (default 3 * BN_MAX_HEADS)
 //     SKINNY_SPLITS=<n>      point splits of skinny_wgrad_kernel (default 256)
 //     BN_W2_BLOCKS=<n>       wgrad256: tiles x point splits per round of the 256 CUs (default 256)
-//     BN_WGRAD_BIAS_INLINE   round 4's wgrad256: bias column sums computed by every workgroup (round 5: only where they are stored)
 //   kind D (numerical diagnostic, results CHANGED on purpose):
 //     BN_DIAG_D8_IN_F32      the fp32 mode sends its activation derivatives through the 16-bit modes' 8-bit codec (Siren layers):
 //                            what the 8-bit D stash alone does to the analytic normals (profiles/diag_c5_rows.py --d8lib=...)
@@ -104,6 +104,11 @@
 #else
 #define BN_F_NO_FIXED_FULL ""
 #endif
+#ifdef BN_ADJ_LOOP
+#define BN_F_ADJ_LOOP "BN_ADJ_LOOP "
+#else
+#define BN_F_ADJ_LOOP ""
+#endif
 #ifdef BN_NO_BUFW
 #define BN_F_NO_BUFW "BN_NO_BUFW "
 #else
@@ -160,11 +165,6 @@
 #define BN_F_W2_BLOCKS ""
 #define BN_W2_BLOCKS 256
 #endif
-#ifdef BN_WGRAD_BIAS_INLINE
-#define BN_F_WGRAD_BIAS_INLINE "BN_WGRAD_BIAS_INLINE "
-#else
-#define BN_F_WGRAD_BIAS_INLINE ""
-#endif
 #ifdef BN_DIAG_D8_IN_F32
 #define BN_F_DIAG_D8_IN_F32 "BN_DIAG_D8_IN_F32 "
 #else
@@ -200,6 +200,6 @@
 // the same defines to every file
 #define BN_BUILD_FLAGS_STRING                                                                                              \
   BN_F_PHASE_TIMING BN_F_PHASE_TIMING_WGRAD BN_F_CLOCK_STAMP BN_F_CLOCK_STAMP_WGRAD BN_F_TIMELINE BN_F_GEMM_PRIO          \
-  BN_F_PRIO_YOUNG BN_F_NO_NT_STASH BN_F_NO_PINGPONG BN_F_BWD_NO_PINGPONG BN_F_PP_LOOP_NKS BN_F_PP_SPLIT BN_F_NO_FIXED_FULL BN_F_NO_BUFW BN_F_FWD_DEPTH_TRAIN            \
+  BN_F_PRIO_YOUNG BN_F_NO_NT_STASH BN_F_NO_PINGPONG BN_F_BWD_NO_PINGPONG BN_F_PP_LOOP_NKS BN_F_PP_SPLIT BN_F_NO_FIXED_FULL BN_F_ADJ_LOOP BN_F_NO_BUFW BN_F_FWD_DEPTH_TRAIN            \
   BN_F_BWD_DEPTH BN_F_BWD_PP_DEPTH BN_F_BWD_D_AT BN_F_HEAD_WIDE BN_F_NO_FLAT_COMPOSITE BN_F_DPH BN_F_SKINNY_SPLITS        \
-  BN_F_W2_BLOCKS BN_F_WGRAD_BIAS_INLINE BN_F_DIAG_D8_IN_F32 BN_F_PROBE_NO_A BN_F_PROBE_NO_B BN_F_PROBE_NO_D BN_F_PROBE_NO_RIDE BN_F_ABLATION_BUILD
+  BN_F_W2_BLOCKS BN_F_DIAG_D8_IN_F32 BN_F_PROBE_NO_A BN_F_PROBE_NO_B BN_F_PROBE_NO_D BN_F_PROBE_NO_RIDE BN_F_ABLATION_BUILD

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjbwd_kernel(const AdjBw
       if (l > 0) {
         if (ride) {
           TileCopyExact<T> acopy(ACT, LDA, adst, F, F, tid, WAVES * 64);
+          // (as a straight-line stream - gemm_fixed - this product takes the kernel from 0 to 624 B of scratch per lane: looped form)
           gemm_seg<T, MT, NT, DP>(acc, w_h, KSF, ACT, LDA, lane, acopy);
         } else {
           gemm_seg<T, MT, NT, DP>(acc, w_h, KSF, ACT, LDA, lane);

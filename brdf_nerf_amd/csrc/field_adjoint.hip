@@ -115,9 +115,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void field_adjoint_kernel(const AdjA
       const T *w_t = packed + A.pl.bwd_trunk[l] + (size_t)(ncol0 / 32) * KSF * 512;
       if (keep && ride) {
         TileCopyExact<T> dcopy(ACT, LDA, ddst, F, F, tid, WAVES * 64);
-        gemm_seg<T, MT, NT, DP>(acc, w_t, KSF, ACT, LDA, lane, dcopy);
+        gemm_full32<T, MT, NT, DP, NT == 2>(acc, w_t, KSF, ACT, LDA, lane, dcopy);
       } else {
+#ifndef BN_ADJ_LOOP
+        gemm_full<T, MT, NT, DP, NT == 2>(acc, w_t, KSF, ACT, LDA, lane);      // (inference: no riding copy)
+#else
         gemm_seg<T, MT, NT, DP>(acc, w_t, KSF, ACT, LDA, lane);
+#endif
       }
 #pragma unroll
       for (int nt = NPRE; nt < NT; ++nt)

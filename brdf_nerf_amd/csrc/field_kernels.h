@@ -391,9 +391,9 @@ __device__ __forceinline__ void gemm_range(f32x16 (&acc)[NTW][MT], const T *__re
 struct NoMid {
   __device__ __forceinline__ void operator()() const {}
 };
-template <typename T, int MT, int NTW, int DEPTH, int NKS, int MID, typename Mid>
+template <typename T, int MT, int NTW, int DEPTH, int NKS, int MID, typename Mid, typename Side = NoSide>
 __device__ __forceinline__ void gemm_fixed(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, int ks0, const T *bsrc, int ldb,
-                                           int lane, Mid &&mid) {
+                                           int lane, Mid &&mid, Side &&side = Side()) {
   typedef typename Elem<T>::frag frag;
   static_assert(sizeof(frag) == 16, "16-bit modes only: one 16-byte fragment piece per lane");
   static_assert(MID >= 0 && MID < NKS && DEPTH <= NKS && (MID == 0 || DEPTH <= MID), "the ring must not wrap inside the prologue");
@@ -438,6 +438,7 @@ __device__ __forceinline__ void gemm_fixed(f32x16 (&acc)[NTW][MT], const T *__re
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) A[j % DEPTH][nt] = ldA(nt, j + DEPTH);
     }
+    side.at(j & 1);      // (side job of the segment, gemm_range: a row-major stash copy riding under the MFMAs)
     __builtin_amdgcn_sched_barrier(0);
     if (MID > 0 && j + 1 == MID) {
       mid();
@@ -478,6 +479,18 @@ __device__ __forceinline__ void gemm_full(f32x16 (&acc)[NTW][MT], const T *__res
   }
 #endif
   gemm_seg<T, MT, NTW, DP>(acc, wp, KS, bsrc, ldb, lane);
+}
+// the F = 512 trunk product (32 k-steps) of the analytic-normal chains with a riding stash copy (field_adjoint / field_adjbwd)
+template <typename T, int MT, int NTW, int DP, bool HOT, typename Side>
+__device__ __forceinline__ void gemm_full32(f32x16 (&acc)[NTW][MT], const T *__restrict__ wp, int KS, const T *bsrc, int ldb, int lane,
+                                            Side &side) {
+#ifndef BN_ADJ_LOOP      // A/B switch (results unchanged): the looped form (round 4); straight-line: adjoint chain -8.6 %, r05 item 7
+  if constexpr (HOT && sizeof(T) == 2) {
+    constexpr int D = (DP & (BN_GEMM_AFFINE - 1)) < 2 ? 2 : (DP & (BN_GEMM_AFFINE - 1));
+    if (KS == 32) { gemm_fixed<T, MT, NTW, D, 32, 0>(acc, wp, KS, 0, bsrc, ldb, lane, NoMid(), side); return; }
+  }
+#endif
+  gemm_seg<T, MT, NTW, DP>(acc, wp, KS, bsrc, ldb, lane, side);
 }
 
 template <int MT, int NTW> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NTW][MT]) {

@@ -301,6 +301,9 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   // 10 % of the kernel (a probe without the sums: -15 %; profiles/r04_ablation.txt item 17, where the other forms tried are:
   // stage-loop instances with / without the sums spill inside the loop; the tiles numbered from the wave's own half - no
   // selects - measured 3 % slower than the selects).
+  // Round 5 (profiles/r05_ablation.txt item 6): the sums as a property of the KERNEL instantiation - the grid launched twice, once
+  // for the workgroups that store them and once, without any sums, for the others - measured 3.48 ms against 2.25: the tiles of a
+  // row / column of a job share their operands through L2 only while they run TOGETHER.  One launch, the sums in every workgroup.
   constexpr int BA = W2_RA / 2;
   const bool do_bias = J.bias != nullptr && k0 == 0;
   float bsum[BA];

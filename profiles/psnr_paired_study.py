@@ -1,11 +1,12 @@
-"""north_star "PSNR within 0.05 dB": paired study of the BRDF stage (BASELINE config 3's model, RPV + analytic normals).
+"""north_star "PSNR within 0.05 dB": paired study of the BRDF stage (BASELINE config 3's model, RPV + analytic normals; round 5:
+BASELINE config 5's models too - Hapke (b, c), Hapke (b, c, theta), microfacet, all with analytic normals).
 
 All modes start from ONE fp32 Lambertian pretraining (400 steps); then the BRDF stage (default 600 steps, lr 5e-4 -> 0) runs
 in fp32 / bf16 / fp16 with the same batches and, per seed, the same in-kernel draws, in deterministic mode (bitwise
 reproducible sums: what differs between the modes of a pair is the arithmetic, nothing else).  Reports the held-out PSNR per
 run, the paired differences to fp32, their mean, standard deviation and the 95 % interval of the mean (Student t).
 
-    python profiles/psnr_paired_study.py [--seeds=16] [--first-seed=101] [--steps=600] [--config=rpv_nan|lambert]
+    python profiles/psnr_paired_study.py [--seeds=16] [--first-seed=101] [--steps=600] [--config=rpv_nan|lambert|hapke_bc|hapke_bct|microfacet]
     python profiles/psnr_paired_study.py --combine=a.txt,b.txt,...     # statistics over the "seed N: ..." lines of earlier runs
 """
 import os
@@ -41,7 +42,10 @@ def main():
     from oracle.config import FieldConfig
     brdf_nerf_amd.set_deterministic(True)
     brdf = config != "lambert"
-    cfg = FieldConfig(n_samples=64, guided_samples=64, **(T.RPV_NAN if brdf else {}))
+    models = dict(T.C5_MODELS, rpv_nan=T.RPV_NAN, lambert={})
+    cfg = FieldConfig(n_samples=64, guided_samples=64, **models[config])
+    from brdf_nerf_amd import build as B
+    print(f"kernel sources {B.source_hash()} (library {B.library_hash()})", flush=True)
     train, held = T._learnable_table(1024 * 64, 3), T._learnable_table(8192, 11)
     warm = first = None
     if brdf:

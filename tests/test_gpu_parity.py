@@ -1870,6 +1870,14 @@ def test_full_size_render_and_train_step_properties(name):
              f"the three worst matrices and their share of |g|^2: " + ", ".join(f"{k} {c:.3f} ({m:.1e})" for k, c, m in bad[:3]))
         diag(f"full size {name} ({dtype}): {dtype} field backward started from the fp32 mode's gradient rows - worst weight-matrix gradient "
              f"cosine {seeded:.5f} ({seeded_k}), worst of all parameters {seeded_all:.5f} ({seeded_all_k}), whole flat gradient {whole:.6f}")
+        # Round 5: where the problem is well conditioned - the referee, fp32 arithmetic on 16-bit-rounded
+        # weights, keeps a whole-gradient cosine >= 0.9 - the UNSEEDED 16-bit step must stay within 0.1 of it.  Round 4's fp16
+        # steps with the 8-bit derivative stash did not (microfacet 0.077 / Hapke + theta 0.875 against 0.998 / 0.997: the analytic
+        # normal's adjoint chain multiplies by D_l in every layer, profiles/r05_ablation.txt item 4); with the fp16 derivative stash
+        # of the fp16 mode (DK16): Hapke 0.987 / Hapke + theta 0.9935 against 0.990 / 0.9995.  The margin is wide because the GGX
+        # lobe's derivative w.r.t. the normal turns 0.1 degrees into several per cent of the cosine.
+        if e2e_ref >= 0.9:
+            assert e2e >= e2e_ref - 0.1, (name, e2e, e2e_ref)
         bf16_an = dtype == "bf16" and kw.get("normal") in ("analystic", "analystic_learned")
         assert whole >= (0.98 if bf16_an else 0.995), whole         # (bf16 + analytic normals: measured 0.993 .. 0.9992, see below)
         # (bf16 through the analytic-normal double backward: 8 significant bits over two chained passes, and the first layer's
@@ -2045,6 +2053,48 @@ def test_reduced_precision_heldout_psnr_tracks_fp32_rpv_analytic_normals():
     diag(f"held-out PSNR rpv_nan, {n_long} BRDF steps, {reps} draw seeds per mode: "
          + ", ".join(f"{k} {mean[k]:.4f} dB (runs {' '.join(f'{x:.4f}' for x in v)})" for k, v in long_.items()) + "; " + "; ".join(msg))
     assert all(m > first + 3.0 for m in mean.values()), (long_, first)
+
+
+C5_MODELS = {    # BASELINE config 5's BRDF models (FULL_SIZE above), analytic normals as in the configuration
+    "hapke_bc": dict(b=1, c=1, normal="analystic"),
+    "hapke_bct": dict(b=1, c=1, theta=1, normal="analystic"),
+    "microfacet": dict(roughness=True, normal="analystic"),
+}
+
+
+@pytest.mark.parametrize("name", list(C5_MODELS))
+def test_reduced_precision_heldout_psnr_tracks_fp32_config5(name):
+    """VERDICT r4 item 2: the PSNR gate of config 3 for BASELINE config 5's models (Hapke (b, c), Hapke (b, c, theta), microfacet;
+    fp16 is the dtype BASELINE.json names, bf16 runs beside it).  The short in-suite form of
+    test_reduced_precision_heldout_psnr_tracks_fp32_rpv_analytic_normals: (a) the BRDF stage trained in fp32 (400 Lambertian + 400
+    BRDF steps), then CONTINUED for 150 steps (lr 1e-4 -> 0, Adam state carried) in every mode, BN_PSNR_REPEATS draw seeds,
+    paired by seed: the mean paired difference within the north_star's 0.05 dB; (b) 300 BRDF steps from the warm start with
+    fresh heads and optimiser state, two seeds: every mode learned the scene, paired means within 0.5 dB (the gross-error gate).
+    The statistical statement over >= 64 paired seeds is profiles/psnr_paired_study.py --config=<name>, kept in
+    profiles/r05_psnr_paired_<name>.txt."""
+    cfg = FieldConfig(n_samples=64, guided_samples=64, **C5_MODELS[name])
+    train, held = _learnable_table(1024 * 64, 3), _learnable_table(8192, 11)
+    _, first, warm = _psnr_run(cfg, "fp32", 400, 0, train, held, draw_seed=1)
+    adam = {}
+    p_trained, _, trained = _psnr_run(cfg, "fp32", 0, 400, train, held, draw_seed=3, init_state=warm, keep_adam=adam)
+    reps = int(os.environ.get("BN_PSNR_REPEATS", "3"))
+    short = {dtype: [_psnr_run(cfg, dtype, 0, 150, train, held, draw_seed=7 + r, init_state=trained, lr0=1e-4, adam=adam)[0]
+                     for r in range(reps)] for dtype in ("fp32", "bf16", "fp16")}
+    pair = {k: [a - b for a, b in zip(short[k], short["fp32"])] for k in ("bf16", "fp16")}
+    diag(f"held-out PSNR config 5 {name}, 150 more BRDF steps (lr 1e-4 -> 0, Adam state carried) from a shared fp32 model "
+         f"({p_trained:.4f} dB after 400 + 400 steps; first-step training PSNR {first:.2f} dB), {reps} draw seeds: "
+         + ", ".join(f"{k} {sum(v) / reps:.4f} dB" for k, v in short.items()) + "; paired differences to fp32: "
+         + ", ".join(f"{k} {sum(v) / reps:+.4f} dB (per seed {' '.join(f'{x:+.4f}' for x in v)})" for k, v in pair.items()))
+    for k, v in pair.items():
+        assert abs(sum(v) / reps) <= 0.05, (name, k, short)
+    long_ = {dtype: [_psnr_run(cfg, dtype, 0, 300, train, held, draw_seed=11 + r, init_state=warm)[0] for r in range(2)]
+             for dtype in ("fp32", "bf16", "fp16")}
+    mean = {k: sum(v) / len(v) for k, v in long_.items()}
+    diag(f"held-out PSNR config 5 {name}, 300 BRDF steps from the warm start, 2 draw seeds per mode: "
+         + ", ".join(f"{k} {mean[k]:.4f} dB (runs {' '.join(f'{x:.4f}' for x in v)})" for k, v in long_.items()))
+    for k in ("bf16", "fp16"):
+        assert abs(mean[k] - mean["fp32"]) <= 0.5, (name, k, long_)
+    assert all(m > first + 3.0 for m in mean.values()), (name, long_, first)
 
 
 def _free_port():
