@@ -134,7 +134,7 @@ def box_calibration(dev, n=8192, seconds=1.0, when="after the bench"):
 
 def cpu_baseline(args, rays=512, seconds_budget=30.0):
     """Time the CPU oracle (port of the reference's PyTorch path) on a bounded sample: same network, same S/G, `rays` rays
-    per step.  profiles/r02_cpu_cross_timing.txt holds the oracle-vs-imported-reference timing of the same step taken in
+    per step.  profiles/history/r02_cpu_cross_timing.txt holds the oracle-vs-imported-reference timing of the same step taken in
     the build container: the stand-in is within a few per cent of the reference itself.
     Bounded (round 4's sweep spent ~150 s in a 256-thread leg): 8 / 16 / min(allowed, 64) threads, each leg
     one warm-up step (itself timed, and taken as the leg's result when it alone exceeds the leg's budget) and at most two steps
@@ -188,17 +188,17 @@ def cpu_baseline(args, rays=512, seconds_budget=30.0):
                 sweep={str(k): round(v[0], 1) for k, v in sweep.items()}, seconds=round(time.perf_counter() - t_all, 1),
                 sample=f"{n} training step(s) of {rays} rays x {args.n_samples}+{args.guided_samples} samples (same network, fp32, "
                        f"torch CPU oracle, {cores} threads)" + (" = the leg's first step" if warm_only else " after 1 warm-up step"),
-                cross_timing="profiles/r02_cpu_cross_timing.txt (oracle vs the imported reference, build container)")
+                cross_timing="profiles/history/r02_cpu_cross_timing.txt (oracle vs the imported reference, build container)")
 
 
 from brdf_nerf_amd.build import source_hash  # noqa: E402  (key of the committed PMC passes)
 
 
 def pmc_record(config, dtype):
-    """Per-kernel counters of the committed rocprofv3 PMC passes (profiles/pmc_collect.sh -> profiles/r03_pmc.json), or
+    """Per-kernel counters of the committed rocprofv3 PMC passes (profiles/pmc_collect.sh -> profiles/r05_pmc.json), or
     ({}, reason) when there is none for this workload or the kernel sources have changed since it was taken."""
-    # the newest committed record whose key matches the sources wins (one per round: profiles/r05_pmc.json, profiles/history/...)
-    cands = [os.path.join(ROOT, "profiles", "r05_pmc.json"), os.path.join(ROOT, "profiles", "history", "r04_pmc.json")]
+    # the newest committed record whose key matches the sources wins (one per round)
+    cands = [os.path.join(ROOT, "profiles", "r05_pmc.json"), os.path.join(ROOT, "profiles", "r04_pmc.json")]
     cands = [c for c in cands if os.path.exists(c)]
     if not cands:
         return {}, "no PMC pass committed"

@@ -215,9 +215,10 @@ def lib():
 
 def set_deterministic(on=True):
     """The reference's Trainer(deterministic=True) (main.py:726).  Since round 4 the parameter gradients are bitwise reproducible
-    in EVERY mode (the weight-gradient kernels write per-split slabs that are summed in fixed order: no atomics); what the switch
-    still changes is the REPORTED loss of the launch-lean step: a fixed-order sum of the per-ray terms instead of atomically
-    added partial sums.  Also switched on by BRDFNERF_DETERMINISTIC=1.  Returns the previous setting."""
+    in EVERY mode (the weight-gradient kernels write per-split slabs that are summed in fixed order: no atomics), and since round 5
+    so is the REPORTED loss of the launch-lean step (FusedTrainer.repeatable_loss: a fixed-order sum of the per-ray terms).  The
+    switch is kept for callers that set it (it is part of a captured step's signature) and changes no result.  Also switched on
+    by BRDFNERF_DETERMINISTIC=1.  Returns the previous setting."""
     return bool(lib().bn_set_deterministic(1 if on else 0))
 
 

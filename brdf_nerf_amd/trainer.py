@@ -59,6 +59,10 @@ class FusedTrainer:
         self.seed_hook = None           # callable(name, tensor): sees / may overwrite "z2" (guided depths), "out_all" (the per-sample field
                                         # outputs of both passes, merged step) and "d_all" (the gradient rows the field backward starts
                                         # from) of a launch-lean step (tests, profiles/diag_c5_rows.py; such steps are not captured)
+        # The LOGGED loss as a fixed-order sum of the per-ray terms (one more small launch per step) instead of float atomics into
+        # 64 slots of the step state: a run's printed losses repeat bit for bit like its gradients do (rounds 3-4
+        # did this in deterministic mode only).  False: the atomics (the loss ring of the step state), one launch fewer.
+        self.repeatable_loss = True
         self.use_graph = True
         self.graph_after = 3            # eager steps with an unchanged signature before the step is captured
         self.max_graphs = 16            # captured steps kept (least recently used evicted; each owns a private memory pool)
@@ -430,7 +434,8 @@ class FusedTrainer:
                    nf.data_ptr(), use_ds, tuple(active), float(self.ds_lambda), float(self.lambda_rgb), bool(self.usealldepth),
                    L.deterministic(), int(self.ray_offset), bool(self.keep_grads), bool(self.merge_passes), bool(apply_brdf),
                    bool(cos_irra_on), float(reg.get("hs", 0)), bool(self.sanitize_grads), float(reg.get("nr_an", 0)),
-                   float(reg.get("nr_lr", 0)), bool(gsam_only), self._noise_f32() != 0.0, float(reg.get("nr_spv", 0)))
+                   float(reg.get("nr_lr", 0)), bool(gsam_only), self._noise_f32() != 0.0, float(reg.get("nr_spv", 0)),
+                   bool(self.repeatable_loss))
             ent = self._graphs.get(sig)
             if ent is not None:
                 self._graphs.move_to_end(sig)
@@ -577,7 +582,7 @@ class FusedTrainer:
             # kernels turns its gradient rows into those of the field outputs.  ~20 small launches, all inside the captured graph.
             from .rendering import _per_ray_brdf
             rgb = self._buf("rgb", (R, 3))
-            det = L.deterministic()
+            det = self.repeatable_loss
             ray_loss = self._buf("ray_loss", (R,)) if det else None
             X = out2 if gsam_only else (out_all if merged else torch.cat([out1, out2], 0))
             n1 = R * S                                   # rows of the first block (gsam_only: all of them, S = G here)
@@ -617,7 +622,7 @@ class FusedTrainer:
                     torch.nan_to_num_(d_all, nan=0.0, posinf=0.0, neginf=0.0)
         elif lambertian:
             rgb = self._buf("rgb", (R, 3))
-            det = L.deterministic()        # the reported loss too: a fixed-order sum of the per-ray terms instead of atomics
+            det = self.repeatable_loss        # the reported loss too: a fixed-order sum of the per-ray terms instead of atomics
             ray_loss = self._buf("ray_loss", (R,)) if det else None
             with torch.no_grad():
                 Fn.lambert_tail(z_all, idx, out1v, out2v, rgbs, model.rgb_padding, self.lambda_rgb, d1o, d2o,
@@ -634,7 +639,7 @@ class FusedTrainer:
             desc = shade_desc(model, args, spec, apply_brdf, cos_irra_on, self.lambda_rgb, self.ds_lambda if use_ds else 0.0,
                               hs, self.usealldepth,
                               irr=sun_irr if (gsam_only and getattr(model, "sun_v", "none") == "analystic" and apply_brdf) else None)
-            det = L.deterministic()
+            det = self.repeatable_loss
             ray_loss = self._buf("ray_loss", (R,)) if det else None
             # NormalRegLoss on the per-sample normals (metrics.py:179-216): its value and gradient come from the compositing kernels
             # NormalLoss between the two normal fields (nr_spv_type 1, main.py:297-303): two batch-wide means - the rays' sums come

@@ -2,7 +2,7 @@
 reference's own CPU path?  Times ONE training step (render_rays + SNerfLoss + DepthLoss + backward + Adam) of the imported
 reference and of the oracle on the same rays / parameters, alternating, in this container (8 host cores).  Build-container
 only: needs /root/reference (read-only; imported with the six I/O-only modules stubbed, exactly like
-tests/golden/make_goldens.py).  Output -> profiles/r02_cpu_cross_timing.txt.
+tests/golden/make_goldens.py).  Output -> profiles/history/r02_cpu_cross_timing.txt.
 
     python profiles/cpu_cross_timing.py [rays=1024] [reps=2]
 """

@@ -473,7 +473,7 @@ def test_random_fused_step_half_and_deterministic(seed):
     nr_an = cfg.normal in ("analystic", "analystic_learned")
     # Tracking is asserted where the problem is well conditioned.  With a BRDF on a RANDOM (untrained) model the loss gradient is
     # a near-cancelling sum over rays at grazing angles / GGX peaks: fp32 itself is dominated by a handful of rays there, and the
-    # autograd path in the same 16-bit mode reproduces the fused step exactly (profiles/r02_ablation.txt, session 41 note) - those
+    # autograd path in the same 16-bit mode reproduces the fused step exactly (profiles/history/r02_ablation.txt, session 41 note) - those
     # cases only have to stay finite and keep the loss.  Without a BRDF: fp16 (11 bits) tightly - it runs the same templates as
     # bf16, so a kernel fault shows there - bf16 (8 bits) coarsely; its acceptance criterion is the PSNR gate.
     assert abs(l16a - l32) <= 0.05 * abs(l32) + 1e-4, f"{tag}: loss {l16a} vs {l32}"

@@ -1844,7 +1844,7 @@ def test_full_size_render_and_train_step_properties(name):
         ref, ref_k = worst_cos("fp32", "fp32_w16")
         diag(f"full size {name} ({dtype}): worst per-matrix gradient cosine vs the fp32 HIP mode {worst:.5f} ({worst_k}); the fp32 mode on "
              f"{dtype}-rounded weights: {ref:.5f} ({ref_k}); dropped {dropped}")
-        # (measured, profiles/r03_parity_errors.txt: the referee itself scatters between -0.99 and 0.997 over these configurations -
+        # (measured, profiles/history/r03_parity_errors.txt: the referee itself scatters between -0.99 and 0.997 over these configurations -
         # a sign flip of the roughness head's bias gradient included - i.e. the BRDF-stage gradient at this state is not
         # reproducible to 2^-9 in the weights; where it is well conditioned, hapke + theta, the 16-bit modes reach 0.94-0.95)
         # -> the end-to-end cosines are REPORTED.  ASSERTED is what the 16-bit kernels are responsible for: every mode runs the
@@ -2003,10 +2003,10 @@ def test_reduced_precision_heldout_psnr_tracks_fp32_rpv_analytic_normals():
       (b) 600 BRDF steps from the warm start, paired by draw seed: the stage restarts three heads from their initialisation
           with a fresh optimiser state; its first 50 steps throw the held-out PSNR anywhere between 16.6 and 19.1 dB in EVERY
           mode and the end states scatter by +-0.15 dB with either sign (fp32 against itself included:
-          profiles/r02_psnr_transient_study.txt).  Three seeds cannot resolve 0.05 dB: the default run only catches a broken
+          profiles/history/r02_psnr_transient_study.txt).  Three seeds cannot resolve 0.05 dB: the default run only catches a broken
           mode (every mode learned the scene, paired means within 0.5 dB); the statistical statement - mean paired difference
           and its 95 % interval over >= 64 seeds in deterministic mode - is profiles/psnr_paired_study.py's, kept in
-          profiles/r03_psnr_paired_rpv.txt, and this test applies the same gate when run with BN_PSNR_PAIRED_SEEDS >= 16."""
+          profiles/history/r03_psnr_paired_rpv.txt, and this test applies the same gate when run with BN_PSNR_PAIRED_SEEDS >= 16."""
     import statistics
     cfg = FieldConfig(n_samples=64, guided_samples=64, **RPV_NAN)
     train, held = _learnable_table(1024 * 64, 3), _learnable_table(8192, 11)
@@ -2029,7 +2029,7 @@ def test_reduced_precision_heldout_psnr_tracks_fp32_rpv_analytic_normals():
         assert abs(sum(v) / reps) <= 0.05, (k, short)
     # (b) paired by draw seed (round 3): per seed the three modes see the same batches and the same in-kernel draws; with
     # BN_PSNR_PAIRED_SEEDS >= 16 (profiles/psnr_paired_study.py runs the same protocol in deterministic mode and keeps its table
-    # in profiles/r03_psnr_paired_rpv.txt: the paired differences have a standard deviation of ~0.19 dB, so the 95 % interval of
+    # in profiles/history/r03_psnr_paired_rpv.txt: the paired differences have a standard deviation of ~0.19 dB, so the 95 % interval of
     # their mean closes to +-0.05 dB at ~64 seeds) the mean paired difference and its interval are gated; the default three seeds
     # only catch a broken mode
     from scipy import stats
@@ -2200,6 +2200,8 @@ def test_gradients_are_bitwise_reproducible_by_default(name, dtype, feat, R):
     b = bench.synthetic_batch(R, 5, torch.device(DEV))
     rays, rgbs = b["rays"], b["rgbs"]
 
+    losses = []          # per run: the step losses as the trainer reports them
+
     def run(det, steps=1, graph=False):
         prev = brdf_nerf_amd.set_deterministic(det)
         try:
@@ -2207,9 +2209,11 @@ def test_gradients_are_bitwise_reproducible_by_default(name, dtype, feat, R):
             model = build_model(cfg, 11, dtype)
             tr = FusedTrainer(model, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
             tr.use_graph, tr.keep_grads = graph, steps == 1
+            losses.append([])
             for _ in range(steps):
-                tr.step(rays, rgbs, valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"], near_far=(0.0, 2.0),
-                        **flags)
+                l_, _ = tr.step(rays, rgbs, valid_depth=b["valid_depth"], depths=b["depths"], depth_std=b["depth_std"], near_far=(0.0, 2.0),
+                                **flags)
+                losses[-1].append(l_.clone())          # (a replayed graph rewrites its output tensor: keep the value)
             torch.cuda.synchronize()
             return tr.flat_grad.clone(), tr.flat_param.clone(), len(tr._graphs)
         finally:
@@ -2227,6 +2231,11 @@ def test_gradients_are_bitwise_reproducible_by_default(name, dtype, feat, R):
     assert torch.equal(q1, q2), f"replayed steps differ: max {float((q1 - q2).abs().max()):.3e}"
     _, q3, _ = run(False, steps=8, graph=False)
     assert torch.equal(q1, q3), f"replayed and eager steps differ: max {float((q1 - q3).abs().max()):.3e}"
+    # round 5: the LOGGED losses repeat bit for bit too (a fixed-order sum of the per-ray terms, FusedTrainer.repeatable_loss;
+    # rounds 3-4 added them up with float atomics outside the deterministic mode) - run to run, eager or replayed
+    as_bits = lambda ls: [float(x) for x in ls]
+    assert as_bits(losses[0]) == as_bits(losses[1]) == as_bits(losses[2]), "the logged loss of one step differs between runs"
+    assert as_bits(losses[3]) == as_bits(losses[4]) == as_bits(losses[5]), "the logged losses of eight steps differ between runs"
     faults = C.c_uint(0)
     _lib.check(_lib.lib().bn_device_faults(C.byref(faults), None), "bn_device_faults")
     assert faults.value == 0
