@@ -170,13 +170,12 @@ class FusedTrainer:
         dev = rays.device
         spec = model.spec(apply_brdf, apply_theta, self.nr_lr, self.nr_an, beta=False)   # (field.py spec(): the loss never reads beta)
         reg0 = self.reg if regularisers else {}
-        # (a loss that reads per-sample channels of the merged set beyond NormalRegLoss / NormalLoss - MultiBRDF - keeps the general path)
-        # --MultiBRDF (one BRDF per sample, spsbrdfnerf.py:289-307,350-352) is a lean step when nothing else reads per-sample
-        # channels: no regulariser, no sun pass (its irradiance is per sample there) - see _lean_body
+        # --MultiBRDF (one BRDF per sample, spsbrdfnerf.py:289-307,350-352) is a lean step unless the sun pass is on (its irradiance is
+        # per sample there) - see _lean_body; the regularisers ride in the compositing kernels as they do for one BRDF per ray
         multi = bool(model.MultiBRDF) and apply_brdf
         kind = self._shade_kind(spec, apply_brdf, cos_irra_on)
-        per_sample0 = multi and (any(abs(float(v)) > 0 for v in reg0.values()) or getattr(model, "sun_v", "none") == "analystic"
-                                 or kind == L.BN_SHADE_LAMBERT)
+        # (round 5: with a regulariser too - _lean_body composites a full-width copy through the generic kernels then)
+        per_sample0 = multi and (getattr(model, "sun_v", "none") == "analystic" or kind == L.BN_SHADE_LAMBERT)
         # the sun-visibility pass (rendering.py:244-259) is a lean step where the reference runs it (gsam_only) and a BRDF shades the
         # ray (its rgb then reads the sun pass through ONE per-ray factor, spsbrdfnerf.py:354); per-sample irradiance of a
         # Lambertian rgb, and the sun pass's own noise draws, keep the general path
@@ -592,6 +591,9 @@ class FusedTrainer:
             c0 = spec.ch_normal_lr if spec.normal_lr else spec.ch_normal_an          # learned wins when both are present
             pad = model.rgb_padding
             sun_d = rays[:, 8:11] if args.data == "sat" else torch.ones_like(rays[:, 0:3])
+            hs = float(reg.get("hs", 0))
+            spv = float(reg.get("nr_spv", 0)) if (spec.normal_an and spec.normal_lr and abs(reg.get("nr_spv", 0)) > 1e-5) else 0.0
+            with_reg = hs > 0 or spv != 0.0 or float(reg.get("nr_an", 0)) > 0 or float(reg.get("nr_lr", 0)) > 0
             with torch.enable_grad():
                 Xl = X.detach().requires_grad_(True)
                 heads = {name: Xl[:, h0:h0 + wdt] for (name, _, _), (h0, wdt) in zip(spec.heads[1:], spec.head_cols[1:])}
@@ -599,21 +601,64 @@ class FusedTrainer:
                 bp = brdf * (1 + 2 * pad) - pad
                 if cos_irra_on:
                     bp = bp * sun_d[:, 2:3].abs()[row_ray]              # upward normal: irradiance = |sun_z| (:260-264)
-                B = torch.cat([bp, Xl[:, 3:4]], 1)
-            with torch.no_grad():
-                Bd = B.detach()
-                d_B = self._buf("d_B", (X.shape[0], 4))
-                B1 = Bd[:n1].view(R, S, 4)
-                B2 = None if gsam_only else Bd[n1:].view(R, G, 4)
-                dB1 = d_B[:n1].view(R, S, 4)
-                dB2 = None if gsam_only else d_B[n1:].view(R, G, 4)
-                Fn.lambert_tail(z_all, idx, B1, B2, rgbs, 0.0, self.lambda_rgb, dB1, dB2,
-                                valid_depth if use_ds else None, depths[:, 0] if use_ds else None, depths[:, 1] if use_ds else None,
-                                depth_std if use_ds else None, self.ds_lambda if use_ds else 0.0, self.usealldepth,
-                                ray_loss=ray_loss, loss_acc=None if det else Fn.state_loss_partials(st), rgb=rgb,
-                                nonfinite=self._nonfinite if self.sanitize_grads else None, noise=nz2)
-                if det:
-                    loss = ray_loss.sum()
+                # no regulariser: a 4-channel copy [bp, sigma] for the one-launch Lambertian tail; with one (round 5): a FULL-width
+                # copy - the rows as they are stored, their colour channels replaced by bp - for the generic compositing kernels,
+                # which carry NormalRegLoss / NormalLoss / HardSurfaceLoss on the per-sample normals and weights
+                B = torch.cat([bp, Xl[:, 3:]] if with_reg else [bp, Xl[:, 3:4]], 1)
+            if with_reg:
+                with torch.no_grad():
+                    Bd = B.detach()
+                    d_B = self._buf("d_Bfull", (X.shape[0], C))
+                    B1 = Bd[:n1].view(R, S, C)
+                    B2 = None if gsam_only else Bd[n1:].view(R, G, C)
+                    dB1 = d_B[:n1].view(R, S, C)
+                    dB2 = None if gsam_only else d_B[n1:].view(R, G, C)
+                    # identity shading of the composited colour: a Lambertian descriptor with no padding and no irradiance (both
+                    # are inside bp already), the losses and regularisers as for one BRDF per ray
+                    from . import _lib as L_
+                    desc = L_.ShadeDesc()
+                    desc.kind, desc.C, desc.ch_normal = L.BN_SHADE_LAMBERT, C, -1
+                    desc.ch_p0 = desc.ch_p1 = desc.ch_p2 = -1
+                    desc.rhoc_is_albedo = desc.shell = desc.cos_irradiance = 0
+                    desc.usealldepth = int(bool(self.usealldepth))
+                    desc.hpk_scl, desc.f0, desc.rgb_padding = 1.0, 0.04, 0.0
+                    desc.lambda_rgb, desc.lambda_ds, desc.lambda_hs = float(self.lambda_rgb), float(self.ds_lambda if use_ds else 0.0), hs
+                    nreg = Fn.normal_reg(rays[:, 3:6], spec.ch_normal_an if spec.normal_an else -1, spec.ch_normal_lr if spec.normal_lr else -1,
+                                         float(reg.get("nr_an", 0)), float(reg.get("nr_lr", 0)), lambda_spv=spv,
+                                         spv_ray=self._buf("spv_ray", (R, 2)) if spv else None, spv_tot=self._buf("spv_tot", (4,)) if spv else None)
+                    o = Fn.merged_composite_forward(z_all, idx, B1, B2,
+                                                    {k: self._buf("m_" + k, sh) for k, sh in (("depth", (R,)), ("acc", (R, C)),
+                                                                                              ("wsum", (R,)), ("var", (R,)), ("reg", (R,)))},
+                                                    want=("depth", "acc", "wsum", "var"), nreg=nreg, noise=nz2)
+                    sb = {k: self._buf("s_" + k, sh) for k, sh in (("rgb", (R, 3)), ("d_acc", (R, C)), ("d_wsum", (R,)), ("d_depth", (R,)))}
+                    gq = Fn.ray_shade_loss(desc, o["acc"], o["wsum"], o["depth"], o["var"], rays[:, 3:6], None, rgbs, sb,
+                                           valid_depth if use_ds else None, depths[:, 0] if use_ds else None,
+                                           depths[:, 1] if use_ds else None, depth_std if use_ds else None, ray_loss=ray_loss,
+                                           loss_acc=None if det else Fn.state_loss_partials(st),
+                                           nonfinite=self._nonfinite if self.sanitize_grads else None, extra_loss=o.get("reg"))
+                    rgb = gq["rgb"]
+                    if spv:
+                        Fn.normal_spv_reduce(nreg, R, z_all.shape[1], ray_loss=ray_loss, loss_acc=None if det else Fn.state_loss_partials(st))
+                    Fn.merged_composite_backward(z_all, idx, B1, B2, None, gq["d_depth"], gq["d_acc"], dB1, dB2, d_wsum=gq["d_wsum"],
+                                                 nonfinite=self._nonfinite if self.sanitize_grads else None,
+                                                 hs_scale=hs / R if hs > 0 else 0.0, depth=o["depth"], nreg=nreg, noise=nz2)
+                    if det:
+                        loss = ray_loss.sum()
+            else:
+              with torch.no_grad():
+                  Bd = B.detach()
+                  d_B = self._buf("d_B", (X.shape[0], 4))
+                  B1 = Bd[:n1].view(R, S, 4)
+                  B2 = None if gsam_only else Bd[n1:].view(R, G, 4)
+                  dB1 = d_B[:n1].view(R, S, 4)
+                  dB2 = None if gsam_only else d_B[n1:].view(R, G, 4)
+                  Fn.lambert_tail(z_all, idx, B1, B2, rgbs, 0.0, self.lambda_rgb, dB1, dB2,
+                                  valid_depth if use_ds else None, depths[:, 0] if use_ds else None, depths[:, 1] if use_ds else None,
+                                  depth_std if use_ds else None, self.ds_lambda if use_ds else 0.0, self.usealldepth,
+                                  ray_loss=ray_loss, loss_acc=None if det else Fn.state_loss_partials(st), rgb=rgb,
+                                  nonfinite=self._nonfinite if self.sanitize_grads else None, noise=nz2)
+                  if det:
+                      loss = ray_loss.sum()
             B.backward(d_B)
             with torch.no_grad():
                 d_all.copy_(Xl.grad)

@@ -748,12 +748,16 @@ def test_lean_step_with_normal_loss_matches_general_step(with_reg, gsam):
         brdf_nerf_amd.set_deterministic(prev)
 
 
-@pytest.mark.parametrize("name,gsam,cosi", [("rpv111_nlr", False, True), ("hapke_bct", False, False), ("microfacet", True, True),
-                                            ("rpv111_nan", True, False)])
-def test_lean_step_multibrdf_matches_general_step(name, gsam, cosi):
+@pytest.mark.parametrize("name,gsam,cosi,with_reg", [("rpv111_nlr", False, True, False), ("hapke_bct", False, False, False),
+                                                     ("microfacet", True, True, False), ("rpv111_nan", True, False, False),
+                                                     ("rpv111_nlr", False, True, True), ("microfacet", False, False, True),
+                                                     ("hapke_bct", True, True, True)])
+def test_lean_step_multibrdf_matches_general_step(name, gsam, cosi, with_reg):
     """--MultiBRDF (one BRDF per sample, models/spsbrdfnerf.py:289-307,350-352) on the launch-lean step: the BRDF evaluated on the
     stored rows, its padded value as the colour channels of a 4-channel copy that the Lambertian tail kernel composites, autograd
-    through the BRDF kernels back to the field outputs - against the general step on the same draws; eager, then replayed."""
+    through the BRDF kernels back to the field outputs - against the general step on the same draws; eager, then replayed.
+    with_reg (round 5): together with the hard-surface and normal regularisers - the lean step then composites a FULL-width copy of
+    the rows (colour channels = the padded BRDF value) through the generic compositing / ray-loss kernels, which carry them."""
     import brdf_nerf_amd
     from test_gpu_parity import build_model, make_args, Replay, diag
     from brdf_nerf_amd import functions as Fn
@@ -772,8 +776,9 @@ def test_lean_step_multibrdf_matches_general_step(name, gsam, cosi):
     try:
         torch.manual_seed(23)
         ma, mb = build_model(cfg, 37, "fp32"), build_model(cfg, 37, "fp32")
-        ta = FusedTrainer(ma, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
-        tb = FusedTrainer(mb, args, lr=5e-4, ds_lambda=10.0, strict_rng=False)
+        lam = dict(hs_lambda=0.1, nr_reg_an_lambda=0.2, nr_reg_lr_lambda=0.1) if with_reg else {}
+        ta = FusedTrainer(ma, args, lr=5e-4, ds_lambda=10.0, strict_rng=False, **lam)
+        tb = FusedTrainer(mb, args, lr=5e-4, ds_lambda=10.0, strict_rng=False, **lam)
         ta.lean = False
         tb.graph_after = 1
         tb.keep_grads = True
@@ -799,7 +804,7 @@ def test_lean_step_multibrdf_matches_general_step(name, gsam, cosi):
             assert e <= 5e-4, (name, step, e)
         assert len(tb._graphs) >= 1, "the lean step was not captured into a HIP graph"
         assert tb._row_ray, "the step did not take the per-sample BRDF branch of the lean path"
-        diag(f"lean step with MultiBRDF {name} gsam_only={gsam}: worst flat-gradient difference over 4 steps {worst:.2e} of the largest entry")
+        diag(f"lean step with MultiBRDF {name} gsam_only={gsam} regularisers={with_reg}: worst flat-gradient difference over 4 steps {worst:.2e} of the largest entry")
     finally:
         brdf_nerf_amd.set_deterministic(prev)
 
