@@ -6,7 +6,7 @@ One "step" = one full training step on a batch of R rays per GPU:
   + SNerfLoss + DepthLoss (ds_lambda=10, README stage 1) + backward + [RCCL grad all-reduce] + Adam.
 Workload at N=1: BASELINE config 2 - Lambertian pretrain, 4096 rays x 64 samples (+64 guided), F=512, 8 Siren layers,
 PE(10), bf16 MFMA, synthetic satellite-shaped rays, random-init weights (seed 0).
-The step is FusedTrainer's launch-lean one (own in-kernel draws, as brdf_nerf_amd.train.TrainLoop runs it): 12 kernel launches,
+The step is FusedTrainer's launch-lean one (own in-kernel draws, as brdf_nerf_amd.train.TrainLoop runs it): 14 library launches + a fixed-order loss sum,
 no host synchronisation, replayed from a captured HIP graph at N = 1 once its inputs have kept their addresses for 3 steps.
 N>1: one process per GPU, gradients all-reduced over RCCL in two buckets overlapped with the rest of the backward; `value` is the
 weak-scaling rate (`--scaling weak`, default: 4096 rays per GPU) and the line carries a `strong` sub-record - ONE 4096-ray batch
