@@ -41,6 +41,11 @@ def main():
         tr.use_graph = False              # the per-kernel events live in the library's launch sites: eager steps
         for kv in filter(None, attrs.split(",")):
             k, v = kv.split("=")
+            if k == "zero_stash":      # timing probes whose forward does not write its stash: the backward must not read NaN bit patterns
+                spec0 = model.spec(*[bool(x) for x in (bench.CONFIG_FLAGS[config][1]["apply_brdf"], bench.CONFIG_FLAGS[config][1]["apply_theta"])],
+                                   tr.nr_lr, tr.nr_an, beta=False)
+                tr._buf("stash_all", (Fn.field_stash_bytes(spec0, n_rays * 128),), torch.uint8).zero_()
+                continue
             setattr(tr, k, {"True": True, "False": False}.get(v, int(v) if v.lstrip("-").isdigit() else v))
         variants[tag] = (h, args, model, tr)
     b = bench.synthetic_batch(n_rays, 1, dev)
