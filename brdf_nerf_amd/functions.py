@@ -676,6 +676,26 @@ def ray_shade_loss(desc, acc, wsum, depth, var, rays_d, sun_d, rgbs, bufs=None, 
     return o
 
 
+def sample_brdf(desc, X, rays, n1, S1, S2, out, backward_of=None, sun_col=8):
+    """Per-sample BRDF of --MultiBRDF on stored field-output rows (bn_sample_brdf_forward / _backward).  X (N, C) rows of which the
+    first n1 are S1 per ray and the rest S2 per ray; rays (R, >= 6) fp32 rows (sun at sun_col, < 0: ones).  Forward: `out` (N, 4) or
+    (N, C) receives [bp, sigma(, the channels behind)].  backward_of = dB (N, 4 | C): `out` (N, C) receives d loss / d X."""
+    N, Cc = X.shape
+    assert X.is_cuda and X.dtype == torch.float32 and X.is_contiguous() and rays.dtype == torch.float32 and rays.stride(1) == 1
+    assert out.is_contiguous() and out.dtype == torch.float32 and out.shape[0] == N
+    R = rays.shape[0]
+    assert n1 == R * S1 and (n1 == N or N - n1 == R * S2), (N, n1, R, S1, S2)
+    if backward_of is None:
+        L.check(L.lib().bn_sample_brdf_forward(C.byref(desc), _p(X), _p(rays), rays.stride(0), sun_col, N, n1, S1, S2, _p(out),
+                                               out.shape[1], _stream()), "bn_sample_brdf_forward")
+    else:
+        dB = backward_of
+        assert dB.is_contiguous() and dB.dtype == torch.float32 and dB.shape[0] == N and out.shape[1] == Cc
+        L.check(L.lib().bn_sample_brdf_backward(C.byref(desc), _p(X), _p(rays), rays.stride(0), sun_col, N, n1, S1, S2, _p(dB),
+                                                dB.shape[1], _p(out), _stream()), "bn_sample_brdf_backward")
+    return out
+
+
 def lambert_tail(z_all, idx, out1, out2, rgbs, rgb_padding, lambda_rgb, d_out1, d_out2, valid_depth=None, target_depth=None,
                  target_weight=None, target_std=None, lambda_ds=0.0, usealldepth=False, ray_loss=None, loss_acc=None, rgb=None,
                  weights=None, depth=None, nonfinite=None, noise=None):

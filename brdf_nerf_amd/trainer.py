@@ -52,7 +52,6 @@ class FusedTrainer:
         self.lean = True
         self.merge_passes = True        # one output array / stash / backward for both passes (False: two backward launch sets)
         self.overlap_allreduce = True   # world > 1: all-reduce the trunk's gradient while the rest of the backward still runs
-        self._row_ray = {}              # MultiBRDF lean step: ray index of every stored sample row
         self._kind_cache = {}
         self.ray_offset = 0             # index of this rank's first ray in the global batch: in-kernel draws are taken per GLOBAL ray
         self.keep_grads = False         # True: the optimiser launch leaves the step's gradient in flat_grad (tests, diagnostics)
@@ -170,18 +169,14 @@ class FusedTrainer:
         dev = rays.device
         spec = model.spec(apply_brdf, apply_theta, self.nr_lr, self.nr_an, beta=False)   # (field.py spec(): the loss never reads beta)
         reg0 = self.reg if regularisers else {}
-        # --MultiBRDF (one BRDF per sample, spsbrdfnerf.py:289-307,350-352) is a lean step unless the sun pass is on (its irradiance is
-        # per sample there) - see _lean_body; the regularisers ride in the compositing kernels as they do for one BRDF per ray
-        multi = bool(model.MultiBRDF) and apply_brdf
-        kind = self._shade_kind(spec, apply_brdf, cos_irra_on)
-        # (round 5: with a regulariser too - _lean_body composites a full-width copy through the generic kernels then)
-        per_sample0 = multi and (getattr(model, "sun_v", "none") == "analystic" or kind == L.BN_SHADE_LAMBERT)
-        # the sun-visibility pass (rendering.py:244-259) is a lean step where the reference runs it (gsam_only) and a BRDF shades the
-        # ray (its rgb then reads the sun pass through ONE per-ray factor, spsbrdfnerf.py:354); per-sample irradiance of a
-        # Lambertian rgb, and the sun pass's own noise draws, keep the general path
+        # --MultiBRDF (one BRDF per sample, spsbrdfnerf.py:289-307,350-352) is a lean step (_lean_body: one per-sample shading launch
+        # each way, csrc/sample_brdf.hip); the regularisers ride in the compositing kernels as they do for one BRDF per ray.
+        # The sun-visibility pass (rendering.py:244-259) is a lean step where the reference runs it (gsam_only): a per-ray BRDF reads
+        # it through ONE per-ray factor (spsbrdfnerf.py:354), a per-sample BRDF or a Lambertian rgb through a per-sample one
+        # (:265-273) that the same launch applies; the sun pass's own noise draws keep the general path
         sun_on = getattr(model, "sun_v", "none") == "analystic" and apply_brdf
-        sun_lean = (sun_on and gsam_only and args.noise_std == 0 and args.data == "sat" and kind != L.BN_SHADE_LAMBERT)
-        if (self.lean and not self.strict_rng and self.reuse_coarse and not per_sample0
+        sun_lean = sun_on and gsam_only and args.noise_std == 0 and args.data == "sat"
+        if (self.lean and not self.strict_rng and self.reuse_coarse
                 and (not sun_on or sun_lean)
                 and rays.dtype == torch.float32 and rays.is_contiguous() and rays.shape[1] >= 8 and S + G <= 512):
             return self._step_lean(spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, apply_theta, cos_irra_on,
@@ -342,16 +337,13 @@ class FusedTrainer:
         return loss.detach(), res["rgb"].detach()
 
     # ------------------------------------------------------------------ launch-lean step
-    def _row_ray_for(self, R, S, G, dev):
-        """MultiBRDF lean step: ray index of every stored sample row ([R S] pass-1 rows, then [R G] guided rows).  Always made
-        OUTSIDE a graph capture (a tensor first allocated inside one would live in that graph's private pool)."""
-        key = (R, S, G)
-        t = self._row_ray.get(key)
-        if t is None:
-            ar = torch.arange(R, device=dev)
-            t = ar.repeat_interleave(S) if G == 0 else torch.cat([ar.repeat_interleave(S), ar.repeat_interleave(G)])
-            self._row_ray[key] = t
-        return t
+    def _sample_desc(self, spec, apply_brdf, cos_irra_on):
+        """bn_shade_desc of the per-sample BRDF launches of a MultiBRDF lean step (cached: its fields are launch arguments)."""
+        key = ("sample", spec.key(), bool(apply_brdf), bool(cos_irra_on))
+        d = self._kind_cache.get(key)
+        if d is None:
+            d = self._kind_cache[key] = shade_desc(self.model, self.args, spec, apply_brdf, cos_irra_on)
+        return d
 
     def _shade_kind(self, spec, apply_brdf, cos_irra_on):
         """BN_SHADE_* kind of the ray-level shading for this head set (cached: step() asks on every call)."""
@@ -421,9 +413,6 @@ class FusedTrainer:
         active = [on[g] for g, _, _ in self.groups]
         self._sync_state(on)
         slot = self._rng_step % 64
-        if bool(model.MultiBRDF) and apply_brdf and not lambertian:
-            S_, G_ = args.n_samples, args.guided_samples
-            self._row_ray_for(rays.shape[0], G_ if gsam_only else S_, 0 if gsam_only else G_, rays.device)
         body = lambda: self._lean_body(spec, rays, rgbs, valid_depth, depths, depth_std, apply_brdf, cos_irra_on, use_ds, nf, reg,
                                        lambertian, active, gsam_only)
         res = None
@@ -535,7 +524,8 @@ class FusedTrainer:
                                                 near_far=torch.cat([far_sun * 0.01, far_sun], -1).contiguous(), stream_id=L.BN_RNG_SUN)
                     sun_rays = torch.cat([rays[:, 0:3] + rays_d * d1.unsqueeze(-1), sun_d], -1).contiguous()
                     sig_sun = Fn.field_sigma(spec, named, packed, rays=sun_rays, z=z_sun)
-                    sun_irr = Fn.composite(z_sun, sig_sun.view(R, G), None, 0.0)[1][:, -1]
+                    sun_T = Fn.composite(z_sun, sig_sun.view(R, G), None, 0.0)[1]       # transparency in front of each sample
+                    sun_irr = sun_T[:, -1]
                 if self.seed_hook is not None:
                     self.seed_hook("z2", z2)
                 out2 = self._buf("out2", (R * G, C))
@@ -573,46 +563,50 @@ class FusedTrainer:
                 d_all = self._buf("d_all", (n_all, C))
                 d1o, d2o = d_all[:R * S].view(R, S, C), d_all[R * S:].view(R, G, C)
         loss = None
-        if bool(model.MultiBRDF) and apply_brdf and not lambertian:
-            # One BRDF per sample: the BRDF is a pointwise function of a sample's field outputs, so it is evaluated on the rows as
-            # they are STORED (pass-1 block, guided block: the merged set is never materialised) and its padded value takes the
-            # place of the albedo in a 4-channel copy [bp_r, bp_g, bp_b, sigma]; the Lambertian tail kernel (compositing through the
-            # sort index + SNerfLoss + DepthLoss + composite backward, padding 0) runs on that copy, and autograd through the BRDF
-            # kernels turns its gradient rows into those of the field outputs.  ~20 small launches, all inside the captured graph.
-            from .rendering import _per_ray_brdf
+        kind_id = self._shade_kind(spec, apply_brdf, cos_irra_on)
+        multi = bool(model.MultiBRDF) and apply_brdf
+        sun_rows = gsam_only and getattr(model, "sun_v", "none") == "analystic" and apply_brdf and (multi or kind_id == L.BN_SHADE_LAMBERT)
+        if (multi and kind_id != L.BN_SHADE_LAMBERT) or sun_rows:
+            # One BRDF per sample (or a per-sample irradiance): the BRDF is a pointwise function of a sample's field outputs, so it is evaluated on the rows as
+            # they are STORED (pass-1 block, guided block: the merged set is never materialised) by ONE launch
+            # (csrc/sample_brdf.hip) that writes a copy of the rows with the padded, irradiance-weighted BRDF value in the place of
+            # the albedo; the compositing + loss + composite-backward kernels run on that copy (padding 0: it is inside bp), and ONE
+            # launch turns the copy's gradient rows into those of the field outputs (J^T in forward-mode duals, like ray_tail.hip).
+            # Rounds 3-4 went through autograd over the per-point BRDF kernels: ~20 glue launches.
             rgb = self._buf("rgb", (R, 3))
             det = self.repeatable_loss
             ray_loss = self._buf("ray_loss", (R,)) if det else None
-            X = out2 if gsam_only else (out_all if merged else torch.cat([out1, out2], 0))
             n1 = R * S                                   # rows of the first block (gsam_only: all of them, S = G here)
-            row_ray = self._row_ray_for(R, S, 0 if gsam_only else G, rays.device)     # (made before the capture decision, _step_lean)
-            kind = {L.BN_SHADE_RPV: "RPV", L.BN_SHADE_HAPKE: "Hapke", L.BN_SHADE_MICROFACET: "Microfacet"}[
-                self._shade_kind(spec, apply_brdf, cos_irra_on)]
-            c0 = spec.ch_normal_lr if spec.normal_lr else spec.ch_normal_an          # learned wins when both are present
-            pad = model.rgb_padding
-            sun_d = rays[:, 8:11] if args.data == "sat" else torch.ones_like(rays[:, 0:3])
+            n_rows = n1 if gsam_only else n_all
+            # (with the sun pass: each row's irradiance is the sun ray's transparency at the row's position in its ray, :265-273 -
+            # a constant of the step; the descriptor then carries this step's array)
+            bdesc = (shade_desc(model, args, spec, apply_brdf, cos_irra_on, irr=sun_T.reshape(-1)) if sun_rows
+                     else self._sample_desc(spec, apply_brdf, cos_irra_on))
+            sun_col = 8 if args.data == "sat" else -1
             hs = float(reg.get("hs", 0))
             spv = float(reg.get("nr_spv", 0)) if (spec.normal_an and spec.normal_lr and abs(reg.get("nr_spv", 0)) > 1e-5) else 0.0
             with_reg = hs > 0 or spv != 0.0 or float(reg.get("nr_an", 0)) > 0 or float(reg.get("nr_lr", 0)) > 0
-            with torch.enable_grad():
-                Xl = X.detach().requires_grad_(True)
-                heads = {name: Xl[:, h0:h0 + wdt] for (name, _, _), (h0, wdt) in zip(spec.heads[1:], spec.head_cols[1:])}
-                brdf, _ = _per_ray_brdf(model, args, kind, sun_d[row_ray], (-rays[:, 3:6])[row_ray], Xl[:, c0:c0 + 3], Xl[:, :3], heads)
-                bp = brdf * (1 + 2 * pad) - pad
-                if cos_irra_on:
-                    bp = bp * sun_d[:, 2:3].abs()[row_ray]              # upward normal: irradiance = |sun_z| (:260-264)
-                # no regulariser: a 4-channel copy [bp, sigma] for the one-launch Lambertian tail; with one (round 5): a FULL-width
-                # copy - the rows as they are stored, their colour channels replaced by bp - for the generic compositing kernels,
-                # which carry NormalRegLoss / NormalLoss / HardSurfaceLoss on the per-sample normals and weights
-                B = torch.cat([bp, Xl[:, 3:]] if with_reg else [bp, Xl[:, 3:4]], 1)
-            if with_reg:
-                with torch.no_grad():
-                    Bd = B.detach()
-                    d_B = self._buf("d_Bfull", (X.shape[0], C))
-                    B1 = Bd[:n1].view(R, S, C)
-                    B2 = None if gsam_only else Bd[n1:].view(R, G, C)
-                    dB1 = d_B[:n1].view(R, S, C)
-                    dB2 = None if gsam_only else d_B[n1:].view(R, G, C)
+            # no regulariser: a 4-channel copy [bp, sigma] for the one-launch Lambertian tail; with one: a FULL-width copy for the
+            # generic compositing kernels, which carry NormalRegLoss / NormalLoss / HardSurfaceLoss on the per-sample normals and weights
+            Cb = C if with_reg else 4
+            # the row blocks as (rows, samples per ray of the first / second part, first row): one launch over [pass 1 | guided]
+            # when they share an array, one per pass otherwise
+            if gsam_only:
+                blocks = [(out2, n1, S, 0, 0)]
+            elif merged:
+                blocks = [(out_all, n1, S, G, 0)]
+            else:
+                blocks = [(out1, n1, S, 0, 0), (out2, R * G, G, 0, n1)]
+            with torch.no_grad():
+                Bd = self._buf("B_full" if with_reg else "B_4", (n_rows, Cb))
+                d_B = self._buf("d_Bfull" if with_reg else "d_B", (n_rows, Cb))
+                for Xb, nb1, s1, s2, r0 in blocks:
+                    Fn.sample_brdf(bdesc, Xb, rays, nb1, s1, s2, Bd[r0:r0 + Xb.shape[0]], sun_col=sun_col)
+                B1 = Bd[:n1].view(R, S, Cb)
+                B2 = None if gsam_only else Bd[n1:].view(R, G, Cb)
+                dB1 = d_B[:n1].view(R, S, Cb)
+                dB2 = None if gsam_only else d_B[n1:].view(R, G, Cb)
+                if with_reg:
                     # identity shading of the composited colour: a Lambertian descriptor with no padding and no irradiance (both
                     # are inside bp already), the losses and regularisers as for one BRDF per ray
                     from . import _lib as L_
@@ -642,26 +636,16 @@ class FusedTrainer:
                     Fn.merged_composite_backward(z_all, idx, B1, B2, None, gq["d_depth"], gq["d_acc"], dB1, dB2, d_wsum=gq["d_wsum"],
                                                  nonfinite=self._nonfinite if self.sanitize_grads else None,
                                                  hs_scale=hs / R if hs > 0 else 0.0, depth=o["depth"], nreg=nreg, noise=nz2)
-                    if det:
-                        loss = ray_loss.sum()
-            else:
-              with torch.no_grad():
-                  Bd = B.detach()
-                  d_B = self._buf("d_B", (X.shape[0], 4))
-                  B1 = Bd[:n1].view(R, S, 4)
-                  B2 = None if gsam_only else Bd[n1:].view(R, G, 4)
-                  dB1 = d_B[:n1].view(R, S, 4)
-                  dB2 = None if gsam_only else d_B[n1:].view(R, G, 4)
-                  Fn.lambert_tail(z_all, idx, B1, B2, rgbs, 0.0, self.lambda_rgb, dB1, dB2,
-                                  valid_depth if use_ds else None, depths[:, 0] if use_ds else None, depths[:, 1] if use_ds else None,
-                                  depth_std if use_ds else None, self.ds_lambda if use_ds else 0.0, self.usealldepth,
-                                  ray_loss=ray_loss, loss_acc=None if det else Fn.state_loss_partials(st), rgb=rgb,
-                                  nonfinite=self._nonfinite if self.sanitize_grads else None, noise=nz2)
-                  if det:
-                      loss = ray_loss.sum()
-            B.backward(d_B)
-            with torch.no_grad():
-                d_all.copy_(Xl.grad)
+                else:
+                    Fn.lambert_tail(z_all, idx, B1, B2, rgbs, 0.0, self.lambda_rgb, dB1, dB2,
+                                    valid_depth if use_ds else None, depths[:, 0] if use_ds else None, depths[:, 1] if use_ds else None,
+                                    depth_std if use_ds else None, self.ds_lambda if use_ds else 0.0, self.usealldepth,
+                                    ray_loss=ray_loss, loss_acc=None if det else Fn.state_loss_partials(st), rgb=rgb,
+                                    nonfinite=self._nonfinite if self.sanitize_grads else None, noise=nz2)
+                if det:
+                    loss = ray_loss.sum()
+                for Xb, nb1, s1, s2, r0 in blocks:
+                    Fn.sample_brdf(bdesc, Xb, rays, nb1, s1, s2, d_all[r0:r0 + Xb.shape[0]], backward_of=d_B[r0:r0 + Xb.shape[0]], sun_col=sun_col)
                 if self.sanitize_grads:
                     Fn.count_nonfinite(d_all, self._nonfinite)
                     torch.nan_to_num_(d_all, nan=0.0, posinf=0.0, neginf=0.0)

@@ -747,9 +747,8 @@ def test_random_lean_step_against_general_step(seed):
     if cfg.normal == "analystic_learned" and rng4.random() < 0.6:      # NormalLoss between the two normal fields (nr_spv_type 1)
         lam["nr_spv_lambda"] = 0.3
     sun_pass = bool(flags.get("gsam_only") and flags["apply_brdf"] and noise_std == 0.0 and rng4.random() < 0.5)
-    # one BRDF per sample: a lean step when no regulariser / sun pass is on (else both sides would take the general step, each with
-    # its own draws: nothing to compare)
-    multi = bool(flags["apply_brdf"] and not sun_pass and not any(lam.values()) and rng4.random() < 0.6)
+    # one BRDF per sample: a lean step too - with the regularisers and with the sun pass's per-sample irradiance since round 5
+    multi = bool(flags["apply_brdf"] and rng4.random() < 0.6)
     if sun_pass or multi:                                               # the sun-visibility pass of the gsam_only stage
         cfg = FieldConfig(**dict(vars(cfg), sun_v="analystic" if sun_pass else cfg.sun_v, MultiBRDF=multi))
         args = make_args(cfg)

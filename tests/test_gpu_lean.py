@@ -754,8 +754,9 @@ def test_lean_step_with_normal_loss_matches_general_step(with_reg, gsam):
                                                      ("hapke_bct", True, True, True)])
 def test_lean_step_multibrdf_matches_general_step(name, gsam, cosi, with_reg):
     """--MultiBRDF (one BRDF per sample, models/spsbrdfnerf.py:289-307,350-352) on the launch-lean step: the BRDF evaluated on the
-    stored rows, its padded value as the colour channels of a 4-channel copy that the Lambertian tail kernel composites, autograd
-    through the BRDF kernels back to the field outputs - against the general step on the same draws; eager, then replayed.
+    stored rows by one launch (csrc/sample_brdf.hip), its padded value as the colour channels of a 4-channel copy that the
+    Lambertian tail kernel composites, one launch for the chain rule back to the field outputs - against the general step (autograd
+    through the per-point BRDF functions) on the same draws; eager, then replayed.
     with_reg (round 5): together with the hard-surface and normal regularisers - the lean step then composites a FULL-width copy of
     the rows (colour channels = the padded BRDF value) through the generic compositing / ray-loss kernels, which carry them."""
     import brdf_nerf_amd
@@ -803,22 +804,110 @@ def test_lean_step_multibrdf_matches_general_step(name, gsam, cosi, with_reg):
             worst = max(worst, e)
             assert e <= 5e-4, (name, step, e)
         assert len(tb._graphs) >= 1, "the lean step was not captured into a HIP graph"
-        assert tb._row_ray, "the step did not take the per-sample BRDF branch of the lean path"
+        assert any(k[0] == "sample" for k in tb._kind_cache), "the step did not take the per-sample BRDF branch of the lean path"
         diag(f"lean step with MultiBRDF {name} gsam_only={gsam} regularisers={with_reg}: worst flat-gradient difference over 4 steps {worst:.2e} of the largest entry")
     finally:
         brdf_nerf_amd.set_deterministic(prev)
 
 
-@pytest.mark.parametrize("name", ["rpv111_nan", "hapke_bct"])
-def test_lean_step_sun_visibility_pass_matches_general_step(name):
+@pytest.mark.parametrize("kind,heads,rhoc_is_albedo,shell", [("RPV", "k t r", False, 0), ("RPV", "k", False, 0), ("RPV", "k t", True, 0),
+                                                             ("Hapke", "b c t", False, 0), ("Hapke", "c", False, 2), ("Hapke", "b t", False, 0),
+                                                             ("Microfacet", "r", False, 0)])
+@pytest.mark.parametrize("full,cosi", [(False, True), (True, False)])
+def test_sample_brdf_kernel_matches_per_point_functions(kind, heads, rhoc_is_albedo, shell, full, cosi):
+    """bn_sample_brdf_forward / _backward (the per-sample BRDF of --MultiBRDF on stored rows, one launch each way) against the
+    per-point BRDF functions under torch autograd (the per-point entry points, themselves pinned by the oracle and the
+    golden vectors) with the gathers, the padding and the irradiance as torch ops: every combination of present heads the model
+    builder allows, a two-block row set with different samples per ray, rows with degenerate geometry (view == normal, sun below
+    the horizon: the NaN-replacement branches) - values and gradients to the last bits, the pass-through channels exactly."""
+    from types import SimpleNamespace
+    from brdf_nerf_amd import _lib as L, functions as Fn
+    from brdf_nerf_amd.rendering import _per_ray_brdf
+    g = torch.Generator().manual_seed(5)
+    R, S1, S2, pad = 37, 5, 3, 0.001
+    names = heads.split()
+    C, cols = 4 + 3 + 2, {}                       # [albedo 3, sigma, 2 spare channels, normal 3, heads ...]: the normal at 6
+    ch_n = 6
+    for nm in names:
+        w = 1 if (kind == "Microfacet" or (kind == "Hapke" and nm == "t")) else 3
+        cols[nm] = (C, w)
+        C += w
+    N, n1 = R * (S1 + S2), R * S1
+    X = torch.rand(N, C, generator=g)
+    nrm = torch.nn.functional.normalize(torch.randn(N, 3, generator=g) + torch.tensor([0.0, 0.0, 1.5]), dim=-1)
+    X[:, ch_n:ch_n + 3] = nrm
+    rays = torch.zeros(R, 11)
+    rays[:, :3] = torch.randn(R, 3, generator=g)
+    rays[:, 3:6] = torch.nn.functional.normalize(torch.randn(R, 3, generator=g) - torch.tensor([0.0, 0.0, 2.0]), dim=-1)
+    rays[:, 8:11] = torch.nn.functional.normalize(torch.randn(R, 3, generator=g) + torch.tensor([0.0, 0.0, 1.0]), dim=-1)
+    rays[3, 8:11] = torch.tensor([0.6, 0.0, -0.8])           # a sun below the horizon
+    X[7 * S1, ch_n:ch_n + 3] = -rays[7, 3:6]                  # view == normal
+    X[n1 + 2 * S2 + 1, ch_n:ch_n + 3] = rays[2, 8:11]         # sun == normal
+    if kind == "RPV" and "k" in cols:
+        X[:, cols["k"][0]:cols["k"][0] + 3] += 0.3
+    X, rays = X.to(DEV), rays.to(DEV)
+    d = L.ShadeDesc()
+    d.kind = {"RPV": L.BN_SHADE_RPV, "Hapke": L.BN_SHADE_HAPKE, "Microfacet": L.BN_SHADE_MICROFACET}[kind]
+    d.C, d.ch_normal = C, ch_n
+    order = {"RPV": ("k", "t", "r"), "Hapke": ("b", "c", "t"), "Microfacet": ("r",)}[kind]
+    p = [cols[nm][0] if nm in cols else -1 for nm in order] + [-1, -1]
+    d.ch_p0, d.ch_p1, d.ch_p2 = p[0], p[1], p[2]
+    d.rhoc_is_albedo, d.shell, d.cos_irradiance, d.usealldepth = int(rhoc_is_albedo), shell, int(cosi), 0
+    d.hpk_scl, d.f0, d.rgb_padding = 1.3, 0.04, pad
+    d.lambda_rgb = d.lambda_ds = d.lambda_hs = 0.0
+    Cb = C if full else 4
+    B = torch.full((N, Cb), float("nan"), device=DEV)
+    Fn.sample_brdf(d, X, rays, n1, S1, S2, B)
+    dB = torch.randn(N, Cb, generator=g).to(DEV)
+    dX = torch.full((N, C), float("nan"), device=DEV)
+    Fn.sample_brdf(d, X, rays, n1, S1, S2, dX, backward_of=dB)
+    # the same through autograd over the per-point functions
+    ar = torch.arange(R, device=DEV)
+    row_ray = torch.cat([ar.repeat_interleave(S1), ar.repeat_interleave(S2)])
+    Xl = X.clone().requires_grad_(True)
+    hn = {"RPV": dict(k="k_from_xyz", t="theta_rpv_from_xyz", r="rhoc_from_xyz"), "Hapke": dict(b="b_from_xyz", c="c_from_xyz", t="theta_from_xyz"),
+          "Microfacet": dict(r="roughness_from_xyz")}[kind]
+    hd = {hn[nm]: Xl[:, c0:c0 + w] for nm, (c0, w) in cols.items()}
+    args = SimpleNamespace(funcH=2 if rhoc_is_albedo else 1, fresnel_f0=0.04, hpk_scl=1.3, shell_hapke=shell)
+    brdf, _ = _per_ray_brdf(None, args, kind, rays[:, 8:11][row_ray], (-rays[:, 3:6])[row_ray], Xl[:, ch_n:ch_n + 3], Xl[:, :3], hd)
+    bp = brdf * (1 + 2 * pad) - pad
+    if cosi:
+        bp = bp * rays[:, 10:11].abs()[row_ray]
+    Bref = torch.cat([bp, Xl[:, 3:]] if full else [bp, Xl[:, 3:4]], 1)
+    Bref.backward(dB)
+    assert torch.equal(torch.isnan(B), torch.isnan(Bref))
+    tol = lambda ref: 2e-6 * float(ref.detach().abs().nan_to_num(0.0).max()) + 1e-9
+    assert float((B - Bref.detach()).abs().nan_to_num(0.0).max()) <= tol(Bref)
+    assert torch.equal(B[:, 3:], Bref.detach()[:, 3:])
+    gref = Xl.grad
+    assert torch.equal(torch.isnan(dX), torch.isnan(gref))
+    err = float((dX - gref).abs().nan_to_num(0.0).max())
+    assert err <= 5e-6 * float(gref.abs().nan_to_num(0.0).max()) + 1e-9, err
+    if full:
+        spare = [4, 5]
+        assert torch.equal(dX[:, spare], dB[:, spare]) and torch.equal(dX[:, 3], dB[:, 3])
+    else:
+        assert float(dX[:, [4, 5]].abs().max()) == 0.0 and torch.equal(dX[:, 3], dB[:, 3])
+    # ragged arguments are refused, not launched
+    with pytest.raises(AssertionError):
+        Fn.sample_brdf(d, X, rays, n1 + 1, S1, S2, B)
+
+
+@pytest.mark.parametrize("name,multi", [("rpv111_nan", False), ("hapke_bct", False), ("rpv111_nan", True), ("microfacet", True),
+                                        ("lambert", False), ("normal_only", False), ("normal_only", True)])
+def test_lean_step_sun_visibility_pass_matches_general_step(name, multi):
     """--sun_v analystic (rendering.py:244-259; the reference runs it in the gsam_only stage) on the launch-lean step: the
     sigma-only pass along the sun direction with in-kernel draws (stream BN_RNG_SUN), its transparency in front of the last sample as
-    the ray's irradiance in bn_ray_shade_loss (spsbrdfnerf.py:354) - against the general step fed with the streams' draws."""
+    the ray's irradiance in bn_ray_shade_loss (spsbrdfnerf.py:354) - against the general step fed with the streams' draws.
+    multi / lambert / normal_only (round 5): the PER-SAMPLE irradiance - with --MultiBRDF each sample's BRDF value, without a BRDF
+    each sample's padded albedo, is weighted by the sun ray's transparency at the sample's position (:265-273) - applied by the
+    per-sample shading launch (csrc/sample_brdf.hip) ahead of the compositing."""
     import brdf_nerf_amd
     from test_gpu_parity import build_model, make_args, Replay, diag
     from brdf_nerf_amd import functions as Fn
     from brdf_nerf_amd.trainer import FusedTrainer
-    cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16, sun_v="analystic", **_lean_cfgs()[name])
+    cfg = FieldConfig(feat=64, n_samples=16, guided_samples=16, sun_v="analystic", MultiBRDF=multi,
+                      **dict(_lean_cfgs(), normal_only=dict(normal="learned"))[name])
     args = make_args(cfg, "fp32")
     R, S, G = 96, 16, 16
     g = torch.Generator().manual_seed(9)
@@ -865,7 +954,7 @@ def test_lean_step_sun_visibility_pass_matches_general_step(name):
         assert float((rgb0 - rgb_sun).abs().max()) > 1e-3
         with pytest.raises(NotImplementedError):
             tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **dict(flags, gsam_only=False))
-        diag(f"lean step with the sun pass {name}: worst flat-gradient difference over 4 steps {worst:.2e} of the largest entry")
+        diag(f"lean step with the sun pass {name} MultiBRDF={int(multi)}: worst flat-gradient difference over 4 steps {worst:.2e} of the largest entry")
     finally:
         brdf_nerf_amd.set_deterministic(prev)
 
