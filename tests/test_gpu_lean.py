@@ -810,6 +810,44 @@ def test_lean_step_multibrdf_matches_general_step(name, gsam, cosi, with_reg):
         brdf_nerf_amd.set_deterministic(prev)
 
 
+def test_sample_brdf_kernel_lambert_kind_and_row_irradiance():
+    """kind LAMBERT of the per-sample shading launch (the padded albedo under a per-ROW irradiance: the sun pass over a Lambertian
+    rgb, models/spsbrdfnerf.py:265-273) and the per-row irradiance on a BRDF kind, against the same arithmetic in torch; the cosine
+    term wins over the rows' irradiance exactly when the model has a normal channel (:260-266)."""
+    from brdf_nerf_amd import _lib as L, functions as Fn
+    g = torch.Generator().manual_seed(8)
+    R, S1, pad = 29, 6, 0.001
+    N = R * S1
+    rays = torch.zeros(R, 11)
+    rays[:, 3:6] = torch.nn.functional.normalize(torch.randn(R, 3, generator=g) - torch.tensor([0.0, 0.0, 2.0]), dim=-1)
+    rays[:, 8:11] = torch.nn.functional.normalize(torch.randn(R, 3, generator=g) + torch.tensor([0.0, 0.0, 1.0]), dim=-1)
+    rays = rays.to(DEV)
+    irr = torch.rand(N, generator=g).to(DEV)
+    for C, ch_n, cosi in ((4, -1, False), (4, -1, True), (7, 4, False), (7, 4, True)):
+        X = torch.rand(N, C, generator=g).to(DEV)
+        d = L.ShadeDesc()
+        d.kind, d.C, d.ch_normal = L.BN_SHADE_LAMBERT, C, ch_n
+        d.ch_p0 = d.ch_p1 = d.ch_p2 = -1
+        d.rhoc_is_albedo = d.shell = d.usealldepth = 0
+        d.cos_irradiance = int(cosi)
+        d.hpk_scl, d.f0, d.rgb_padding = 1.0, 0.04, pad
+        d.lambda_rgb = d.lambda_ds = d.lambda_hs = 0.0
+        d.irr, d.irr_stride = irr.data_ptr(), 1
+        for Cb in sorted({4, C}):
+            B = torch.full((N, Cb), float("nan"), device=DEV)
+            Fn.sample_brdf(d, X, rays, N, S1, 0, B)
+            w = rays[:, 10].abs().repeat_interleave(S1) if (cosi and ch_n >= 0) else irr
+            ref = torch.cat([(X[:, :3] * (1 + 2 * pad) - pad) * w[:, None], X[:, 3:Cb]], 1)
+            assert torch.equal(B, ref), (C, cosi, Cb)
+            dB = torch.randn(N, Cb, generator=g).to(DEV)
+            dX = torch.full((N, C), float("nan"), device=DEV)
+            Fn.sample_brdf(d, X, rays, N, S1, 0, dX, backward_of=dB)
+            dref = torch.zeros(N, C, device=DEV)
+            dref[:, :3] = dB[:, :3] * (1 + 2 * pad) * w[:, None]
+            dref[:, 3:Cb] = dB[:, 3:]
+            assert torch.equal(dX, dref), (C, cosi, Cb)
+
+
 @pytest.mark.parametrize("kind,heads,rhoc_is_albedo,shell", [("RPV", "k t r", False, 0), ("RPV", "k", False, 0), ("RPV", "k t", True, 0),
                                                              ("Hapke", "b c t", False, 0), ("Hapke", "c", False, 2), ("Hapke", "b t", False, 0),
                                                              ("Microfacet", "r", False, 0)])
@@ -888,9 +926,21 @@ def test_sample_brdf_kernel_matches_per_point_functions(kind, heads, rhoc_is_alb
         assert torch.equal(dX[:, spare], dB[:, spare]) and torch.equal(dX[:, 3], dB[:, 3])
     else:
         assert float(dX[:, [4, 5]].abs().max()) == 0.0 and torch.equal(dX[:, 3], dB[:, 3])
-    # ragged arguments are refused, not launched
+    # ragged arguments are refused, not launched: by the wrapper, and by the C entry point itself (error text names the argument)
     with pytest.raises(AssertionError):
         Fn.sample_brdf(d, X, rays, n1 + 1, S1, S2, B)
+    import ctypes as C_
+    lib, vp = L.lib(), lambda t: C_.c_void_p(t.data_ptr())
+    call = lambda dd, n1_, s1_, stride: lib.bn_sample_brdf_forward(C_.byref(dd), vp(X), vp(rays), rays.stride(0), 8, N, n1_, s1_, S2, vp(B), stride, None)
+    assert call(d, n1 + 1, S1, Cb) != 0 and b"do not split" in lib.bn_last_error()
+    assert call(d, n1, S1, 5) != 0 and b"row stride" in lib.bn_last_error()
+    bad = L.ShadeDesc.from_buffer_copy(d)
+    bad.ch_normal = C - 1
+    assert call(bad, n1, S1, Cb) != 0 and b"normal channel" in lib.bn_last_error()
+    bad = L.ShadeDesc.from_buffer_copy(d)
+    bad.kind = 9
+    assert call(bad, n1, S1, Cb) != 0 and b"kind" in lib.bn_last_error()
+    assert lib.bn_sample_brdf_backward(C_.byref(d), vp(X), vp(rays), rays.stride(0), 8, N, n1, S1, S2, None, Cb, vp(dX), None) != 0
 
 
 @pytest.mark.parametrize("name,multi", [("rpv111_nan", False), ("hapke_bct", False), ("rpv111_nan", True), ("microfacet", True),
