@@ -53,14 +53,14 @@ def needs_build():
 
 # extra hipcc flags per source file (basename), on top of FLAGS.  The weight-gradient kernels gain from the max-ILP machine
 # scheduler (fp16 256-tile kernel -13 %, skinny kernel -16 % with analytic normals); the chain kernels lose 1-6 % with it
-# (profiles/r02_ablation.txt, session 24) - hence their own translation unit.
+# (profiles/history/r02_ablation.txt, session 24) - hence their own translation unit.
 # The backward chain and the analytic-normal chains gain 1-3 % from the AMDGPU register-pressure trackers in the scheduler (the
 # forward loses 2-7 % with them, the weight-gradient kernels 2-20 %: session 25).
 # (The weight-fragment prefetch depth of the chain GEMM is a template parameter per kernel instantiation: field_kernels.h
 # FwdDepth / BwdDepth.)
 # -fno-slp-vectorize (round 3): hipcc's SLP pass packs the epilogues' independent fp32 adds / multiplies into v_pk_*_f32 with
 # v_mov shuffles around them - more instructions AND more live registers: the fp16 training forward went from 944 to 132
-# bytes of scratch per lane, the inference forward from 700 to 0 (profiles/r03_kernel_resources.txt).
+# bytes of scratch per lane, the inference forward from 700 to 0 (profiles/history/r03_kernel_resources.txt).
 _NOSLP = ("-fno-slp-vectorize",)
 _TRACKERS = ("-mllvm", "-amdgpu-use-amdgpu-trackers=1") + _NOSLP
 FILE_FLAGS = {"field_wgrad.hip": ("-mllvm", "-amdgpu-sched-strategy=max-ilp"),

@@ -4,7 +4,7 @@
 #include "common.h"
 
 #define BN_MAX_PASS 3
-#ifndef BN_DPH                    // (diag.h: an A/B build may pin 12 = the four-head layout of ABI <= 2, profiles/r02_ablation.txt)
+#ifndef BN_DPH                    // (diag.h: an A/B build may pin 12 = the four-head layout of ABI <= 2, profiles/history/r02_ablation.txt)
 #define BN_DPH (3 * BN_MAX_HEADS)   // pre-activation gradients of the heads' (<= 3) outputs kept per point
 #endif
 // 32-column tiles per wave in a single-head pass (N = F/2 columns): NT/2 spreads the pass over all eight waves; NT keeps

@@ -580,7 +580,7 @@ extern "C" int bn_field_backward_parts(const bn_field_desc *desc, const bn_field
   if (f16m) {
     // (a kernel, not hipMemsetAsync: inside a captured HIP graph the memset became a memset NODE, and replays of such graphs
     // were seen to run the atomicMax kernels below against a stale / late-cleared word once in a few hundred steps - fp16 steps
-    // with analytic normals ended with non-finite parameters, profiles/r03_ablation.txt; kernel nodes are ordered like launches)
+    // with analytic normals ended with non-finite parameters, profiles/history/r03_ablation.txt; kernel nodes are ordered like launches)
     clear_words_kernel<<<1, 64, 0, st>>>((unsigned int *)amax, 4);
     BN_LAUNCH_CHECK("clear amax");
     if (a.an) {

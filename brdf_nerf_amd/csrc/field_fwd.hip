@@ -125,7 +125,7 @@ __device__ __forceinline__ void head_pass(const FwdArgs &A, int p, const T *ACT,
   // --input_viewdir: the encoded view direction of every point, an extra K segment of the rgb head's first layer (like the
   // positional-encoding segment of the skip layer).  The tile lives behind the staged parameters in the (free) encoding buffer.
   // DIR (= the model has extra inputs, KD > 0) is a template parameter: compiled into the one kernel, the segment costs the hot
-  // head pass registers (2 - 3 % of the forward with no extra input at all: profiles/r02_ablation.txt)
+  // head pass registers (2 - 3 % of the forward with no extra input at all: profiles/history/r02_ablation.txt)
   const bool dir_on = DIR && p == 0;
   T *DIRT = (T *)((char *)PRM + 8192);
   const int LDD = g.KD + Elem<T>::kPad;

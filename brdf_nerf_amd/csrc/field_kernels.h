@@ -221,7 +221,7 @@ __device__ __forceinline__ void pp_signal(int *flag, int lane) {
 }
 
 // Weight-fragment prefetch depth of the chain GEMM (k-steps in flight per wave), chosen per kernel instantiation
-// (profiles/r02_ablation.txt session 42: the training forward gains 1-1.7 % with 6, the backward / adjoint chains 1-3 % with 2).
+// (profiles/history/r02_ablation.txt session 42: the training forward gains 1-1.7 % with 6, the backward / adjoint chains 1-3 % with 2).
 // (BN_FWD_DEPTH_TRAIN = 6, BN_BWD_DEPTH = 2: diag.h)
 // BN_GEMM_AFFINE added to a depth: the k-loop keeps ONE LDS base address per point tile and block of DEPTH k-steps (4 vector adds
 // per block instead of 4 per k-step; 4 more live registers).  Round 4, profiles/r04_ablation.txt item 18: training forward -1.4 %

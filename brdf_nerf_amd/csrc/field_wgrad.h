@@ -1,6 +1,6 @@
 // Weight-gradient kernels of the field backward (csrc/field_wgrad.hip): job descriptions built by bn_field_backward
 // (csrc/field_bwd.hip) and the launchers it calls.  The kernels live in their own translation unit because they want another
-// instruction-scheduling strategy than the chain kernels (brdf_nerf_amd/build.py FILE_FLAGS, profiles/r02_ablation.txt).
+// instruction-scheduling strategy than the chain kernels (brdf_nerf_amd/build.py FILE_FLAGS, profiles/history/r02_ablation.txt).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

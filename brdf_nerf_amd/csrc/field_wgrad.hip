@@ -5,7 +5,7 @@
 //   skinny_wgrad_kernel: the <= 4-row matrices (sigma head, learned normal, second head layers).
 // Autograd counterpart in the reference: loss.backward() through SpSBRDFNeRF.forward (models/spsbrdfnerf.py:662-757).
 // Compiled with -mllvm -amdgpu-sched-strategy=max-ilp (build.py FILE_FLAGS): -13 % on the fp16 256-tile kernel, -16 % on the
-// skinny kernel with analytic normals, -1.7 % bf16; the same strategy costs the chain kernels 1-6 % (profiles/r02_ablation.txt).
+// skinny kernel with analytic normals, -1.7 % bf16; the same strategy costs the chain kernels 1-6 % (profiles/history/r02_ablation.txt).
 #include "field_kernels.h"
 #include "field_wgrad.h"
 
@@ -194,8 +194,10 @@ BN_PH_DEFINE_READER(bn_debug_phase_read_wgrad)
 #define WG_PH_FLUSH
 #endif
 // W2_WAVES = 8: wave tile 64(n) x 128(k), 2 waves per SIMD.  W2_WAVES = 4 (wave tile 128 x 128, accumulators in the
-// AGPR half of the register file, a third fewer LDS fragment bytes per MFMA) compiles but spills in the k-loop and
-// measured 5.7x slower (profiles/r01_ablation.txt): kept only as an experiment switch.
+// AGPR half of the register file, a third fewer LDS fragment bytes per MFMA) spilled in the k-loop and measured 5.7x
+// slower in round 1 (profiles/history/r01_ablation.txt); the native-order staging of rounds 3-4 (one 32-column block per
+// wave) is written for 8 waves, so the switch no longer builds - the static_assert below says so.  The form is the open
+// candidate for this kernel's LDS time (6 fragment reads per 8 MFMAs here, 8 per 16 there): docs/next/README.md.
 #ifndef W2_WAVES
 #define W2_WAVES 8
 #endif
@@ -244,7 +246,7 @@ __device__ __forceinline__ void w2_body(const WgradJob &J, int n0, int k0, int64
   // next write.
   u32x4 ra[NC], rb[NC];
   // columns beyond a row-major operand's extent read one 16-byte block of zeros with row stride 0: the stage loop has no
-  // branch (an exec-masked load per chunk split its basic block and cost 6 % of the kernel: profiles/r01_ablation.txt)
+  // branch (an exec-masked load per chunk split its basic block and cost 6 % of the kernel: profiles/history/r01_ablation.txt)
   const T *pa = a_ok ? gA + cc : (const T *)w2_zeros, *pb = b_ok ? gB + cc : (const T *)w2_zeros;
   const int64_t sa = a_ok ? J.lda : 0, sb = b_ok ? J.ldb : 0;
   auto gload1 = [&](int64_t m, int c) {
