@@ -195,9 +195,11 @@ BN_PH_DEFINE_READER(bn_debug_phase_read_wgrad)
 #endif
 // W2_WAVES = 8: wave tile 64(n) x 128(k), 2 waves per SIMD.  W2_WAVES = 4 (wave tile 128 x 128, accumulators in the
 // AGPR half of the register file, a third fewer LDS fragment bytes per MFMA) spilled in the k-loop and measured 5.7x
-// slower in round 1 (profiles/history/r01_ablation.txt); the native-order staging of rounds 3-4 (one 32-column block per
-// wave) is written for 8 waves, so the switch no longer builds - the static_assert below says so.  The form is the open
-// candidate for this kernel's LDS time (6 fragment reads per 8 MFMAs here, 8 per 16 there): docs/next/README.md.
+// slower in round 1 (profiles/history/r01_ablation.txt); rebuilt in round 4 with the native staging generalised to two
+// 32-column blocks per wave it allocated cleanly (206 VGPRs + 256 AGPRs) and still lost, 2.727 ms against 2.397: with one
+// wave per SIMD nothing covers the stage barrier and the first fragment reads behind it (profiles/r04_ablation.txt item 13).
+// The staging below is the 8-wave form (one 32-column block per wave): the switch does not build any more - the
+// static_assert says so - and stays only as the name of that experiment.
 #ifndef W2_WAVES
 #define W2_WAVES 8
 #endif
