@@ -567,12 +567,12 @@ class FusedTrainer:
         multi = bool(model.MultiBRDF) and apply_brdf
         sun_rows = gsam_only and getattr(model, "sun_v", "none") == "analystic" and apply_brdf and (multi or kind_id == L.BN_SHADE_LAMBERT)
         if (multi and kind_id != L.BN_SHADE_LAMBERT) or sun_rows:
-            # One BRDF per sample (or a per-sample irradiance): the BRDF is a pointwise function of a sample's field outputs, so it is evaluated on the rows as
-            # they are STORED (pass-1 block, guided block: the merged set is never materialised) by ONE launch
-            # (csrc/sample_brdf.hip) that writes a copy of the rows with the padded, irradiance-weighted BRDF value in the place of
-            # the albedo; the compositing + loss + composite-backward kernels run on that copy (padding 0: it is inside bp), and ONE
-            # launch turns the copy's gradient rows into those of the field outputs (J^T in forward-mode duals, like ray_tail.hip).
-            # Rounds 3-4 went through autograd over the per-point BRDF kernels: ~20 glue launches.
+            # One BRDF per sample (or a per-sample irradiance): the BRDF is a pointwise function of a sample's field outputs, so it
+            # is evaluated on the rows as they are STORED (pass-1 block, guided block: the merged set is never materialised) by ONE
+            # launch (csrc/sample_brdf.hip) that writes a copy of the rows with the padded, irradiance-weighted BRDF value in the
+            # place of the albedo; the compositing + loss + composite-backward kernels run on that copy (padding 0: it is inside bp),
+            # and ONE launch turns the copy's gradient rows into those of the field outputs (J^T in forward-mode duals, like
+            # ray_tail.hip).  Rounds 3-4 went through autograd over the per-point BRDF kernels: ~20 glue launches.
             rgb = self._buf("rgb", (R, 3))
             det = self.repeatable_loss
             ray_loss = self._buf("ray_loss", (R,)) if det else None
