@@ -423,7 +423,9 @@ class FusedTrainer:
                    L.deterministic(), int(self.ray_offset), bool(self.keep_grads), bool(self.merge_passes), bool(apply_brdf),
                    bool(cos_irra_on), float(reg.get("hs", 0)), bool(self.sanitize_grads), float(reg.get("nr_an", 0)),
                    float(reg.get("nr_lr", 0)), bool(gsam_only), self._noise_f32() != 0.0, float(reg.get("nr_spv", 0)),
-                   bool(self.repeatable_loss))
+                   bool(self.repeatable_loss),
+                   # model switches that change WHICH launches the step consists of (they are attributes, not part of the head set)
+                   str(getattr(model, "sun_v", "none")), bool(model.MultiBRDF), str(args.data))
             ent = self._graphs.get(sig)
             if ent is not None:
                 self._graphs.move_to_end(sig)

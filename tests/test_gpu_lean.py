@@ -996,12 +996,35 @@ def test_lean_step_sun_visibility_pass_matches_general_step(name, multi):
             worst = max(worst, e)
             assert e <= 5e-4, (name, step, e)
         assert len(tb._graphs) >= 1, "the lean step was not captured into a HIP graph"
-        # the sun pass matters: without it the rgb differs
-        rgb_sun = rgb_b.clone()                 # (the step returns its persistent buffer)
-        mb.sun_v = "none"
-        _, rgb0 = tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
-        mb.sun_v = "analystic"
-        assert float((rgb0 - rgb_sun).abs().max()) > 1e-3
+        # the sun pass matters, and switching it off on the SAME trainer must not replay the graph captured with it (sun_v is a model
+        # attribute: it has to be part of the step's signature): the step without the sun pass against the general step without it
+        n_graphs = len(tb._graphs)
+        ma.sun_v = mb.sun_v = "none"
+        for again in range(2):
+            tb.flat_param.copy_(ta.flat_param)
+            tb.exp_avg.copy_(ta.exp_avg)
+            tb.exp_avg_sq.copy_(ta.exp_avg_sq)
+            draws = [Fn.rng_uniform(tb.state, 1, R * S).view(R, S), Fn.rng_uniform(tb.state, 2, R * G).view(R, G),
+                     Fn.rng_uniform(tb.state, 3, R * G).view(R, G)]
+            with Replay(draws) as rp:
+                _, rgb_a0 = ta.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+                assert rp.draws == []
+            # (the same draws WITH the sun pass, for the "it matters" half: the sun stream's draws are in-kernel on this side)
+            _, rgb_b0 = tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+            assert float((rgb_a0 - rgb_b0).abs().max()) <= 2e-5, (name, "a stale graph with the sun pass was replayed", again)
+        assert len(tb._graphs) == n_graphs + 1
+        ma.sun_v = mb.sun_v = "analystic"
+        tb.flat_param.copy_(ta.flat_param)
+        tb.exp_avg.copy_(ta.exp_avg)
+        tb.exp_avg_sq.copy_(ta.exp_avg_sq)
+        draws_sun = [Fn.rng_uniform(tb.state, 1, R * S).view(R, S), Fn.rng_uniform(tb.state, 2, R * G).view(R, G),
+                     Fn.rng_uniform(tb.state, 3, R * G).view(R, G)]
+        ma.sun_v = "none"
+        with Replay(draws_sun) as rp:
+            _, rgb_nosun = ta.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+        ma.sun_v = "analystic"
+        _, rgb_sun = tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **flags)
+        assert float((rgb_nosun - rgb_sun).abs().max()) > 1e-3      # same draws, same parameters: only the sun pass differs
         with pytest.raises(NotImplementedError):
             tb.step(rays, rgbs, valid_depth=valid, depths=depths, depth_std=dstd, **dict(flags, gsam_only=False))
         diag(f"lean step with the sun pass {name} MultiBRDF={int(multi)}: worst flat-gradient difference over 4 steps {worst:.2e} of the largest entry")
