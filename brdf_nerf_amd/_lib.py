@@ -148,10 +148,10 @@ _SIGS = {
     "bn_lambert_tail": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, C.c_int32, C.c_int32, C.c_int64, fptr, fptr, C.c_int64, fptr,
                                   C.c_int64, fptr, C.c_int64, fptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, fptr, fptr,
                                   C.c_int32, fptr, fptr, fptr, fptr, fptr, fptr, fptr, fptr]),
-    "bn_sample_brdf_forward": (C.c_int, [fptr, fptr, fptr, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, fptr,
-                                         C.c_int32, fptr]),
-    "bn_sample_brdf_backward": (C.c_int, [fptr, fptr, fptr, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, fptr,
-                                          C.c_int32, fptr, fptr]),
+    "bn_sample_brdf_forward": (C.c_int, [fptr, fptr, fptr, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                         fptr, C.c_int32, fptr]),
+    "bn_sample_brdf_backward": (C.c_int, [fptr, fptr, fptr, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                          fptr, C.c_int32, fptr, fptr]),
     "bn_fold_heads": (C.c_int, [fptr, fptr]),
     "bn_unfold_heads": (C.c_int, [fptr, fptr]),
     "bn_adam_multi": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int32, fptr, fptr, fptr, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -150,8 +150,8 @@ template <int KIND, bool BWD> __global__ __launch_bounds__(128) void sample_brdf
   }
 }
 
-int check_args(const bn_shade_desc *desc, const float *X, const float *rays, int64_t ray_stride, int32_t sun_col, int64_t N, int64_t n1,
-               int32_t S1, int32_t S2, int32_t stride, const char *what) {
+int check_args(const bn_shade_desc *desc, const float *X, const float *rays, int64_t R, int64_t ray_stride, int32_t sun_col, int64_t N,
+               int64_t n1, int32_t S1, int32_t S2, int32_t stride, const char *what) {
   BN_REQUIRE(desc && X && rays && N > 0, "%s: null argument", what);
   const bn_shade_desc &q = *desc;
   BN_REQUIRE(q.kind >= BN_SHADE_LAMBERT && q.kind <= BN_SHADE_MICROFACET, "%s: kind=%d", what, q.kind);
@@ -166,8 +166,9 @@ int check_args(const bn_shade_desc *desc, const float *X, const float *rays, int
   BN_REQUIRE(q.kind != BN_SHADE_MICROFACET || q.ch_p0 >= 4, "%s: microfacet needs the roughness channel", what);
   BN_REQUIRE(q.kind != BN_SHADE_HAPKE || q.ch_p0 >= 4 || (q.shell >= 1 && q.shell <= 3), "%s: Hapke without b needs shell_hapke in {1,2,3}", what);
   BN_REQUIRE(ray_stride >= 6 && (sun_col < 0 || sun_col + 3 <= ray_stride), "%s: ray stride %lld, sun column %d", what, (long long)ray_stride, sun_col);
-  BN_REQUIRE(n1 >= 0 && n1 <= N && S1 > 0 && (n1 == N || S2 > 0) && n1 % S1 == 0 && (n1 == N || (N - n1) % S2 == 0),
-             "%s: %lld rows do not split into blocks of %d / %d samples per ray at %lld", what, (long long)N, S1, S2, (long long)n1);
+  // every row's ray exists: the blocks are R rays of S1 (and, behind row n1, R rays of S2) samples each
+  BN_REQUIRE(R > 0 && S1 > 0 && n1 == R * (int64_t)S1 && (n1 == N || (S2 > 0 && N - n1 == R * (int64_t)S2)),
+             "%s: %lld rows do not split into %lld rays of %d (+ %d) samples at row %lld", what, (long long)N, (long long)R, S1, S2, (long long)n1);
   return 0;
 }
 
@@ -186,9 +187,10 @@ template <bool BWD> int launch(const SampleArgs &a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int bn_sample_brdf_forward(const bn_shade_desc *desc, const float *X, const float *rays, int64_t ray_stride, int32_t sun_col,
-                                      int64_t N, int64_t n1, int32_t S1, int32_t S2, float *B, int32_t b_stride, void *stream) {
-  if (int e = check_args(desc, X, rays, ray_stride, sun_col, N, n1, S1, S2, b_stride, "sample_brdf_forward")) return e;
+extern "C" int bn_sample_brdf_forward(const bn_shade_desc *desc, const float *X, const float *rays, int64_t R, int64_t ray_stride,
+                                      int32_t sun_col, int64_t N, int64_t n1, int32_t S1, int32_t S2, float *B, int32_t b_stride,
+                                      void *stream) {
+  if (int e = check_args(desc, X, rays, R, ray_stride, sun_col, N, n1, S1, S2, b_stride, "sample_brdf_forward")) return e;
   BN_REQUIRE(B, "sample_brdf_forward: null output");
   SampleArgs a;
   a.d = *desc; a.X = X; a.rays = rays; a.ray_stride = ray_stride; a.sun_col = sun_col; a.N = N; a.n1 = n1; a.S1 = S1; a.S2 = S2 > 0 ? S2 : 1;
@@ -196,10 +198,10 @@ extern "C" int bn_sample_brdf_forward(const bn_shade_desc *desc, const float *X,
   return launch<false>(a, (hipStream_t)stream);
 }
 
-extern "C" int bn_sample_brdf_backward(const bn_shade_desc *desc, const float *X, const float *rays, int64_t ray_stride, int32_t sun_col,
-                                       int64_t N, int64_t n1, int32_t S1, int32_t S2, const float *dB, int32_t b_stride, float *dX,
-                                       void *stream) {
-  if (int e = check_args(desc, X, rays, ray_stride, sun_col, N, n1, S1, S2, b_stride, "sample_brdf_backward")) return e;
+extern "C" int bn_sample_brdf_backward(const bn_shade_desc *desc, const float *X, const float *rays, int64_t R, int64_t ray_stride,
+                                       int32_t sun_col, int64_t N, int64_t n1, int32_t S1, int32_t S2, const float *dB, int32_t b_stride,
+                                       float *dX, void *stream) {
+  if (int e = check_args(desc, X, rays, R, ray_stride, sun_col, N, n1, S1, S2, b_stride, "sample_brdf_backward")) return e;
   BN_REQUIRE(dB && dX, "sample_brdf_backward: null argument");
   SampleArgs a;
   a.d = *desc; a.X = X; a.rays = rays; a.ray_stride = ray_stride; a.sun_col = sun_col; a.N = N; a.n1 = n1; a.S1 = S1; a.S2 = S2 > 0 ? S2 : 1;

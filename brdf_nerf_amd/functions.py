@@ -686,12 +686,12 @@ def sample_brdf(desc, X, rays, n1, S1, S2, out, backward_of=None, sun_col=8):
     R = rays.shape[0]
     assert n1 == R * S1 and (n1 == N or N - n1 == R * S2), (N, n1, R, S1, S2)
     if backward_of is None:
-        L.check(L.lib().bn_sample_brdf_forward(C.byref(desc), _p(X), _p(rays), rays.stride(0), sun_col, N, n1, S1, S2, _p(out),
+        L.check(L.lib().bn_sample_brdf_forward(C.byref(desc), _p(X), _p(rays), R, rays.stride(0), sun_col, N, n1, S1, S2, _p(out),
                                                out.shape[1], _stream()), "bn_sample_brdf_forward")
     else:
         dB = backward_of
         assert dB.is_contiguous() and dB.dtype == torch.float32 and dB.shape[0] == N and out.shape[1] == Cc
-        L.check(L.lib().bn_sample_brdf_backward(C.byref(desc), _p(X), _p(rays), rays.stride(0), sun_col, N, n1, S1, S2, _p(dB),
+        L.check(L.lib().bn_sample_brdf_backward(C.byref(desc), _p(X), _p(rays), R, rays.stride(0), sun_col, N, n1, S1, S2, _p(dB),
                                                 dB.shape[1], _p(out), _stream()), "bn_sample_brdf_backward")
     return out
 

@@ -425,7 +425,11 @@ class FusedTrainer:
                    float(reg.get("nr_lr", 0)), bool(gsam_only), self._noise_f32() != 0.0, float(reg.get("nr_spv", 0)),
                    bool(self.repeatable_loss),
                    # model switches that change WHICH launches the step consists of (they are attributes, not part of the head set)
-                   str(getattr(model, "sun_v", "none")), bool(model.MultiBRDF), str(args.data))
+                   str(getattr(model, "sun_v", "none")), bool(model.MultiBRDF), str(args.data),
+                   # and the host-side constants baked into a captured launch's arguments
+                   int(args.n_samples), int(args.guided_samples), float(args.std_range), float(model.rgb_padding),
+                   int(getattr(args, "funcH", 1)), float(getattr(args, "hpk_scl", 1.0)), float(getattr(args, "fresnel_f0", 0.04)),
+                   int(getattr(args, "shell_hapke", 0)), tuple(float(b) for b in self.betas), float(self.eps), float(self.wd))
             ent = self._graphs.get(sig)
             if ent is not None:
                 self._graphs.move_to_end(sig)

@@ -448,7 +448,7 @@ int bn_lambert_tail(const float *z, const int64_t *sort_idx, const float *out1, 
 /* Per-SAMPLE shading on the field-output rows as they are stored, one launch forward and one backward: --MultiBRDF
  * (models/spsbrdfnerf.py:289-307, 350-352: every sample is shaded by its own BRDF, the shaded colours are composited) and the
  * per-sample irradiance of the sun pass (:265-273).  X [N][C]: rows [0, n1) belong to ray row / S1, rows [n1, N) to ray
- * (row - n1) / S2 (the [pass-1 | guided] blocks of a training step; n1 == N: one block).  view = -rays[ray][3:6], sun =
+ * (row - n1) / S2 (the [pass-1 | guided] blocks of a training step, n1 == R S1 and N - n1 == R S2 for the R rays; n1 == N: one block).  view = -rays[ray][3:6], sun =
  * rays[ray][sun_col : +3] (sun_col < 0: (1, 1, 1)); the normal, albedo (channels 0-2) and parameter channels are read per row as
  * bn_shade_desc names them (its loss fields unused).  kind LAMBERT: the "BRDF" is the albedo itself.  irradiance: |sun_z| with
  * cos_irradiance and a normal channel, else desc->irr[row * irr_stride] - here per ROW, not per ray - when given, else 1.
@@ -457,11 +457,11 @@ int bn_lambert_tail(const float *z, const int64_t *sort_idx, const float *out1, 
  *   backward: dX[row] = J^T dB[row][0:3] on the normal / albedo / parameter channels + dB[row][3] on sigma
  *             (+ dB[row][4:] on the channels behind it when b_stride == C); every channel of dX is written.
  * The derivative conventions are those of the per-point BRDF backward entry points above: torch autograd's. */
-int bn_sample_brdf_forward(const bn_shade_desc *desc, const float *X, const float *rays, int64_t ray_stride, int32_t sun_col,
-                           int64_t N, int64_t n1, int32_t S1, int32_t S2, float *B, int32_t b_stride, void *stream);
-int bn_sample_brdf_backward(const bn_shade_desc *desc, const float *X, const float *rays, int64_t ray_stride, int32_t sun_col,
-                            int64_t N, int64_t n1, int32_t S1, int32_t S2, const float *dB, int32_t b_stride, float *dX,
-                            void *stream);
+int bn_sample_brdf_forward(const bn_shade_desc *desc, const float *X, const float *rays, int64_t R, int64_t ray_stride,
+                           int32_t sun_col, int64_t N, int64_t n1, int32_t S1, int32_t S2, float *B, int32_t b_stride, void *stream);
+int bn_sample_brdf_backward(const bn_shade_desc *desc, const float *X, const float *rays, int64_t R, int64_t ray_stride,
+                            int32_t sun_col, int64_t N, int64_t n1, int32_t S1, int32_t S2, const float *dB, int32_t b_stride,
+                            float *dX, void *stream);
 
 /* Folding of the linear feats layer into the heads' first layers (bn_field_desc.fold_feats) and the chain rule back, as
  * two launches of exact-fp32 MFMA tiles:

@@ -931,7 +931,7 @@ def test_sample_brdf_kernel_matches_per_point_functions(kind, heads, rhoc_is_alb
         Fn.sample_brdf(d, X, rays, n1 + 1, S1, S2, B)
     import ctypes as C_
     lib, vp = L.lib(), lambda t: C_.c_void_p(t.data_ptr())
-    call = lambda dd, n1_, s1_, stride: lib.bn_sample_brdf_forward(C_.byref(dd), vp(X), vp(rays), rays.stride(0), 8, N, n1_, s1_, S2, vp(B), stride, None)
+    call = lambda dd, n1_, s1_, stride: lib.bn_sample_brdf_forward(C_.byref(dd), vp(X), vp(rays), R, rays.stride(0), 8, N, n1_, s1_, S2, vp(B), stride, None)
     assert call(d, n1 + 1, S1, Cb) != 0 and b"do not split" in lib.bn_last_error()
     assert call(d, n1, S1, 5) != 0 and b"row stride" in lib.bn_last_error()
     bad = L.ShadeDesc.from_buffer_copy(d)
@@ -940,7 +940,7 @@ def test_sample_brdf_kernel_matches_per_point_functions(kind, heads, rhoc_is_alb
     bad = L.ShadeDesc.from_buffer_copy(d)
     bad.kind = 9
     assert call(bad, n1, S1, Cb) != 0 and b"kind" in lib.bn_last_error()
-    assert lib.bn_sample_brdf_backward(C_.byref(d), vp(X), vp(rays), rays.stride(0), 8, N, n1, S1, S2, None, Cb, vp(dX), None) != 0
+    assert lib.bn_sample_brdf_backward(C_.byref(d), vp(X), vp(rays), R, rays.stride(0), 8, N, n1, S1, S2, None, Cb, vp(dX), None) != 0
 
 
 @pytest.mark.parametrize("name,multi", [("rpv111_nan", False), ("hapke_bct", False), ("rpv111_nan", True), ("microfacet", True),
